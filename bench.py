@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec of Motion_Latent_Model.forward on the BASELINE.json clip
+(32 frames x 2048 mesh points x 512x512 video, 4096 surface samples, batch 1, bf16) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward of the hot path over one 32-frame clip per GPU, inputs resident in HBM.
+Multi-GPU: clips are independent: every rank runs its own clip with no collective
+inside the forward; the per-clip [T,N,3] offsets are all-gathered at the end of each step.  Weak scaling.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+WORKLOAD = dict(B=1, T=32, N=2048, S=4096, HW=512, frames=32)   # BASELINE.json configs[1]
+
+
+def algorithmic_flops(B, T, N, S, d=768, K=64, g=16, n_layer=16, pcd_layers=4, dino_depth=12):
+    """Forward FLOPs (2*MAC) of the reference's arithmetic, SURVEY.md 8(d) (incl. its per-frame recompute
+    of the decoder point features): 7.527 TFLOP for the c2 clip."""
+    lin = lambda m, i, o: 2.0 * m * i * o
+    att = lambda b, q, k: 4.0 * b * (d // 64) * q * k * 64
+    blk = lambda m: lin(m, d, 3 * d) + lin(m, d, d) + 2 * lin(m, d, 4 * d)
+    L = 4 + K + g * g
+    f = B * (lin(S, 51, d) + lin(S, d + 6, d))
+    f += B * (2 * lin(K, d, d) + 2 * lin(S, d, d) + att(1, K, S) + 2 * lin(K, d, 4 * d))
+    f += pcd_layers * B * (blk(K) + att(1, K, K))
+    f += B * T * (lin(g * g, 588, d) + dino_depth * (blk(g * g + 1) + att(1, g * g + 1, g * g + 1)))
+    f += (n_layer // 2) * B * (blk(T * L) + att(1, T * L, T * L))
+    f += (n_layer // 2) * B * (blk(T * L) + T * att(1, L, L))
+    f += B * T * (2 * lin(N, d, d) + 2 * lin(K, d, d) + 2 * lin(N, d, 4 * d) + att(1, N, K))
+    f += B * T * (lin(N, d, d) + lin(N, d, 3))
+    f += B * T * (lin(N, 51, d) + lin(N, d + 6, d))
+    return f
+
+
+def build_model(device, frames):
+    import motion324_amd as m
+    from motion324_amd import synth
+    cfg = synth.make_config(frames=frames)
+    model = m.Motion_Latent_Model(cfg)
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.Dims(frames=frames), seed=0).items()}
+    model.load_state_dict(sd, strict=False)
+    return model.eval().to(device), sd
+
+
+def cpu_baseline(sd, sample_np, frames):
+    """The CPU oracle (fp32 restatement of the reference path) timed on this host: ONE forward of the
+    same 32-frame clip, all cores, no warm-up (about 10-30 s of CPU work)."""
+    from oracle import ref_forward as oracle
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sample = oracle.to_torch(sample_np)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = oracle.forward(sd, sample, frames=frames)["pcd_moved"]
+    dt = time.perf_counter() - t0
+    T = sample["rgb_video"].shape[1]
+    return {"value": round(T / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 forward of the full {T}-frame clip (fp32, torch CPU ops, {threads} threads, no warm-up), {dt:.1f} s"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to benchmark")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import motion324_amd as m
+    from motion324_amd import synth
+    from motion324_amd.timing import Recorder
+    w = WORKLOAD
+    model, sd = build_model(dev, w["frames"])
+    # every rank works on its own clip: same shape, different seed
+    sample_np = synth.synth_inputs(w["B"], w["T"], w["N"], w["S"], w["HW"], seed=1 + rank)
+    sample = {k: torch.from_numpy(v).to(dev) for k, v in sample_np.items()}
+    m.set_precision(args.precision)
+
+    def step():
+        with torch.no_grad():
+            out = model(sample).pcd_moved
+        if world > 1:
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            torch.distributed.all_gather(gathered, out)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    rec = Recorder()
+    t0 = time.perf_counter()
+    with rec:
+        for _ in range(args.steps):
+            out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        frames_per_step = world * w["B"] * w["T"]
+        ms = dt / args.steps * 1e3
+        value = frames_per_step * args.steps / dt
+        summ = rec.summary()
+        dom = max(summ, key=lambda k: summ[k]["total_ms"])
+        d = summ[dom]
+        peak = PEAK_BF16_TFLOPS if dom.endswith("bf16") else PEAK_F32_TFLOPS
+        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": d["launches"] // args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
+                "by_kernel": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 3),
+                                  "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
+        flops = algorithmic_flops(w["B"], w["T"], w["N"], w["S"])
+        line = {
+            "metric": "frames/sec (32-frame clip, 2048 pts, 512x512)", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "Motion_Latent_Model.forward inference, B=1 x 32 frames x 2048 points x 512x512 video, "
+                                   "4096 surface samples, training.frames=32, random-init weights (one clip per GPU)",
+                       "parallelism": f"clip-parallel x{world}"},
+            "end_to_end_tflops": round(flops * world * args.steps / dt / 1e12, 1),
+            "end_to_end_frac_of_bf16_peak": round(flops * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, ref = cpu_baseline(sd, sample_np, w["frames"])
+            line["cpu_baseline"] = cb
+            err = float((out.double().cpu() - ref.double()).norm() / ref.double().norm())
+            line["rel_err_vs_cpu_oracle"] = round(err, 6)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

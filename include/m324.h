@@ -1,0 +1,160 @@
+/*
+ * libm324 -- C ABI of the MI355X-native (gfx950) kernels behind Motion324's per-frame
+ * motion-prediction hot path (Motion_Latent_Model.forward).
+ *
+ * The reference has no FFI of its own on this path: its arithmetic is issued through torch.nn,
+ * xformers' flash-attention op and the torch.hub DINOv2 module.  Each entry point below states
+ * the reference call site it replaces (paths relative to the reference repo).  A maintainer binds
+ * them with ctypes; motion324_amd/lib.py is that binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (PyTorch
+ *     allocations in practice); the library allocates nothing persistent.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it.
+ *   - return 0 on success, negative m324_status on failure; m324_last_error() gives the text of
+ *     the calling thread's last failure.  Nothing throws or aborts across the boundary.
+ *   - dtype codes: M324_F32 = fp32 "parity" arithmetic (f32 MFMA, exact), M324_BF16 = bf16 operands
+ *     with fp32 accumulation ("speed" mode, what the reference runs under torch.autocast(bf16)).
+ *   - matrices are row-major; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef M324_H
+#define M324_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { M324_OK = 0, M324_ERR_INVALID = -1, M324_ERR_HIP = -2, M324_ERR_UNSUPPORTED = -3 } m324_status;
+typedef enum { M324_F32 = 0, M324_BF16 = 1 } m324_dtype;
+typedef enum { M324_ACT_NONE = 0, M324_ACT_GELU = 1 } m324_act;
+
+/* ABI version of this header (bumped on any signature change). */
+int m324_abi_version(void);
+/* Copies the calling thread's last error text into buf (NUL-terminated); returns its length. */
+int m324_last_error(char* buf, int n);
+/* Fills name with the device's gcnArchName ("gfx950..."), returns CU count or negative status. */
+int m324_device_info(char* name, int n);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_gemm: C = epilogue(A[M,K] . W[N,K]^T)  -- every nn.Linear / the patch Conv2d on the path.
+ *   replaces: F.linear in model/transformer.py:112-116,182-183,73-78 (to_q/to_k/to_v/to_qkv/fc/MLP),
+ *             model/Pcd_motion.py:175,284,338-340 (point_embed.mlp, point_normal_rgb_proj, head),
+ *             DINOv2 patch_embed.proj / qkv / proj / fc1 / fc2 (model/image_encoder/dino/model_dino.py:160-170,
+ *             174-231,338-354).
+ *   epilogue, in this order:  v = acc (+ bias[n]) ; v = gelu_erf(v) if act ; v *= gamma[n] ;
+ *                             v += residual[(m % res_rows) * ldr + n] ; store as out_dtype at
+ *                             C[out_row(m) * ldc + n],  out_row(m) = (m / row_gin) * row_gout + m % row_gin + row_off.
+ *   constraints: K % 64 == 0 (bf16) / K % 32 == 0 (f32) -- pad K with zeros; A, W rows 16-byte aligned.
+ *   in_dtype selects the MFMA: bf16 -> v_mfma_f32_32x32x16_bf16, f32 -> v_mfma_f32_32x32x2_f32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* A;  long lda;
+    const void* W;  long ldw;
+    void* C;        long ldc;
+    int M, N, K;
+    int in_dtype, out_dtype;
+    const float* bias;
+    int act;
+    const float* gamma;
+    const float* residual; long ldr; int res_rows;   /* res_rows <= 0 -> M */
+    int row_gin, row_gout, row_off;                  /* row_gin <= 0 -> identity */
+} m324_gemm_args;
+int m324_gemm(const m324_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_layernorm: y = (x - mean) * rsqrt(var + eps) * w (+ b) over the last dim of fp32 x.
+ *   replaces: nn.LayerNorm at model/transformer.py:345-346,357,400,411 (bias=False, eps 1e-5),
+ *             model/Pcd_motion.py:326,337 and DINOv2 norm1/norm2/norm (eps 1e-6, with bias).
+ *   input row r is read from x[in_row(r) * ldx], in_row(r) = (r / gin) * gout + r % gin + off
+ *   (gin <= 0 -> identity): lets the decoder normalise the 64 latent tokens of every frame in place
+ *   (Pcd_motion.py:520, transformer.py:368-369) without a gather copy.
+ *   C % 4 == 0, C <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int m324_layernorm(const float* x, long ldx, const float* w, const float* b, float eps,
+                   void* y, long ldy, int out_dtype, int rows, int C,
+                   int gin, int gout, int off, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_qkv_split: head-major operands for m324_attention from token-major projections.
+ *   replaces: rearrange "b l (nh dh) -> b l nh dh" + RMSNorm(q), RMSNorm(k)
+ *             (model/transformer.py:128-132,200-207; RMSNorm :36-42, eps 1e-5, fp32 inside).
+ *   q_src/k_src/v_src: [B*L, *] rows of `dtype` with leading dims ldq/ldk/ldv (any may be NULL);
+ *   row b*L + l, columns h*64 .. h*64+63.  q_w / k_w: RMSNorm weights [64] or NULL (DINO: no qk-norm).
+ *   Outputs (same dtype): Q[B,H,L,64], K[B,H,L,64], Vt[B,H,64,Lp] with Lp = round_up(L, 64);
+ *   Vt columns L..Lp-1 are written as zeros.  head_dim is fixed at 64 (config d_head).
+ * ------------------------------------------------------------------------------------------ */
+int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, const void* v_src, long ldv,
+                   const float* q_w, const float* k_w, float eps,
+                   void* Q, void* K, void* Vt, int B, int L, int H, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_attention: O = softmax(Q K^T * scale) V, flash-style (no L x L matrix in HBM).
+ *   replaces: xformers.ops.memory_efficient_attention(q,k,v, op=flash) at model/transformer.py:134-139,
+ *             209-214 and DINOv2 self-attention (model_dino.py:200-222); scale = 64^-0.5.
+ *   Q[Bq,H,Lq,64] (q_bstride elements between batches; 0 = one query set shared by every batch, as the
+ *   decoder does with the mesh points, Pcd_motion.py:534-560), K[B,H,Lk,64], Vt[B,H,64,Lkp]
+ *   (Lkp = round_up(Lk,64), zero padded).  O[B, Lq, H*64] token-major (ldo = row stride), same dtype.
+ * ------------------------------------------------------------------------------------------ */
+int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo,
+                   int B, int H, int Lq, int Lk, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_patchify: video frames -> DINOv2 patch rows.
+ *   replaces: permute + F.interpolate(bilinear, align_corners=False) (model/Pcd_motion.py:470-472),
+ *             ImageNet normalisation (model/image_encoder/dinov2.py:78-80) and the im2col of the
+ *             k=s=14 patch convolution (model_dino.py:160-170).
+ *   video [F, Hin, Win, 3] fp32 in [0,1]; out [F * g*g, Kp] (dtype), g = size / patch, column
+ *   c*patch*patch + ky*patch + kx (the Conv2d weight's flattening), columns 3*patch*patch..Kp-1 zero.
+ * ------------------------------------------------------------------------------------------ */
+int m324_patchify(const float* video, int F, int Hin, int Win, int size, int patch,
+                  void* out, int Kp, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_point_encode: Fourier features of points, PointEmbed.embed (model/Pcd_motion.py:178-182).
+ *   xyz [P,3] fp32 -> out [P, ld] (dtype): [sin(xyz . basis) (24) | cos (24) | xyz (3) | zeros to 64];
+ *   basis = 2^j * pi, j = 0..7 per axis (:164-173).  Always evaluated in fp32 (the reference's bf16
+ *   einsum loses the phase).
+ * m324_point_concat: writes [normal | rgb | zeros] into columns C..Kp-1 of feat [P, Kp] whose first C
+ *   columns already hold point_embed.mlp's output -- the torch.cat at Pcd_motion.py:459,551-553.
+ * ------------------------------------------------------------------------------------------ */
+int m324_point_encode(const float* xyz, int P, void* out, long ld, int dtype, void* stream);
+int m324_point_concat(const float* normal, const float* rgb, int P, void* feat, int C, int Kp,
+                      int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_dino_cls_rows: x[f*rows_per_frame + 0, :] = cls + pos[0]  (model_dino.py:127-131).
+ * ------------------------------------------------------------------------------------------ */
+int m324_dino_cls_rows(const float* cls, const float* pos0, float* x, int F, int rows_per_frame, int C,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_assemble_tokens: trunk input [B,T,4+K+P,C] fp32 =
+ *      LN_in( [special(t) (4) | mesh_feat[b] (K) | LN_dino(dino_x[b,t,1+p]) + pos_embed[t*P+p] (P)] )
+ *   replaces: DINOv2 final norm + CLS drop (model_dino.py:645, dinov2.py:99-103), pos-embed add
+ *             (model/Pcd_motion.py:477-493), token stacking (:495-507) and transformer_input_layernorm (:509).
+ *   dino_x [B*T, 1+P, C] fp32 (pre final-norm); dino_w/dino_b final-norm affine, eps_dino (1e-6);
+ *   pos [T*P, C]; sp0/spr [4,C]; mesh [B,K,C]; ln_w [C], eps_in (1e-5).
+ * ------------------------------------------------------------------------------------------ */
+int m324_assemble_tokens(const float* dino_x, const float* dino_w, const float* dino_b, float eps_dino,
+                         const float* pos, const float* sp0, const float* spr, const float* mesh,
+                         const float* ln_w, float eps_in, float* out,
+                         int B, int T, int K, int P, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_linear_n3: out[M,3] fp32 = A[M,K] . W[3,K]^T + bias -- the xyz regression head's last layer
+ *   (shared_mlp_output.3, model/Pcd_motion.py:340,561).  W, bias fp32; A in `dtype`.
+ * ------------------------------------------------------------------------------------------ */
+int m324_linear_n3(const void* A, long lda, const float* W, const float* bias, float* out,
+                   int M, int K, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_mse: *out = weight * mean((pred - target)^2) over n fp32 elements -- model/loss.py:59-61.
+ *   `partial` is a caller-provided fp32 scratch of >= 1024 elements.
+ * ------------------------------------------------------------------------------------------ */
+int m324_mse(const float* pred, const float* target, long n, float weight, float* partial, float* out,
+             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M324_H */

@@ -1,0 +1,265 @@
+"""Motion_Latent_Model on MI355X: the reference's model API, executed by libm324 HIP kernels.
+
+Drop-in for the reference's model/Pcd_motion.py::Motion_Latent_Model (:268-598): same constructor
+(``config`` with the keys of configs/dyscene.yaml), same parameter / buffer names and shapes
+(state-dict compatible), same ``forward(sample) -> EasyDict{input_data, pcd_moved[, loss_metrics]}``.
+Select it from the reference's own callers with ``model.class_name=motion324_amd.Pcd_motion.Motion_Latent_Model``
+(train.py:84-86, scripts/inference_with_video_mesh.py:309-311).
+
+Precision follows the caller exactly like the reference: under ``torch.autocast('cuda', bf16)`` the
+bf16-operand / fp32-accumulate kernels run; without autocast the fp32 parity kernels run.  The point
+Fourier embedding is always evaluated in fp32 (the reference's bf16 einsum destroys the phase).
+
+There is no CPU path: inputs must live on a HIP device and libm324.so must be built.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .easydict import EasyDict as edict
+from .image_encoder import DINO_EPS, DinoEncoder
+from .lib import ACT_GELU, M324Error
+from .loss import MSELossComputer
+from .prepared import Prepared, compute_dtype, pad_k
+from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
+
+DECODE_ROWS = 1 << 17     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class PointEmbed(nn.Module):
+    """Fourier point embedding (reference Pcd_motion.py:157-187)."""
+
+    def __init__(self, hidden_dim=48, dim=768):
+        super().__init__()
+        if hidden_dim != 48:
+            raise NotImplementedError("m324_point_encode implements the reference's 48 Fourier features")
+        self.embedding_dim = hidden_dim
+        e = torch.pow(2, torch.arange(hidden_dim // 6)).float() * torch.pi
+        z = torch.zeros(hidden_dim // 6)
+        self.register_buffer("basis", torch.stack([torch.cat([e, z, z]), torch.cat([z, e, z]), torch.cat([z, z, e])]))
+        self.mlp = nn.Linear(hidden_dim + 3, dim)
+
+
+def generate_pos_embed(T: int, H: int, W: int, embed_dim: int) -> torch.Tensor:
+    """3-D Fourier position table [1, T*H*W, embed_dim] (reference Pcd_motion.py:230-266); host-side constant."""
+    def axis(n):
+        a = torch.arange(n, dtype=torch.float32)
+        return 2 * (a / (n - 1)) - 1 if n > 1 else torch.tensor([0.0], dtype=torch.float32)
+    t, h, w = torch.meshgrid(axis(T), axis(H), axis(W), indexing="ij")
+    pos = torch.stack([t, h, w], dim=-1).unsqueeze(-1)
+    freq = (2.0 ** torch.linspace(0.0, 7.0, embed_dim // 6)).view(1, 1, 1, 1, -1)
+    pos = pos * freq
+    return torch.cat([torch.sin(pos), torch.cos(pos)], dim=-1).reshape(1, -1, embed_dim)
+
+
+def resize_pos_embed(posemb, src_shape, target_shape):
+    """Trilinear resize of the position table (reference Pcd_motion.py:221-228); cached per clip length."""
+    posemb = posemb.reshape(1, src_shape[0], src_shape[1], src_shape[2], -1).permute(0, 4, 1, 2, 3)
+    posemb = F.interpolate(posemb, size=target_shape, mode="trilinear", align_corners=False)
+    return posemb.permute(0, 2, 3, 4, 1).reshape(1, target_shape[0] * target_shape[1] * target_shape[2], -1)
+
+
+class Motion_Latent_Model(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        model_cfg = _get(config, "model")
+        train_cfg = _get(config, "training")
+        self.feat_dim = _get(model_cfg, "feat_dim")
+        vcfg = _get(model_cfg, "video_encoder")
+        tcfg = _get(vcfg, "transformer")
+        icfg = _get(vcfg, "image_tokenizer")
+        use_qk_norm = _get(tcfg, "use_qk_norm", True)
+        d_model, d_head = _get(tcfg, "d"), _get(tcfg, "d_head")
+        if self.feat_dim != d_model:
+            raise NotImplementedError("feat_dim must equal transformer.d (as in configs/dyscene.yaml)")
+        if d_model % 6 != 0 or d_model % 4 != 0 or d_model > 1024:
+            raise NotImplementedError("transformer.d must be a multiple of 12 and <= 1024")
+
+        # _init_video_patchify (reference :346-370)
+        self.image_size = _get(icfg, "image_size", 224)
+        self.video_length = _get(train_cfg, "frames")
+        self.patch_size = _get(icfg, "patch_size", 14)
+        self.patch_length = _get(icfg, "patch_length", 1)
+        self.embed_dim = d_model
+        self.num_patches_h = self.num_patches_w = self.image_size // self.patch_size
+        self.num_patches_t = self.video_length // self.patch_length
+        self.latent_length, self.latent_size = self.num_patches_t, self.num_patches_h
+        self.register_buffer("pos_embed", generate_pos_embed(self.latent_length, self.latent_size, self.latent_size,
+                                                             self.embed_dim))
+        self.drop_rate = float(_get(tcfg, "drop_rate", 0.1))
+        self.pos_drop = nn.Dropout(p=self.drop_rate)
+
+        self.point_embed = PointEmbed(dim=d_model)
+        self.point_normal_rgb_proj = nn.Linear(d_model + 3 + 3, d_model)
+        self.point_normal_rgb_proj.apply(init_weights)
+
+        self.num_learnable_tokens = _get(model_cfg, "tokens")
+        self.learnable_tokens = nn.Parameter(torch.randn(1, self.num_learnable_tokens, d_model))
+        self.special_token_0 = nn.Parameter(torch.randn(1, 4, d_model))
+        self.special_token_rest = nn.Parameter(torch.randn(1, 4, d_model))
+
+        self.encoder_cross_attn = QK_Norm_CrossAttentionBlock(dim=d_model, head_dim=d_head, kv_dim=d_model,
+                                                              use_qk_norm=use_qk_norm)
+        self.points_transformer_blocks = nn.ModuleList([
+            QK_Norm_TransformerBlock(d_model, d_head, use_qk_norm=use_qk_norm) for _ in range(_get(model_cfg, "pcd_layers"))])
+        self.points_transformer_blocks.apply(init_weights)
+
+        dino_kw = _get(model_cfg, "dino", None) or {}          # optional override (tests use a shallow ViT)
+        self.image_encoder = DinoEncoder(patch_size=14, embed_dim=d_model, num_heads=d_model // 64,
+                                         depth=_get(dino_kw, "depth", 12), pos_grid=_get(dino_kw, "pos_grid", 37))
+        self.alternating_layers = _get(tcfg, "n_layer", 12)
+        assert self.alternating_layers % 2 == 0, "Alternating layers should be even."
+        self.global_transformer_blocks = nn.ModuleList([
+            QK_Norm_TransformerBlock(d_model, d_head, use_qk_norm=use_qk_norm) for _ in range(self.alternating_layers // 2)])
+        self.global_transformer_blocks.apply(init_weights)
+        self.local_transformer_blocks = nn.ModuleList([
+            QK_Norm_TransformerBlock(d_model, d_head, use_qk_norm=use_qk_norm) for _ in range(self.alternating_layers // 2)])
+        self.local_transformer_blocks.apply(init_weights)
+
+        self.transformer_input_layernorm = nn.LayerNorm(d_model, bias=False)
+        self.decoder_cross_attn = QK_Norm_CrossAttentionBlock(dim=d_model, head_dim=d_head, kv_dim=d_model,
+                                                              use_qk_norm=use_qk_norm)
+        self.shared_mlp_output = nn.Sequential(nn.LayerNorm(self.feat_dim), nn.Linear(self.feat_dim, self.feat_dim),
+                                               nn.GELU(), nn.Linear(self.feat_dim, 3))
+        self.shared_mlp_output.apply(init_weights)
+        self.loss_computer = MSELossComputer(self.config)
+
+    def train(self, mode=True):
+        # the reference's override returns None (Pcd_motion.py:372-373); returning self keeps
+        # `model.eval()` as a statement working and also the usual chaining
+        super().train(mode)
+        return self
+
+    # ------------------------------------------------------------------------------------ stages
+    def _point_features(self, P: Prepared, xyz, normal, rgb) -> torch.Tensor:
+        """[P,3] x3 -> fp32 [P, C] = point_normal_rgb_proj(cat[point_embed(xyz), normal, rgb])
+        (reference :456-459, :550-553)."""
+        C = self.embed_dim
+        n = xyz.shape[0]
+        enc = ops.point_encode(xyz, P.dtype)                                   # [n, 64]
+        kp = pad_k(C + 6)
+        feat = torch.empty((n, kp), dtype=P.dtype, device=xyz.device)
+        ops.gemm(enc, P.mat(self.point_embed.mlp.weight), feat, bias=P.vec(self.point_embed.mlp.bias))
+        ops.point_concat(normal, rgb, feat, C)
+        out = torch.empty((n, C), dtype=torch.float32, device=xyz.device)
+        ops.gemm(feat, P.mat(self.point_normal_rgb_proj.weight), out, bias=P.vec(self.point_normal_rgb_proj.bias))
+        return out
+
+    def _video_pos(self, P: Prepared, T: int) -> torch.Tensor:
+        g = self.latent_size
+        if T == self.latent_length:
+            return P.f32(self.pos_embed).reshape(-1, self.embed_dim)
+        return P.derived(f"pos_T{T}", (self.pos_embed,), lambda: resize_pos_embed(
+            self.pos_embed.detach().float(), (self.latent_length, g, g), (T, g, g)).reshape(-1, self.embed_dim)
+            .contiguous().to(P.device))
+
+    def _f32c(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(torch.float32).contiguous()
+
+    def forward(self, sample: Dict[str, torch.Tensor]):
+        ref_pcd = sample["ref_pcd"]
+        dev = ref_pcd.device
+        if dev.type != "cuda":
+            raise M324Error("motion324_amd.Motion_Latent_Model runs only on a HIP device (model.to('cuda'), inputs on "
+                            "'cuda'); there is no CPU fallback on this path")
+        if self.training and self.drop_rate > 0.0:
+            raise NotImplementedError("training-mode dropout on video tokens (drop_rate > 0) is not implemented yet; "
+                                      "set model.video_encoder.transformer.drop_rate=0")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("backward through the HIP path is not implemented yet (inference only): "
+                                      "call under torch.no_grad() / model.eval()")
+        P = Prepared.for_module(self, dev, compute_dtype())
+        cap = getattr(self, "_capture", None)      # tests: dict that receives clones of stage activations
+        B, N, _ = ref_pcd.shape
+        C, K = self.embed_dim, self.num_learnable_tokens
+        S = sample["ref_shape_pcd"].shape[1]
+
+        # A. shape encoder (reference :456-464)
+        pts = self._point_features(P, self._f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
+                                   self._f32c(sample["ref_shape_normals"]), self._f32c(sample["ref_shape_rgbs"]))
+        query = P.f32(self.learnable_tokens).reshape(K, C).repeat(B, 1)          # fp32 [B*K, C]
+        mesh = self.encoder_cross_attn.run(P, query, pts, B, K, S)
+        if cap is not None:
+            cap["shape_point_feat"], cap["encoder_out"] = pts.clone(), mesh.clone()
+        for blk in self.points_transformer_blocks:
+            blk.run(P, mesh, B, K)
+        if cap is not None:
+            cap["mesh_feat"] = mesh.clone()
+
+        # B. image encoder (reference :466-475): resize + normalise + patchify + ViT, frozen
+        video = self._f32c(sample["rgb_video"])
+        _, T, Hin, Win, _ = video.shape
+        dino_x = self.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))
+        Pn = self.num_patches_h * self.num_patches_w
+
+        # C. DINO final norm + pos-embed + token assembly + input LN in one pass (reference :477-510)
+        enc = self.image_encoder.model
+        tok = ops.assemble_tokens(dino_x, P.vec(enc.norm.weight), P.vec(enc.norm.bias), DINO_EPS, self._video_pos(P, T),
+                                  P.f32(self.special_token_0).reshape(4, C), P.f32(self.special_token_rest).reshape(4, C),
+                                  mesh, P.vec(self.transformer_input_layernorm.weight),
+                                  self.transformer_input_layernorm.eps, B, T, K, Pn)
+        Lt = 4 + K + Pn
+        if cap is not None:
+            dn = torch.empty((B * T * Pn, C), dtype=torch.float32, device=dev)
+            ops.layernorm(dino_x, P.vec(enc.norm.weight), P.vec(enc.norm.bias), DINO_EPS, dn, row_map=(Pn, Pn + 1, 1))
+            cap["dino_tokens"], cap["trunk_in"] = dn, tok.clone()
+
+        # D. alternating global / local trunk (reference :394-409)
+        for gblk, lblk in zip(self.global_transformer_blocks, self.local_transformer_blocks):
+            gblk.run(P, tok, B, T * Lt)
+            lblk.run(P, tok, B * T, Lt)
+            if cap is not None and "trunk_block0" not in cap:
+                cap["trunk_block0"] = tok.clone()
+        if cap is not None:
+            cap["trunk_out"] = tok.clone()
+
+        # E+F. decoder (reference :520-579): the mesh points are projected once per sample and attend to
+        # each frame's K latent tokens; rows = (frame, point).
+        dec = self.decoder_cross_attn
+        out = torch.empty((B, T, N, 3), dtype=torch.float32, device=dev)
+        head_ln, head_fc1, head_fc2 = self.shared_mlp_output[0], self.shared_mlp_output[1], self.shared_mlp_output[3]
+        w3, b3 = P.f32(head_fc2.weight), P.vec(head_fc2.bias)
+        Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))           # latent tokens 4..4+K of every frame
+        nchunk = max(1, min(N, DECODE_ROWS // T))
+        pcd, nrm, rgb = (self._f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
+        for b in range(B):
+            for n0 in range(0, N, nchunk):
+                n1 = min(N, n0 + nchunk)
+                pf = self._point_features(P, pcd[b, n0:n1], nrm[b, n0:n1].contiguous(), rgb[b, n0:n1].contiguous())
+                Q = dec.project_q(P, pf, 1, n1 - n0)
+                x = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True)
+                if cap is not None and n0 == 0 and n1 == N:
+                    cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
+                h = torch.empty(x.shape, dtype=P.dtype, device=dev)
+                ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
+                h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
+                ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
+                if n0 == 0 and n1 == N:
+                    ops.linear_n3(h2, w3, b3, out[b])
+                else:
+                    o = torch.empty((T, n1 - n0, 3), dtype=torch.float32, device=dev)
+                    ops.linear_n3(h2, w3, b3, o)
+                    out[b, :, n0:n1] = o
+        if cap is not None and "decoder_out_t0" in cap:
+            cap["decoder_out_t0"] = torch.stack(cap["decoder_out_t0"], dim=0)
+
+        result = edict(input_data=sample, pcd_moved=out)
+        if "point_clouds" in sample:                                           # reference :582-592
+            m = self.loss_computer(out, sample["point_clouds"].to(dev))
+            lm = edict()
+            lm.loss = m.loss
+            lm.xyz_loss = m.coord_mse_loss
+            result.loss_metrics = lm
+        return result

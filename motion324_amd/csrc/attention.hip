@@ -1,0 +1,329 @@
+// m324_attention: flash-style softmax(Q K^T * scale) V for head_dim 64 on gfx950 matrix cores.
+//
+// Operands arrive head-major from m324_qkv_split: Q[Bq,H,Lq,64], K[B,H,Lk,64], Vt[B,H,64,Lkp]
+// (V transposed, zero padded to a multiple of 64 keys).  A workgroup = 4 waves = 128 query rows of
+// one (batch, head); each wave owns 32 query rows and walks the keys in tiles of 64.
+//
+// "Swapped" formulation -- no cross-lane shuffle and no P round trip through LDS:
+//   S^T[kv, q] = K[kv, :] . Q[q, :]        MFMA A = K rows (from LDS), B = Q rows (registers)
+//       C layout: lane holds column q = lane & 31, rows kv = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+//       -> a query's scores live in ONE lane pair (l, l ^ 32): row max / sum are in-register
+//          reductions plus a single cross-half exchange.
+//   O^T[d, q]  = Vt[d, kv] . P^T[kv, q]    MFMA A = Vt rows (from LDS), B = P^T = the lane's own S^T
+//       registers (the contraction index kv may be visited in any order as long as A and B agree, so
+//       Vt fragments are simply gathered in the C-layout's kv order: two 8-byte LDS reads per MFMA).
+// LDS per stage: K tile [64 kv][64 d] and Vt tile [64 d][64 kv], rows of 128 bytes (bf16) with
+// XOR-swizzled 16-byte (K) / 8-byte (Vt) chunks so the per-row fragment reads are conflict-free;
+// double buffered, global -> register -> LDS staging overlapped with the MFMAs, one barrier per tile.
+// The fp32 parity variant uses v_mfma_f32_32x32x2_f32 on padded fp32 tiles (single buffered).
+#include "common.h"
+
+namespace {
+
+constexpr int QW = 32;          // query rows per wave
+constexpr int NW = 4;           // waves per workgroup
+constexpr int QB = QW * NW;     // 128 query rows per workgroup
+constexpr int KV = 64;          // keys per tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------- bf16
+__device__ __forceinline__ int k_off(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int v_off(int row, int c8) { return row * 128 + ((c8 ^ ((row >> 1) & 15)) << 3); }
+
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
+                                                        const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+                                                        bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
+                                                        int Lkp, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 8192];   // [stage][K | Vt]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * QB + wave * QW;
+
+    const bf16_t* Qh = Q + (long)b * q_bstride + (long)h * Lq * 64;
+    const bf16_t* Kh = K + ((long)b * H + h) * (long)Lk * 64;
+    const bf16_t* Vh = Vt + ((long)b * H + h) * 64 * (long)Lkp;
+
+    // Q fragments (B operand): lane (q = l31, hi) holds Q[q][ks*16 + hi*8 .. +7] for ks = 0..3
+    bf16x8 qf[4];
+    {
+        const int q = q0 + l31;
+        const bool ok = q < Lq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 v = ok ? *reinterpret_cast<const uint4*>(Qh + (long)q * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+            qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+        }
+    }
+
+    // staging: K tile = 512 chunks of 16 B (row = kv, 8 chunks), Vt tile = 512 chunks (row = d, 8 chunks)
+    uint4 rk[2], rv[2];
+    auto load_tile = [&](int t) {
+        const int kv0 = t * KV;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+            rk[i] = (kv0 + row < Lk) ? *reinterpret_cast<const uint4*>(Kh + (long)(kv0 + row) * 64 + c * 8)
+                                     : make_uint4(0, 0, 0, 0);
+            rv[i] = *reinterpret_cast<const uint4*>(Vh + (long)row * Lkp + kv0 + c * 8);   // padded: in range
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* sk = smem + buf * 16384;
+        unsigned char* sv = sk + 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4*>(sk + k_off(row, c)) = rk[i];
+            *reinterpret_cast<uint2*>(sv + v_off(row, 2 * c)) = make_uint2(rv[i].x, rv[i].y);
+            *reinterpret_cast<uint2*>(sv + v_off(row, 2 * c + 1)) = make_uint2(rv[i].z, rv[i].w);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // running max (log2 domain) and this lane's partial row sum
+
+    const int nt = (Lk + KV - 1) / KV;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) load_tile(t + 1);
+        const unsigned char* sk = smem + (t & 1) * 16384;
+        const unsigned char* sv = sk + 8192;
+
+        // ---- S^T = K Q^T : two 32-key blocks
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (log2 domain).  Lane holds keys kv = kb*32 + (r&3) + 8*(r>>2) + 4*hi
+        const int kv0 = t * KV;
+        if (kv0 + KV > Lk) {   // ragged last tile: mask keys >= Lk (wave-uniform branch)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[kb][r] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * scale_log2e);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+        bf16x8 pf[4];   // P^T fragments, k-step j = kb*2 + (r>>3)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint32_t pk[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m_new));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], scale_log2e, -m_new));
+                rs += p0 + p1;
+                pk[r >> 1] = pack_bf16x2(p0, p1);
+            }
+            uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            pf[kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
+            pf[kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
+        }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // ---- O^T += Vt P^T.  k-step j covers keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int d = db * 32 + l31;
+                uint2 a0 = *reinterpret_cast<const uint2*>(sv + v_off(d, 4 * j + hi));
+                uint2 a1 = *reinterpret_cast<const uint2*>(sv + v_off(d, 4 * j + 2 + hi));
+                uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av), pf[j], o[db], 0, 0, 0);
+            }
+        }
+
+        if (more) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store.  o[db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < Lq) {
+        bf16_t* orow = O + ((long)b * Lq + q) * ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack_bf16x2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
+                w.y = pack_bf16x2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + db * 32 + g * 8 + hi * 4) = w;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- fp32
+constexpr int FLD = 65;   // padded row length (floats) of the fp32 tiles: conflict-free column reads
+
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ Q, long q_bstride,
+                                                       const float* __restrict__ K, const float* __restrict__ Vt,
+                                                       float* __restrict__ O, long ldo, int H, int Lq, int Lk, int Lkp,
+                                                       float scale_log2e) {
+    __shared__ float sk[KV * FLD];   // [kv][d]
+    __shared__ float sv[64 * FLD];   // [d][kv]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * QB + wave * QW;
+
+    const float* Qh = Q + (long)b * q_bstride + (long)h * Lq * 64;
+    const float* Kh = K + ((long)b * H + h) * (long)Lk * 64;
+    const float* Vh = Vt + ((long)b * H + h) * 64 * (long)Lkp;
+
+    // lane (q, hi) holds Q[q][2s + hi], s = 0..31
+    float qf[32];
+    {
+        const int q = q0 + l31;
+        const bool ok = q < Lq;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qf[s] = ok ? Qh[(long)q * 64 + 2 * s + hi] : 0.f;
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (Lk + KV - 1) / KV;
+    for (int t = 0; t < nt; ++t) {
+        const int kv0 = t * KV;
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // 64 x 64 floats = 1024 float4 per tile, 4 per thread
+            const int id = tid + 256 * i, row = id >> 4, c = id & 15;
+            float4 kx = (kv0 + row < Lk) ? *reinterpret_cast<const float4*>(Kh + (long)(kv0 + row) * 64 + c * 4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 vx = *reinterpret_cast<const float4*>(Vh + (long)row * Lkp + kv0 + c * 4);
+            float* pk = sk + row * FLD + c * 4;
+            float* pv = sv + row * FLD + c * 4;
+            pk[0] = kx.x; pk[1] = kx.y; pk[2] = kx.z; pk[3] = kx.w;
+            pv[0] = vx.x; pv[1] = vx.y; pv[2] = vx.z; pv[3] = vx.w;
+        }
+        __syncthreads();
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 32; ++st)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[(kb * 32 + l31) * FLD + 2 * st + hi], qf[st], s[kb], 0, 0, 0);
+        }
+        if (kv0 + KV > Lk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[kb][r] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * scale_log2e);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[kb][r] = exp2f(fmaf(s[kb][r], scale_log2e, -m_new));
+                rs += s[kb][r];
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        // O^T += Vt P^T : MFMA step (kb, r) contracts key kv = kb*32 + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[(db * 32 + l31) * FLD + kv], s[kb][r], o[db], 0, 0, 0);
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < Lq) {
+        float* orow = O + ((long)b * Lq + q) * ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 w = make_float4(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv,
+                                       o[db][g * 4 + 3] * inv);
+                *reinterpret_cast<float4*>(orow + db * 32 + g * 8 + hi * 4) = w;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B,
+                              int H, int Lq, int Lk, float scale, int dtype, void* stream) {
+    M324_REQUIRE(Q && K && Vt && O, "m324_attention: null pointer");
+    M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "m324_attention: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
+    M324_REQUIRE(ldo >= (long)H * 64, "m324_attention: ldo too small");
+    M324_REQUIRE(H <= 65535 && B <= 65535, "m324_attention: grid too large");
+    const int Lkp = (Lk + 63) / 64 * 64;
+    dim3 grid(ceil_div(Lq, QB), H, B);
+    hipStream_t s = (hipStream_t)stream;
+    const float sl = scale * LOG2E;
+    if (dtype == M324_BF16) {
+        M324_REQUIRE((ldo * 2) % 8 == 0, "m324_attention: ldo misaligned");
+        hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K,
+                           (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl);
+    } else if (dtype == M324_F32) {
+        M324_REQUIRE(ldo % 4 == 0, "m324_attention: ldo misaligned");
+        hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, s, (const float*)Q, q_bstride, (const float*)K,
+                           (const float*)Vt, (float*)O, ldo, H, Lq, Lk, Lkp, sl);
+    } else {
+        M324_FAIL(M324_ERR_UNSUPPORTED, "m324_attention: dtype %d", dtype);
+    }
+    M324_CHECK_LAUNCH("m324_attention");
+    return M324_OK;
+}

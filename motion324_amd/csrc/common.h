@@ -1,0 +1,65 @@
+// Shared device/host helpers for libm324 (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/m324.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+typedef uint16_t bf16_t;   // storage type of a bf16 element in HBM / LDS
+
+// ---- error plumbing (never throw / abort across the C ABI) -------------------------------
+void m324_set_error(const char* fmt, ...);
+#define M324_FAIL(code, ...)            \
+    do {                                \
+        m324_set_error(__VA_ARGS__);    \
+        return (code);                  \
+    } while (0)
+#define M324_REQUIRE(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) M324_FAIL(M324_ERR_INVALID, __VA_ARGS__);    \
+    } while (0)
+#define M324_CHECK_LAUNCH(name)                                                             \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) M324_FAIL(M324_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ---------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PER16 = 4;   // elements per 16-byte chunk
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int PER16 = 8;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// exact (erf) GELU, nn.GELU() default -- reference model/transformer.py:58
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,432 @@
+// HBM-bound kernels of the Motion324 hot path: normalisation, layout changes, patchify, point
+// Fourier features, token assembly, the 3-wide regression head and the MSE loss.
+// One wave (64 lanes) per token row wherever a row reduction is needed; 16-byte accesses per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;   // float4 per lane -> C <= 1024
+
+__device__ __forceinline__ long remap_row(long r, int gin, int gout, int off) {
+    return gin > 0 ? (r / gin) * gout + (r % gin) + off : r;
+}
+
+// mean / rstd of a row held as nv float4 per lane (two-pass, like torch's LayerNorm)
+// slot i of a lane covers columns lane*4 + i*256 .. +3; slots past C are skipped (statically unrolled
+// so the row stays in registers)
+#define LN_FOR(i, c) _Pragma("unroll") for (int i = 0, c = lane * 4; i < LN_MAXV; ++i, c += 256) if (c < C)
+
+__device__ __forceinline__ void row_load(float4 (&v)[LN_MAXV], const float* src, int lane, int C) {
+    LN_FOR(i, c) v[i] = *reinterpret_cast<const float4*>(src + c);
+}
+__device__ __forceinline__ void row_stats(const float4 (&v)[LN_MAXV], int lane, int C, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+    LN_FOR(i, c) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    LN_FOR(i, c) {
+        float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+    }
+    rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+// ----------------------------------------------------------------------------------- layernorm
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
+                                                        int rows, int C, int gin, int gout, int off) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + remap_row(row, gin, gout, off) * ldx;
+    float4 v[LN_MAXV];
+    row_load(v, xr, lane, C);
+    float mean, rstd;
+    row_stats(v, lane, C, eps, mean, rstd);
+    T* yr = y + row * ldy;
+    LN_FOR(i, c) {
+        float4 ww = *reinterpret_cast<const float4*>(w + c);
+        float4 bb = b ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        store4<T>(yr + c, (v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                  (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+    }
+}
+
+// ----------------------------------------------------------------------------------- qkv split
+// One workgroup per (64-token tile, head, batch).  Thread t: token = t >> 2, 16 columns (t & 3) * 16.
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs, long ldq, const T* __restrict__ ks, long ldk,
+                                                        const T* __restrict__ vs, long ldv, const float* __restrict__ qw,
+                                                        const float* __restrict__ kw, float eps, T* __restrict__ Q,
+                                                        T* __restrict__ K, T* __restrict__ Vt, int L, int H, int Lp) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x, tok = t >> 2, part = t & 3;
+    const int b = blockIdx.z, h = blockIdx.y, l0 = blockIdx.x * 64;
+    const int l = l0 + tok;
+    const bool ok = l < L;
+    const long srow = (long)b * L + l;
+    const long hbase = ((long)b * H + h);
+
+    auto do_qk = [&](const T* src, long ld, const float* w, T* dst) {
+        float v[16];
+        if (ok) {
+            const T* p = src + srow * ld + h * 64 + part * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 f = load4<T>(p + i * 4);
+                v[i * 4] = f.x; v[i * 4 + 1] = f.y; v[i * 4 + 2] = f.z; v[i * 4 + 3] = f.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = 0.f;
+        }
+        if (w) {   // RMSNorm over the 64 columns of this (token, head): 4 neighbouring lanes
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ss += v[i] * v[i];
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            const float r = rsqrtf(ss * (1.0f / 64.0f) + eps);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = v[i] * r * w[part * 16 + i];
+        }
+        if (ok) {
+            T* o = dst + (hbase * L + l) * 64 + part * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store4<T>(o + i * 4, v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
+        }
+    };
+    if (qs) do_qk(qs, ldq, qw, Q);
+    if (ks) do_qk(ks, ldk, kw, K);
+    if (vs) {
+        if (ok) {
+            const T* p = vs + srow * ldv + h * 64 + part * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 f = load4<T>(p + i * 4);
+                tile[part * 16 + i * 4 + 0][tok] = f.x;
+                tile[part * 16 + i * 4 + 1][tok] = f.y;
+                tile[part * 16 + i * 4 + 2][tok] = f.z;
+                tile[part * 16 + i * 4 + 3][tok] = f.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tile[part * 16 + i][tok] = 0.f;   // zero padding up to Lp
+        }
+        __syncthreads();
+        const int d = t >> 2;   // output row d, 16 tokens (t & 3) * 16
+        T* o = Vt + (hbase * 64 + d) * (long)Lp + l0 + part * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            store4<T>(o + i * 4, tile[d][part * 16 + i * 4], tile[d][part * 16 + i * 4 + 1], tile[d][part * 16 + i * 4 + 2],
+                      tile[d][part * 16 + i * 4 + 3]);
+    }
+}
+
+// ----------------------------------------------------------------------------------- patchify
+// One thread per output pixel (frame, oy, ox): 4 bilinear taps x 3 interleaved channels.
+// PyTorch upsample_bilinear2d, align_corners=False: src = scale * (dst + 0.5) - 0.5 clamped at 0,
+// scale = in / out; i1 = min(i0 + 1, in - 1).
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ video, int F, int Hin, int Win, int size,
+                                                       int patch, T* __restrict__ out, int Kp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)F * size * size;
+    if (idx >= total) return;
+    const int ox = (int)(idx % size), oy = (int)((idx / size) % size), f = (int)(idx / ((long)size * size));
+    const float sh = (float)Hin / (float)size, sw = (float)Win / (float)size;
+    float fy = fmaxf(sh * ((float)oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)fy, Hin - 1), x0 = min((int)fx, Win - 1);
+    const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = video + (long)f * Hin * Win * 3;
+    const float* p00 = base + ((long)y0 * Win + x0) * 3;
+    const float* p01 = base + ((long)y0 * Win + x1) * 3;
+    const float* p10 = base + ((long)y1 * Win + x0) * 3;
+    const float* p11 = base + ((long)y1 * Win + x1) * 3;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};   // dinov2.py:7-8
+    const int g = size / patch;
+    const int py = oy / patch, ky = oy % patch, px = ox / patch, kx = ox % patch;
+    T* orow = out + ((long)f * g * g + (long)py * g + px) * Kp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+        Elem<T>::store(orow + c * patch * patch + ky * patch + kx, (v - mean[c]) / stdv[c]);
+    }
+    // zero the K padding once per patch row (the thread of the patch's first pixel)
+    if (ky == 0 && kx == 0)
+        for (int c = 3 * patch * patch; c < Kp; ++c) Elem<T>::store(orow + c, 0.f);
+}
+
+// ----------------------------------------------------------------------------------- point features
+// 64 columns per point: [sin(x e_j), sin(y e_j), sin(z e_j) | cos ... | x y z | 0 x 13], e_j = 2^j pi.
+template <typename T>
+__global__ __launch_bounds__(256) void point_encode_kernel(const float* __restrict__ xyz, int P, T* __restrict__ out, long ld) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per (point, column)
+    const long p = idx >> 6;
+    const int c = (int)(idx & 63);
+    if (p >= P) return;
+    float v = 0.f;
+    if (c < 48) {
+        const int cc = c % 24, axis = cc >> 3, j = cc & 7;
+        // the reference multiplies by the fp32 constant fl(2^j * pi) (Pcd_motion.py:164): reproduce it
+        const float e = (float)(1 << j) * 3.14159274101257324f;
+        const float arg = xyz[p * 3 + axis] * e;
+        v = c < 24 ? sinf(arg) : cosf(arg);
+    } else if (c < 51) {
+        v = xyz[p * 3 + (c - 48)];
+    }
+    Elem<T>::store(out + p * ld + c, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void point_concat_kernel(const float* __restrict__ normal, const float* __restrict__ rgb,
+                                                           int P, T* __restrict__ feat, int C, int Kp) {
+    const int w = Kp - C;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long p = idx / w;
+    const int c = (int)(idx % w);
+    if (p >= P) return;
+    float v = 0.f;
+    if (c < 3) v = normal[p * 3 + c];
+    else if (c < 6) v = rgb[p * 3 + c - 3];
+    Elem<T>::store(feat + p * Kp + C + c, v);
+}
+
+__global__ void dino_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos0, float* __restrict__ x, int F,
+                                int rpf, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)F * C) return;
+    const int c = (int)(idx % C);
+    const long f = idx / C;
+    x[f * rpf * C + c] = cls[c] + pos0[c];
+}
+
+// ----------------------------------------------------------------------------------- token assembly
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ dino_x, const float* __restrict__ dw,
+                                                       const float* __restrict__ db, float eps_d, const float* __restrict__ pos,
+                                                       const float* __restrict__ sp0, const float* __restrict__ spr,
+                                                       const float* __restrict__ mesh, const float* __restrict__ lw, float eps_in,
+                                                       float* __restrict__ out, int B, int T, int K, int P, int C) {
+    const int lane = threadIdx.x & 63;
+    const int Lt = 4 + K + P;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * T * Lt) return;
+    const int j = (int)(row % Lt);
+    const int t = (int)((row / Lt) % T);
+    const int b = (int)(row / ((long)Lt * T));
+    float4 v[LN_MAXV];
+    if (j < 4 + K) {   // wave-uniform: a wave owns one row
+        const float* src = j < 4 ? (t == 0 ? sp0 : spr) + (long)j * C : mesh + ((long)b * K + (j - 4)) * C;
+        row_load(v, src, lane, C);
+    } else {
+        const int p = j - 4 - K;
+        row_load(v, dino_x + (((long)b * T + t) * (P + 1) + 1 + p) * C, lane, C);
+        float mean, rstd;
+        row_stats(v, lane, C, eps_d, mean, rstd);
+        const float* pe = pos + ((long)t * P + p) * C;
+        LN_FOR(i, c) {
+            float4 ww = *reinterpret_cast<const float4*>(dw + c), bb = *reinterpret_cast<const float4*>(db + c);
+            float4 pp = *reinterpret_cast<const float4*>(pe + c);
+            v[i].x = (v[i].x - mean) * rstd * ww.x + bb.x + pp.x;
+            v[i].y = (v[i].y - mean) * rstd * ww.y + bb.y + pp.y;
+            v[i].z = (v[i].z - mean) * rstd * ww.z + bb.z + pp.z;
+            v[i].w = (v[i].w - mean) * rstd * ww.w + bb.w + pp.w;
+        }
+    }
+    float mean, rstd;
+    row_stats(v, lane, C, eps_in, mean, rstd);
+    float* o = out + row * C;
+    LN_FOR(i, c) {
+        float4 ww = *reinterpret_cast<const float4*>(lw + c);
+        *reinterpret_cast<float4*>(o + c) = make_float4((v[i].x - mean) * rstd * ww.x, (v[i].y - mean) * rstd * ww.y,
+                                                        (v[i].z - mean) * rstd * ww.z, (v[i].w - mean) * rstd * ww.w);
+    }
+}
+
+// ----------------------------------------------------------------------------------- 3-wide head
+template <typename T>
+__global__ __launch_bounds__(256) void linear_n3_kernel(const T* __restrict__ A, long lda, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int M, int K) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* a = A + row * lda;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < K; c += 256) {
+        float4 x = load4<T>(a + c);
+        float4 w0 = *reinterpret_cast<const float4*>(W + c), w1 = *reinterpret_cast<const float4*>(W + K + c),
+               w2 = *reinterpret_cast<const float4*>(W + 2 * (long)K + c);
+        s0 += x.x * w0.x + x.y * w0.y + x.z * w0.z + x.w * w0.w;
+        s1 += x.x * w1.x + x.y * w1.y + x.z * w1.z + x.w * w1.w;
+        s2 += x.x * w2.x + x.y * w2.y + x.z * w2.z + x.w * w2.w;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        out[row * 3 + 0] = s0 + bias[0];
+        out[row * 3 + 1] = s1 + bias[1];
+        out[row * 3 + 2] = s2 + bias[2];
+    }
+}
+
+// ----------------------------------------------------------------------------------- MSE
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        s += d * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void mse_final_kernel(const float* __restrict__ partial, int np, long n, float weight,
+                                                       float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *out = weight * (s / (float)n);
+}
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, name, ...)                                  \
+    if ((dtype) == M324_BF16) { using T = bf16_t; __VA_ARGS__; }          \
+    else if ((dtype) == M324_F32) { using T = float; __VA_ARGS__; }       \
+    else M324_FAIL(M324_ERR_UNSUPPORTED, name ": dtype %d", (int)(dtype))
+
+extern "C" int m324_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, void* y, long ldy,
+                              int out_dtype, int rows, int C, int gin, int gout, int off, void* stream) {
+    M324_REQUIRE(x && w && y, "m324_layernorm: null pointer");
+    M324_REQUIRE(rows > 0, "m324_layernorm: rows=%d", rows);
+    M324_REQUIRE(C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV, "m324_layernorm: C=%d unsupported", C);
+    M324_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "m324_layernorm: leading dims must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(out_dtype, "m324_layernorm",
+                   hipLaunchKernelGGL(layernorm_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, w, b, eps,
+                                      (T*)y, ldy, rows, C, gin, gout, off));
+    M324_CHECK_LAUNCH("m324_layernorm");
+    return M324_OK;
+}
+
+extern "C" int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, const void* v_src, long ldv,
+                              const float* q_w, const float* k_w, float eps, void* Q, void* K, void* Vt, int B, int L, int H,
+                              int dtype, void* stream) {
+    M324_REQUIRE(B > 0 && L > 0 && H > 0, "m324_qkv_split: empty problem");
+    M324_REQUIRE((!q_src || Q) && (!k_src || K) && (!v_src || Vt), "m324_qkv_split: missing output");
+    M324_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "m324_qkv_split: leading dims must be multiples of 4");
+    const int Lp = (L + 63) / 64 * 64;
+    dim3 grid(Lp / 64, H, B);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_qkv_split",
+                   hipLaunchKernelGGL(qkv_split_kernel<T>, grid, dim3(256), 0, s, (const T*)q_src, ldq, (const T*)k_src, ldk,
+                                      (const T*)v_src, ldv, q_w, k_w, eps, (T*)Q, (T*)K, (T*)Vt, L, H, Lp));
+    M324_CHECK_LAUNCH("m324_qkv_split");
+    return M324_OK;
+}
+
+extern "C" int m324_patchify(const float* video, int F, int Hin, int Win, int size, int patch, void* out, int Kp, int dtype,
+                             void* stream) {
+    M324_REQUIRE(video && out, "m324_patchify: null pointer");
+    M324_REQUIRE(F > 0 && Hin > 0 && Win > 0 && size > 0 && patch > 0 && size % patch == 0, "m324_patchify: bad geometry");
+    M324_REQUIRE(Kp >= 3 * patch * patch, "m324_patchify: Kp=%d too small", Kp);
+    const long total = (long)F * size * size;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_patchify",
+                   hipLaunchKernelGGL(patchify_kernel<T>, dim3(ceil_div(total, 256)), dim3(256), 0, s, video, F, Hin, Win,
+                                      size, patch, (T*)out, Kp));
+    M324_CHECK_LAUNCH("m324_patchify");
+    return M324_OK;
+}
+
+extern "C" int m324_point_encode(const float* xyz, int P, void* out, long ld, int dtype, void* stream) {
+    M324_REQUIRE(xyz && out && P > 0 && ld >= 64, "m324_point_encode: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_point_encode",
+                   hipLaunchKernelGGL(point_encode_kernel<T>, dim3(ceil_div((long)P * 64, 256)), dim3(256), 0, s, xyz, P,
+                                      (T*)out, ld));
+    M324_CHECK_LAUNCH("m324_point_encode");
+    return M324_OK;
+}
+
+extern "C" int m324_point_concat(const float* normal, const float* rgb, int P, void* feat, int C, int Kp, int dtype,
+                                 void* stream) {
+    M324_REQUIRE(normal && rgb && feat && P > 0 && Kp >= C + 6, "m324_point_concat: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_point_concat",
+                   hipLaunchKernelGGL(point_concat_kernel<T>, dim3(ceil_div((long)P * (Kp - C), 256)), dim3(256), 0, s,
+                                      normal, rgb, P, (T*)feat, C, Kp));
+    M324_CHECK_LAUNCH("m324_point_concat");
+    return M324_OK;
+}
+
+extern "C" int m324_dino_cls_rows(const float* cls, const float* pos0, float* x, int F, int rows_per_frame, int C,
+                                  void* stream) {
+    M324_REQUIRE(cls && pos0 && x && F > 0 && C > 0, "m324_dino_cls_rows: bad arguments");
+    hipLaunchKernelGGL(dino_cls_kernel, dim3(ceil_div((long)F * C, 256)), dim3(256), 0, (hipStream_t)stream, cls, pos0, x, F,
+                       rows_per_frame, C);
+    M324_CHECK_LAUNCH("m324_dino_cls_rows");
+    return M324_OK;
+}
+
+extern "C" int m324_assemble_tokens(const float* dino_x, const float* dino_w, const float* dino_b, float eps_dino,
+                                    const float* pos, const float* sp0, const float* spr, const float* mesh,
+                                    const float* ln_w, float eps_in, float* out, int B, int T, int K, int P, int C,
+                                    void* stream) {
+    M324_REQUIRE(dino_x && dino_w && dino_b && pos && sp0 && spr && mesh && ln_w && out, "m324_assemble_tokens: null pointer");
+    M324_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV, "m324_assemble_tokens: C=%d unsupported", C);
+    const long rows = (long)B * T * (4 + K + P);
+    hipLaunchKernelGGL(assemble_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, dino_x, dino_w, dino_b,
+                       eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, out, B, T, K, P, C);
+    M324_CHECK_LAUNCH("m324_assemble_tokens");
+    return M324_OK;
+}
+
+extern "C" int m324_linear_n3(const void* A, long lda, const float* W, const float* bias, float* out, int M, int K, int dtype,
+                              void* stream) {
+    M324_REQUIRE(A && W && bias && out && M > 0, "m324_linear_n3: bad arguments");
+    M324_REQUIRE(K % 4 == 0 && lda % 4 == 0, "m324_linear_n3: K and lda must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_linear_n3",
+                   hipLaunchKernelGGL(linear_n3_kernel<T>, dim3(ceil_div(M, 4)), dim3(256), 0, s, (const T*)A, lda, W, bias,
+                                      out, M, K));
+    M324_CHECK_LAUNCH("m324_linear_n3");
+    return M324_OK;
+}
+
+extern "C" int m324_mse(const float* pred, const float* target, long n, float weight, float* partial, float* out,
+                        void* stream) {
+    M324_REQUIRE(pred && target && partial && out && n > 0, "m324_mse: bad arguments");
+    const int nb = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, s, pred, target, n, partial);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, s, partial, nb, n, weight, out);
+    M324_CHECK_LAUNCH("m324_mse");
+    return M324_OK;
+}

@@ -1,0 +1,167 @@
+"""DINOv2 ViT-B/14 image encoder on libm324 kernels, with the hub model's parameter names.
+
+Replaces the reference's model/image_encoder/dinov2.py::DinoEncoder, which wraps
+``torch.hub.load('facebookresearch/dinov2', 'dinov2_vitb14')`` (:44) -- a network download of an
+unpinned third-party module.  Here the architecture is built locally (random-init; weights come
+from a checkpoint's ``image_encoder.model.*`` entries, which use the hub names kept below), and
+the arithmetic follows the reference's in-tree restatement model/image_encoder/dino/model_dino.py:
+patch conv k=s=14 (:160-170), [CLS] + interpolated position table (:83-134, bicubic, +0.1 offset),
+12 x { x + ls1 * proj(attn(LN x)); x + ls2 * fc2(gelu(fc1(LN x))) } (:393-422), LayerNorm eps 1e-6.
+The final LayerNorm + CLS drop (x_norm_patchtokens, dinov2.py:99-103) is fused into the trunk's token
+assembly kernel (m324_assemble_tokens), so ``run`` returns the PRE-norm residual stream.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .lib import ACT_GELU
+from .prepared import Prepared, pad_k
+
+DINO_EPS = 1e-6
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, 3 * dim, bias=True)
+        self.proj = nn.Linear(dim, dim, bias=True)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden, bias=True)
+        self.fc2 = nn.Linear(hidden, dim, bias=True)
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim, init_values=1.0):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=DINO_EPS)
+        self.attn = _Attention(dim)
+        self.ls1 = _LayerScale(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=DINO_EPS)
+        self.mlp = _Mlp(dim, hidden)
+        self.ls2 = _LayerScale(dim)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim, patch):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+
+class DinoVisionTransformer(nn.Module):
+    """Parameter tree of hub ``dinov2_vitb14`` (names = the released checkpoints' ``image_encoder.model.*`` keys)."""
+
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, patch_size=14, pos_grid=37, mlp_ratio=4):
+        super().__init__()
+        self.embed_dim, self.patch_size, self.num_heads, self.pos_grid = embed_dim, patch_size, num_heads, pos_grid
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, 1 + pos_grid * pos_grid, embed_dim))
+        self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
+        self.patch_embed = _PatchEmbed(embed_dim, patch_size)
+        self.blocks = nn.ModuleList([_Block(embed_dim, embed_dim * mlp_ratio) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=DINO_EPS)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def interpolated_pos(self, grid: int) -> torch.Tensor:
+        """[1 + grid*grid, C] position table for a grid x grid image (model_dino.py:83-116)."""
+        pe = self.pos_embed.detach().float()
+        n = pe.shape[1] - 1
+        m = int(math.sqrt(n))
+        if m == grid:
+            return pe[0].contiguous()
+        dim = pe.shape[-1]
+        patch = pe[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2)
+        sf = float((grid + 0.1) / math.sqrt(n))
+        patch = F.interpolate(patch, scale_factor=(sf, sf), mode="bicubic", align_corners=False)
+        if patch.shape[-1] != grid or patch.shape[-2] != grid:
+            raise ValueError("Width or height does not match with the interpolated position embeddings")
+        patch = patch.permute(0, 2, 3, 1).reshape(-1, dim)
+        return torch.cat([pe[0, :1], patch], dim=0).contiguous()
+
+
+class DinoEncoder(nn.Module):
+    """Frozen DINOv2 feature extractor (reference dinov2.py:39-131): parameters never require grad and the
+    module stays in eval mode (train() override, :126-131)."""
+
+    def __init__(self, patch_size=14, model_name="dinov2_vitb14", embed_dim=768, depth=12, num_heads=12, pos_grid=37):
+        super().__init__()
+        if model_name != "dinov2_vitb14":
+            raise NotImplementedError(model_name)
+        self.model = DinoVisionTransformer(embed_dim=embed_dim, depth=depth, num_heads=num_heads, patch_size=patch_size,
+                                           pos_grid=pos_grid)
+        self.patch_size = patch_size
+        self.image_size = 224
+        self.num_patches_per_dim = self.image_size // patch_size
+        self.num_patches_total = self.num_patches_per_dim ** 2
+        for p in self.model.parameters():
+            p.requires_grad = False
+        self.model.eval()
+
+    def train(self, mode: bool = False):
+        super().train(mode)
+        self.model.eval()
+        return self
+
+    def run(self, P: Prepared, video: torch.Tensor) -> torch.Tensor:
+        """video [F, Hin, Win, 3] fp32 in [0,1] (channel-last, any size) -> pre-final-norm tokens
+        [F * (1 + g*g), C] fp32.  Resize to 224^2 + ImageNet normalisation + im2col happen in one kernel
+        (Pcd_motion.py:470-472, dinov2.py:78-80)."""
+        m = self.model
+        Fr = video.shape[0]
+        g, C, H = self.num_patches_per_dim, m.embed_dim, m.num_heads
+        Lt = 1 + g * g
+        kp = pad_k(3 * self.patch_size ** 2)
+        patches = ops.patchify(video, self.image_size, self.patch_size, kp, P.dtype)
+        pos = P.derived(f"dino_pos{g}", (m.pos_embed,), lambda: m.interpolated_pos(g).to(P.device))
+        x = torch.empty((Fr * Lt, C), dtype=torch.float32, device=video.device)
+        ops.gemm(patches, P.mat(m.patch_embed.proj.weight), x, bias=P.vec(m.patch_embed.proj.bias),
+                 residual=pos[1:], res_rows=g * g, row_map=(g * g, Lt, 1))
+        ops.dino_cls_rows(P.f32(m.cls_token).reshape(-1), pos[0], x, Fr, Lt)
+        h = torch.empty((Fr * Lt, C), dtype=P.dtype, device=video.device)
+        qkv = torch.empty((Fr * Lt, 3 * C), dtype=P.dtype, device=video.device)
+        h1 = torch.empty((Fr * Lt, m.blocks[0].mlp.fc1.out_features), dtype=P.dtype, device=video.device)
+        for blk in m.blocks:
+            ops.layernorm(x, P.vec(blk.norm1.weight), P.vec(blk.norm1.bias), DINO_EPS, h)
+            ops.gemm(h, P.mat(blk.attn.qkv.weight), qkv, bias=P.vec(blk.attn.qkv.bias))
+            Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, None, 0.0, Fr, Lt, H, P.dtype)
+            ops.attention(Q, K, Vt, h)
+            ops.gemm(h, P.mat(blk.attn.proj.weight), x, bias=P.vec(blk.attn.proj.bias), gamma=P.vec(blk.ls1.gamma),
+                     residual=x)
+            ops.layernorm(x, P.vec(blk.norm2.weight), P.vec(blk.norm2.bias), DINO_EPS, h)
+            ops.gemm(h, P.mat(blk.mlp.fc1.weight), h1, bias=P.vec(blk.mlp.fc1.bias), act=ACT_GELU)
+            ops.gemm(h1, P.mat(blk.mlp.fc2.weight), x, bias=P.vec(blk.mlp.fc2.bias), gamma=P.vec(blk.ls2.gamma),
+                     residual=x)
+        return x
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        """Reference-compatible surface: image [B,3,224,224] in [0,1] -> x_norm_patchtokens [B,256,C]
+        (dinov2.py:65-86).  The normalised output is produced by m324_layernorm here."""
+        B, Cc, Hh, Ww = image.shape
+        assert Hh == self.image_size and Ww == self.image_size, \
+            f"Input image size must be {self.image_size}x{self.image_size}, but got {Hh}x{Ww}"
+        P = Prepared.for_module(self, image.device)
+        x = self.run(P, image.detach().float().permute(0, 2, 3, 1).contiguous())
+        Lt = 1 + self.num_patches_total
+        out = torch.empty((B * self.num_patches_total, x.shape[1]), dtype=torch.float32, device=image.device)
+        ops.layernorm(x, P.vec(self.model.norm.weight), P.vec(self.model.norm.bias), DINO_EPS, out,
+                      row_map=(self.num_patches_total, Lt, 1))
+        return out.reshape(B, self.num_patches_total, -1)

@@ -1,0 +1,101 @@
+"""ctypes binding of libm324.so -- the C ABI declared in include/m324.h.
+
+The product path has no fallback: if the shared library is missing or a call fails, this module
+raises.  Nothing here touches torch; motion324_amd.ops adapts tensors to raw pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libm324.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU = 0, 1
+ABI_VERSION = 1
+
+
+class M324Error(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_long),
+        ("W", C.c_void_p), ("ldw", C.c_long),
+        ("C", C.c_void_p), ("ldc", C.c_long),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("in_dtype", C.c_int), ("out_dtype", C.c_int),
+        ("bias", C.c_void_p),
+        ("act", C.c_int),
+        ("gamma", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_long), ("res_rows", C.c_int),
+        ("row_gin", C.c_int), ("row_gout", C.c_int), ("row_off", C.c_int),
+    ]
+
+
+_P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
+
+# name -> argtypes: exactly the declarations of include/m324.h
+SIGNATURES = {
+    "m324_abi_version": [],
+    "m324_last_error": [C.c_char_p, _I],
+    "m324_device_info": [C.c_char_p, _I],
+    "m324_gemm": [C.POINTER(GemmArgs), _P],
+    "m324_layernorm": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P],
+    "m324_attention": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _I, _P],
+    "m324_patchify": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "m324_point_encode": [_P, _I, _P, _L, _I, _P],
+    "m324_point_concat": [_P, _P, _I, _P, _I, _I, _I, _P],
+    "m324_dino_cls_rows": [_P, _P, _P, _I, _I, _I, _P],
+    "m324_assemble_tokens": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
+    "m324_linear_n3": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
+    "m324_mse": [_P, _P, _L, _F, _P, _P, _P],
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Loads libm324.so (once) and installs argtypes.  Raises M324Error when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise M324Error(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m motion324_amd.build` "
+                "(there is no CPU or PyTorch fallback on this path).")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        if lib.m324_abi_version() != ABI_VERSION:
+            raise M324Error(f"libm324 ABI {lib.m324_abi_version()} != binding {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().m324_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise M324Error(f"{what} failed ({rc}): {last_error()}")
+
+
+def device_info():
+    buf = C.create_string_buffer(256)
+    n = load().m324_device_info(buf, 256)
+    check(0 if n >= 0 else n, "m324_device_info")
+    return buf.value.decode(), n

@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the libm324 C ABI (motion324_amd/lib.py).
+
+PyTorch is only the owner of device memory and of the HIP stream here; every op below is one
+C-ABI call that enqueues hand-written gfx950 kernels on torch's current stream.  All tensors must
+live on a HIP device -- there is deliberately no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+from .timing import span
+
+F32, BF16 = L.F32, L.BF16
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def code_of(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise L.M324Error(f"unsupported dtype {dtype}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return _TORCH_DT[code]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.M324Error("libm324 ops need HIP device tensors (no CPU fallback on this path)")
+    return t.data_ptr()
+
+
+def _vec(t: Optional[torch.Tensor], n: int, name: str) -> Optional[int]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+        raise L.M324Error(f"{name}: expected contiguous fp32[{n}], got {t.dtype}{tuple(t.shape)}")
+    return _p(t)
+
+
+def _rows(t: torch.Tensor, name: str):
+    """2-D view contract: unit inner stride; returns (ptr, leading dimension in elements)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise L.M324Error(f"{name}: expected a 2-D tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+    return _p(t), t.stride(0)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = L.ACT_NONE, gamma=None,
+         residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0)) -> torch.Tensor:
+    """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm."""
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or a.dtype != w.dtype:
+        raise L.M324Error(f"gemm: a{tuple(a.shape)} {a.dtype} vs w{tuple(w.shape)} {w.dtype}")
+    args = L.GemmArgs()
+    args.A, args.lda = _rows(a, "a")
+    args.W, args.ldw = _rows(w, "w")
+    args.C, args.ldc = _rows(out, "out")
+    args.M, args.N, args.K = M, N, K
+    args.in_dtype, args.out_dtype = code_of(a.dtype), code_of(out.dtype)
+    args.bias = _vec(bias, N, "bias")
+    args.act = act
+    args.gamma = _vec(gamma, N, "gamma")
+    if residual is not None:
+        if residual.dtype != torch.float32:
+            raise L.M324Error("gemm: residual must be fp32")
+        args.residual, args.ldr = _rows(residual, "residual")
+        args.res_rows = res_rows
+    gin, gout, off = row_map
+    need = ((M - 1) // gin * gout + (M - 1) % gin + off + 1) if gin > 0 else M
+    if out.shape[0] < need or out.shape[1] < N:
+        raise L.M324Error(f"gemm: out{tuple(out.shape)} too small for {need} x {N}")
+    args.row_gin, args.row_gout, args.row_off = gin, gout, off
+    esz = a.element_size()
+    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, esz * (M * K + N * K) + out.element_size() * M * N):
+        L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float, out: torch.Tensor,
+              rows: Optional[int] = None, row_map=(0, 0, 0)) -> torch.Tensor:
+    if x.dtype != torch.float32:
+        raise L.M324Error("layernorm: x must be fp32")
+    px, ldx = _rows(x, "x")
+    py, ldy = _rows(out, "out")
+    Cdim = x.shape[1]
+    rows = out.shape[0] if rows is None else rows
+    gin, gout, off = row_map
+    need = ((rows - 1) // gin * gout + (rows - 1) % gin + off + 1) if gin > 0 else rows
+    if x.shape[0] < need or out.shape[0] < rows or out.shape[1] != Cdim:
+        raise L.M324Error("layernorm: shape mismatch")
+    L.check(L.load().m324_layernorm(px, ldx, _vec(w, Cdim, "w"), _vec(b, Cdim, "b"), eps, py, ldy, code_of(out.dtype),
+                                    rows, Cdim, gin, gout, off, _stream()), "m324_layernorm")
+    return out
+
+
+def qkv_split(q_src, k_src, v_src, q_w, k_w, eps: float, B: int, Lq: int, H: int, dtype: torch.dtype, *,
+              q_out=None, k_out=None, vt_out=None):
+    """Head-major Q[B,H,L,64], K[B,H,L,64], Vt[B,H,64,Lp] from token-major sources (any may be None).
+
+    All given sources share B and L (use separate calls for cross-attention's q and k/v)."""
+    dev = next(t for t in (q_src, k_src, v_src) if t is not None).device
+    Lp = (Lq + 63) // 64 * 64
+    Q = K = Vt = None
+    if q_src is not None:
+        Q = q_out if q_out is not None else torch.empty((B, H, Lq, 64), dtype=dtype, device=dev)
+    if k_src is not None:
+        K = k_out if k_out is not None else torch.empty((B, H, Lq, 64), dtype=dtype, device=dev)
+    if v_src is not None:
+        Vt = vt_out if vt_out is not None else torch.empty((B, H, 64, Lp), dtype=dtype, device=dev)
+
+    def src(t, name):
+        if t is None:
+            return None, 0
+        if t.dtype != dtype or t.shape[0] < B * Lq:
+            raise L.M324Error(f"qkv_split: {name} {t.dtype}{tuple(t.shape)}")
+        return _rows(t, name)
+    pq, ldq = src(q_src, "q_src")
+    pk, ldk = src(k_src, "k_src")
+    pv, ldv = src(v_src, "v_src")
+    L.check(L.load().m324_qkv_split(pq, ldq, pk, ldk, pv, ldv, _vec(q_w, 64, "q_w"), _vec(k_w, 64, "k_w"), eps,
+                                    _p(Q), _p(K), _p(Vt), B, Lq, H, code_of(dtype), _stream()), "m324_qkv_split")
+    return Q, K, Vt
+
+
+def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Tensor, *, shared_q: bool = False,
+              scale: Optional[float] = None) -> torch.Tensor:
+    """out[B*Lq, H*64] = softmax(Q K^T scale) V.  Q[Bq,H,Lq,64] (Bq == 1 with shared_q), K[B,H,Lk,64],
+    Vt[B,H,64,Lkp]."""
+    B, H, Lk, D = K.shape
+    Lq = Q.shape[2]
+    if D != 64 or Q.shape[3] != 64 or Q.shape[1] != H or Vt.shape[:3] != (B, H, 64) or Vt.shape[3] != (Lk + 63) // 64 * 64:
+        raise L.M324Error(f"attention: Q{tuple(Q.shape)} K{tuple(K.shape)} Vt{tuple(Vt.shape)}")
+    if not (Q.is_contiguous() and K.is_contiguous() and Vt.is_contiguous()):
+        raise L.M324Error("attention: operands must be contiguous")
+    if Q.dtype != K.dtype or K.dtype != Vt.dtype or out.dtype != Q.dtype:
+        raise L.M324Error("attention: dtype mismatch")
+    if not shared_q and Q.shape[0] != B:
+        raise L.M324Error("attention: batch mismatch")
+    po, ldo = _rows(out, "out")
+    if out.shape[0] < B * Lq or out.shape[1] < H * 64:
+        raise L.M324Error("attention: out too small")
+    qbs = 0 if shared_q else H * Lq * 64
+    scale = 64 ** -0.5 if scale is None else scale
+    esz = Q.element_size()
+    with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
+              esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq)):
+        L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, code_of(Q.dtype),
+                                        _stream()), "m324_attention")
+    return out
+
+
+def patchify(video: torch.Tensor, size: int, patch: int, Kp: int, dtype: torch.dtype) -> torch.Tensor:
+    """video [F,Hin,Win,3] fp32 -> [F*(size/patch)^2, Kp] normalised, bilinearly resized patch rows."""
+    if video.dtype != torch.float32 or not video.is_contiguous() or video.dim() != 4 or video.shape[3] != 3:
+        raise L.M324Error(f"patchify: video {video.dtype}{tuple(video.shape)}")
+    Fr, Hin, Win, _ = video.shape
+    g = size // patch
+    out = torch.empty((Fr * g * g, Kp), dtype=dtype, device=video.device)
+    L.check(L.load().m324_patchify(_p(video), Fr, Hin, Win, size, patch, _p(out), Kp, code_of(dtype), _stream()),
+            "m324_patchify")
+    return out
+
+
+def point_encode(xyz: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    xyz = xyz.reshape(-1, 3)
+    if xyz.dtype != torch.float32 or not xyz.is_contiguous():
+        raise L.M324Error("point_encode: xyz must be contiguous fp32")
+    out = torch.empty((xyz.shape[0], 64), dtype=dtype, device=xyz.device)
+    L.check(L.load().m324_point_encode(_p(xyz), xyz.shape[0], _p(out), 64, code_of(dtype), _stream()), "m324_point_encode")
+    return out
+
+
+def point_concat(normal: torch.Tensor, rgb: torch.Tensor, feat: torch.Tensor, Cdim: int) -> torch.Tensor:
+    normal, rgb = normal.reshape(-1, 3), rgb.reshape(-1, 3)
+    for t in (normal, rgb):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise L.M324Error("point_concat: normal/rgb must be contiguous fp32")
+    P, Kp = feat.shape
+    if not feat.is_contiguous() or normal.shape[0] != P or rgb.shape[0] != P:
+        raise L.M324Error("point_concat: shape mismatch")
+    L.check(L.load().m324_point_concat(_p(normal), _p(rgb), P, _p(feat), Cdim, Kp, code_of(feat.dtype), _stream()),
+            "m324_point_concat")
+    return feat
+
+
+def dino_cls_rows(cls: torch.Tensor, pos0: torch.Tensor, x: torch.Tensor, Fr: int, rows_per_frame: int) -> None:
+    Cdim = x.shape[1]
+    L.check(L.load().m324_dino_cls_rows(_vec(cls, Cdim, "cls"), _vec(pos0, Cdim, "pos0"), _p(x), Fr, rows_per_frame, Cdim,
+                                        _stream()), "m324_dino_cls_rows")
+
+
+def assemble_tokens(dino_x, dino_w, dino_b, eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, B, T, K, P) -> torch.Tensor:
+    Cdim = dino_x.shape[1]
+    for name, t, n in (("dino_x", dino_x, B * T * (P + 1) * Cdim), ("pos", pos, T * P * Cdim), ("sp0", sp0, 4 * Cdim),
+                       ("spr", spr, 4 * Cdim), ("mesh", mesh, B * K * Cdim)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise L.M324Error(f"assemble_tokens: {name} {t.dtype}{tuple(t.shape)} (want {n} fp32)")
+    out = torch.empty((B * T * (4 + K + P), Cdim), dtype=torch.float32, device=dino_x.device)
+    L.check(L.load().m324_assemble_tokens(_p(dino_x), _vec(dino_w, Cdim, "dino_w"), _vec(dino_b, Cdim, "dino_b"), eps_dino,
+                                          _p(pos), _p(sp0), _p(spr), _p(mesh), _vec(ln_w, Cdim, "ln_w"), eps_in, _p(out),
+                                          B, T, K, P, Cdim, _stream()), "m324_assemble_tokens")
+    return out
+
+
+def linear_n3(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    M, K = a.shape
+    pa, lda = _rows(a, "a")
+    if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (3, K):
+        raise L.M324Error("linear_n3: w must be contiguous fp32 [3,K]")
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != M * 3:
+        raise L.M324Error("linear_n3: out must be contiguous fp32 [M,3]")
+    L.check(L.load().m324_linear_n3(pa, lda, _p(w), _vec(bias, 3, "bias"), _p(out), M, K, code_of(a.dtype), _stream()),
+            "m324_linear_n3")
+    return out
+
+
+def mse(pred: torch.Tensor, target: torch.Tensor, weight: float) -> torch.Tensor:
+    if pred.shape != target.shape:
+        raise L.M324Error(f"mse: shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)}")
+    pred = pred.contiguous().float()
+    target = target.contiguous().float()
+    partial = torch.empty(1024, dtype=torch.float32, device=pred.device)
+    out = torch.empty((), dtype=torch.float32, device=pred.device)
+    L.check(L.load().m324_mse(_p(pred), _p(target), pred.numel(), weight, _p(partial), _p(out), _stream()), "m324_mse")
+    return out

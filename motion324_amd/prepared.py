@@ -1,0 +1,119 @@
+"""Kernel-ready views of a module's parameters (compute-dtype copies, K padding), cached.
+
+libm324's GEMM wants K-major weight rows in the compute dtype with K a multiple of the K-tile; the
+parameters themselves stay fp32 nn.Parameters with the reference's names and shapes.  A Prepared
+object converts each parameter once per (device, dtype) and re-converts it when the parameter is
+modified in place (optimizer step, load_state_dict) or re-allocated (``.to(device)``).
+This is one-time weight preparation, done with torch copies; no arithmetic of the path lives here.
+"""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+K_ALIGN = 64   # GEMM K-tile of the bf16 kernel (fp32 needs 32); one padding rule for both modes
+
+_OVERRIDE: Optional[torch.dtype] = None
+
+
+def set_precision(p: Optional[str]) -> None:
+    """Force 'bf16' / 'fp32' for every forward, or None to follow torch.autocast (the reference's switch)."""
+    global _OVERRIDE
+    _OVERRIDE = {None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[p]
+
+
+def compute_dtype() -> torch.dtype:
+    """bf16 speed mode under torch.autocast(cuda, bf16/fp16) -- what the reference's callers request
+    (train.py:150-155, scripts/inference_with_video_mesh.py:162-167) -- else fp32 parity mode."""
+    if _OVERRIDE is not None:
+        return _OVERRIDE
+    env = os.environ.get("M324_PRECISION")
+    if env:
+        return {"bf16": torch.bfloat16, "fp32": torch.float32}[env]
+    if torch.is_autocast_enabled("cuda"):
+        return torch.bfloat16      # fp16 autocast is served by the bf16 kernels (same operand width)
+    return torch.float32
+
+
+def pad_k(k: int) -> int:
+    return (k + K_ALIGN - 1) // K_ALIGN * K_ALIGN
+
+
+class Prepared:
+    _registry: "weakref.WeakKeyDictionary[torch.nn.Module, Dict[Tuple[str, torch.dtype], Prepared]]" = \
+        weakref.WeakKeyDictionary()
+
+    def __init__(self, device: torch.device, dtype: torch.dtype):
+        self.device, self.dtype = device, dtype
+        self._cache: Dict[tuple, Tuple[tuple, torch.Tensor]] = {}
+
+    @classmethod
+    def for_module(cls, module: torch.nn.Module, device: torch.device, dtype: Optional[torch.dtype] = None) -> "Prepared":
+        dtype = compute_dtype() if dtype is None else dtype
+        per_mod = cls._registry.setdefault(module, {})
+        key = (str(device), dtype)
+        if key not in per_mod:
+            per_mod[key] = cls(device, dtype)
+        return per_mod[key]
+
+    @staticmethod
+    def _stamp(ps: Sequence[torch.Tensor]) -> tuple:
+        return tuple((p.data_ptr(), p._version) for p in ps)
+
+    def _get(self, kind: str, ps: Sequence[torch.Tensor], make):
+        key = (kind,) + tuple(id(p) for p in ps)
+        stamp = self._stamp(ps)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            t = make()
+        self._cache[key] = (stamp, t)
+        return t
+
+    def _mat_of(self, p: torch.Tensor) -> torch.Tensor:
+        w = p.detach().reshape(p.shape[0], -1)
+        k = w.shape[1]
+        kp = pad_k(k)
+        if kp == k:
+            return w.to(device=self.device, dtype=self.dtype).contiguous()
+        out = torch.zeros((w.shape[0], kp), dtype=self.dtype, device=self.device)
+        out[:, :k] = w
+        return out
+
+    def mat(self, p: torch.Tensor) -> torch.Tensor:
+        """[N, K'] compute-dtype GEMM operand of a Linear/Conv weight (flattened, K zero-padded to 64)."""
+        return self._get("mat", (p,), lambda: self._mat_of(p))
+
+    def cat_rows(self, ps: Sequence[torch.Tensor]) -> torch.Tensor:
+        """Several [N_i, K] weights stacked along N (one GEMM for k and v projections)."""
+        return self._get("cat", tuple(ps), lambda: torch.cat([self._mat_of(p) for p in ps], dim=0).contiguous())
+
+    def vec(self, p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """fp32 epilogue / normalisation vector (bias, LN weight, LayerScale gamma ...)."""
+        if p is None:
+            return None
+        if p.dtype == torch.float32 and p.device == self.device and p.is_contiguous():
+            return p.detach().reshape(-1)
+        return self._get("vec", (p,), lambda: p.detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1))
+
+    def cat_vecs(self, ps: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
+        if all(p is None for p in ps):
+            return None
+        if any(p is None for p in ps):
+            raise ValueError("cat_vecs: either all or none of the biases must exist")
+        return self._get("catv", tuple(ps), lambda: torch.cat(
+            [p.detach().to(device=self.device, dtype=torch.float32).reshape(-1) for p in ps]).contiguous())
+
+    def f32(self, p: torch.Tensor) -> torch.Tensor:
+        """fp32 contiguous device copy of a parameter/buffer of any shape (tokens, position tables)."""
+        if p.dtype == torch.float32 and p.device == self.device and p.is_contiguous():
+            return p.detach()
+        return self._get("f32", (p,), lambda: p.detach().to(device=self.device, dtype=torch.float32).contiguous())
+
+    def derived(self, name: str, ps: Sequence[torch.Tensor], make) -> torch.Tensor:
+        """Cached tensor derived from parameters by ``make()`` (e.g. an interpolated position table)."""
+        return self._get("derived:" + name, tuple(ps), make)

@@ -1,0 +1,61 @@
+"""Optional per-launch HIP-event timing of libm324 calls (used by bench.py for the roofline object).
+
+When a Recorder is active, ops.gemm / ops.attention bracket their C-ABI call with events on torch's
+current stream -- the stream the kernels are launched on -- and tag them with the launch's algorithmic
+FLOPs.  Durations are read after the timed region has been synchronised.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+_active: Optional["Recorder"] = None
+
+
+class Recorder:
+    def __init__(self):
+        self.items: List[Tuple[str, float, float, torch.cuda.Event, torch.cuda.Event]] = []
+
+    def __enter__(self):
+        global _active
+        _active = self
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        _active = None
+
+    def summary(self) -> Dict[str, dict]:
+        """kernel class -> {launches, total_ms, avg_ms, flops, bytes} (call after torch.cuda.synchronize())."""
+        acc = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for name, flops, nbytes, e0, e1 in self.items:
+            a = acc[name]
+            a["launches"] += 1
+            a["total_ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        for a in acc.values():
+            a["avg_ms"] = a["total_ms"] / max(a["launches"], 1)
+        return dict(acc)
+
+
+class span:
+    """with span(name, flops, bytes): <one C-ABI launch>"""
+    __slots__ = ("name", "flops", "nbytes", "e0")
+
+    def __init__(self, name: str, flops: float, nbytes: float = 0.0):
+        self.name, self.flops, self.nbytes, self.e0 = name, flops, nbytes, None
+
+    def __enter__(self):
+        if _active is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and _active is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _active.items.append((self.name, self.flops, self.nbytes, self.e0, e1))

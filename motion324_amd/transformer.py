@@ -1,0 +1,206 @@
+"""Parameter containers with the reference's names + the HIP execution of each block.
+
+Mirrors the public classes of the reference's model/transformer.py (RMSNorm :30-42, MLP :46-81,
+QK_Norm_CrossAttention :84-144, QK_Norm_SelfAttention :146-219, QK_Norm_CrossAttentionBlock
+:324-377, QK_Norm_TransformerBlock :379-423, init_weights :15-25) so that state-dict keys and
+constructor arguments are identical.  The arithmetic is NOT torch.nn: every block runs as a chain
+of libm324 calls (motion324_amd.ops) on raw device buffers:
+
+    LN -> GEMM(qkv) -> split/RMSNorm/transpose -> flash attention -> GEMM(fc)+residual
+       -> LN -> GEMM(fc1)+GELU -> GEMM(fc2)+residual
+
+Activations feeding a GEMM are held in the compute dtype (bf16 speed mode / fp32 parity mode);
+the residual stream is always fp32, as it is in the reference under autocast.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import ACT_GELU
+from .prepared import Prepared
+
+LN_EPS = 1e-5     # nn.LayerNorm default, reference transformer.py:345-346,357,400,411
+RMS_EPS = 1e-5    # reference transformer.py:31
+
+
+def init_weights(module, std=0.02):
+    """Same initialisation rule as the reference (transformer.py:15-25)."""
+    if isinstance(module, (nn.Linear, nn.Embedding)):
+        torch.nn.init.normal_(module.weight, mean=0.0, std=std)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            torch.nn.init.zeros_(module.bias)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = RMS_EPS):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class MLP(nn.Module):
+    def __init__(self, dim, mlp_ratio=4, bias=False, dropout=0.0, activation=nn.GELU, mlp_dim=None):
+        super().__init__()
+        if bias or dropout != 0.0 or activation is not nn.GELU:
+            raise NotImplementedError("the HIP path implements the configuration the reference instantiates "
+                                      "(no bias, no dropout, exact GELU)")
+        hidden = mlp_dim if mlp_dim is not None else int(dim * mlp_ratio)
+        self.mlp = nn.Sequential(nn.Linear(dim, hidden, bias=False), nn.GELU(), nn.Linear(hidden, dim, bias=False),
+                                 nn.Dropout(0.0))
+
+
+class _AttnBase(nn.Module):
+    def __init__(self, dim, head_dim, use_qk_norm):
+        super().__init__()
+        if head_dim != 64:
+            raise NotImplementedError("libm324 attention kernels are specialised for head_dim 64 (config d_head)")
+        assert dim % head_dim == 0, f"Token dimension {dim} should be divisible by head dimension {head_dim}"
+        self.dim, self.head_dim, self.num_heads, self.use_qk_norm = dim, head_dim, dim // head_dim, use_qk_norm
+        if use_qk_norm:
+            self.q_norm = RMSNorm(head_dim)
+            self.k_norm = RMSNorm(head_dim)
+
+    def _qk_w(self, P: Prepared):
+        if not self.use_qk_norm:
+            return None, None
+        return P.vec(self.q_norm.weight), P.vec(self.k_norm.weight)
+
+
+class QK_Norm_SelfAttention(_AttnBase):
+    def __init__(self, dim, head_dim, qkv_bias=False, fc_bias=True, attn_dropout=0.0, fc_dropout=0.0, use_qk_norm=True):
+        super().__init__(dim, head_dim, use_qk_norm)
+        if attn_dropout != 0.0 or fc_dropout != 0.0:
+            raise NotImplementedError("attention / projection dropout is 0 everywhere in the reference model")
+        self.to_qkv = nn.Linear(dim, 3 * dim, bias=qkv_bias)
+        self.fc = nn.Linear(dim, dim, bias=fc_bias)
+
+
+class QK_Norm_CrossAttention(_AttnBase):
+    def __init__(self, dim, head_dim, kv_dim=None, qkv_bias=False, fc_bias=True, attn_dropout=0.0, fc_dropout=0.0,
+                 use_qk_norm=True):
+        super().__init__(dim, head_dim, use_qk_norm)
+        if attn_dropout != 0.0 or fc_dropout != 0.0:
+            raise NotImplementedError("attention / projection dropout is 0 everywhere in the reference model")
+        kv_dim = dim if kv_dim is None else kv_dim
+        self.kv_dim = kv_dim
+        self.to_q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.to_k = nn.Linear(kv_dim, dim, bias=qkv_bias)
+        self.to_v = nn.Linear(kv_dim, dim, bias=qkv_bias)
+        self.fc = nn.Linear(dim, dim, bias=fc_bias)
+
+
+def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor) -> torch.Tensor:
+    """x += fc2(gelu(fc1(LN(x))))  (reference transformer.py:376,422), x fp32 [rows, C], in place."""
+    rows, C = x.shape
+    fc1, fc2 = mlp.mlp[0], mlp.mlp[2]
+    h = torch.empty((rows, C), dtype=P.dtype, device=x.device)
+    ops.layernorm(x, P.vec(norm2.weight), P.vec(norm2.bias), norm2.eps, h)
+    h1 = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=x.device)
+    ops.gemm(h, P.mat(fc1.weight), h1, bias=P.vec(fc1.bias), act=ACT_GELU)
+    ops.gemm(h1, P.mat(fc2.weight), x, bias=P.vec(fc2.bias), residual=x)
+    return x
+
+
+class QK_Norm_TransformerBlock(nn.Module):
+    """Pre-norm self-attention block (reference transformer.py:379-423)."""
+
+    def __init__(self, dim, head_dim, ln_bias=False, attn_qkv_bias=False, attn_dropout=0.0, attn_fc_bias=False,
+                 attn_fc_dropout=0.0, mlp_ratio=4, mlp_bias=False, mlp_dropout=0.0, use_qk_norm=True):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, bias=ln_bias)
+        self.attn = QK_Norm_SelfAttention(dim, head_dim, qkv_bias=attn_qkv_bias, fc_bias=attn_fc_bias,
+                                          attn_dropout=attn_dropout, fc_dropout=attn_fc_dropout, use_qk_norm=use_qk_norm)
+        self.norm2 = nn.LayerNorm(dim, bias=ln_bias)
+        self.mlp = MLP(dim, mlp_ratio=mlp_ratio, bias=mlp_bias, dropout=mlp_dropout)
+
+    def run(self, P: Prepared, x: torch.Tensor, B: int, L: int) -> torch.Tensor:
+        """x: fp32 [B*L, C] residual stream, updated in place (x + attn(LN x); x + mlp(LN x))."""
+        rows, C = x.shape
+        assert rows == B * L
+        a = self.attn
+        h = torch.empty((rows, C), dtype=P.dtype, device=x.device)
+        ops.layernorm(x, P.vec(self.norm1.weight), P.vec(self.norm1.bias), self.norm1.eps, h)
+        qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)
+        ops.gemm(h, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
+        qw, kw = a._qk_w(P)
+        Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads, P.dtype)
+        ops.attention(Q, K, Vt, h)                                       # h reused as the attention output
+        ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
+        return _mlp_residual(P, self.norm2, self.mlp, x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Stand-alone use: x [B, L, C] on a HIP device; precision follows torch.autocast like the reference."""
+        B, L, C = x.shape
+        P = Prepared.for_module(self, x.device)
+        y = x.detach().float().reshape(B * L, C).clone()
+        return self.run(P, y, B, L).reshape(B, L, C)
+
+
+class QK_Norm_CrossAttentionBlock(nn.Module):
+    """Cross-attention block; key and value are the same tensor at both call sites of the reference
+    (transformer.py:324-377, Pcd_motion.py:462,556-560)."""
+
+    def __init__(self, dim, head_dim, kv_dim=None, ln_bias=False, attn_qkv_bias=False, attn_dropout=0.0,
+                 attn_fc_bias=False, attn_fc_dropout=0.0, mlp_ratio=4, mlp_bias=False, mlp_dropout=0.0, use_qk_norm=True):
+        super().__init__()
+        self.norm_q = nn.LayerNorm(dim, bias=ln_bias)
+        self.norm_kv = nn.LayerNorm(kv_dim if kv_dim is not None else dim, bias=ln_bias)
+        self.attn = QK_Norm_CrossAttention(dim, head_dim, kv_dim=kv_dim, qkv_bias=attn_qkv_bias, fc_bias=attn_fc_bias,
+                                           attn_dropout=attn_dropout, fc_dropout=attn_fc_dropout, use_qk_norm=use_qk_norm)
+        self.norm2 = nn.LayerNorm(dim, bias=ln_bias)
+        self.mlp = MLP(dim, mlp_ratio=mlp_ratio, bias=mlp_bias, dropout=mlp_dropout)
+
+    # -- the two halves are exposed separately so the decoder can project the mesh points once and
+    #    reuse them for every frame (the reference recomputes them T times, Pcd_motion.py:539-553)
+    def project_q(self, P: Prepared, query: torch.Tensor, B: int, Lq: int) -> torch.Tensor:
+        """query fp32 [B*Lq, C] -> Q[B,H,Lq,64] = RMSNorm(to_q(LN_q(query)))."""
+        a = self.attn
+        qn = torch.empty(query.shape, dtype=P.dtype, device=query.device)
+        ops.layernorm(query, P.vec(self.norm_q.weight), P.vec(self.norm_q.bias), self.norm_q.eps, qn)
+        q = torch.empty(query.shape, dtype=P.dtype, device=query.device)
+        ops.gemm(qn, P.mat(a.to_q.weight), q, bias=P.vec(a.to_q.bias))
+        qw, _ = a._qk_w(P)
+        Q, _, _ = ops.qkv_split(q, None, None, qw, None, RMS_EPS, B, Lq, a.num_heads, P.dtype)
+        return Q
+
+    def project_kv(self, P: Prepared, kv: torch.Tensor, B: int, Lk: int, row_map=(0, 0, 0)):
+        """kv fp32 rows (optionally gathered through row_map) -> K[B,H,Lk,64], Vt[B,H,64,Lkp]."""
+        a = self.attn
+        C = kv.shape[1]
+        kn = torch.empty((B * Lk, C), dtype=P.dtype, device=kv.device)
+        ops.layernorm(kv, P.vec(self.norm_kv.weight), P.vec(self.norm_kv.bias), self.norm_kv.eps, kn, row_map=row_map)
+        w_kv, b_kv = P.cat_rows((a.to_k.weight, a.to_v.weight)), P.cat_vecs((a.to_k.bias, a.to_v.bias))
+        kvp = torch.empty((B * Lk, 2 * a.dim), dtype=P.dtype, device=kv.device)
+        ops.gemm(kn, w_kv, kvp, bias=b_kv)
+        _, kw = a._qk_w(P)
+        _, K, Vt = ops.qkv_split(None, kvp[:, :a.dim], kvp[:, a.dim:], None, kw, RMS_EPS, B, Lk, a.num_heads, P.dtype)
+        return K, Vt
+
+    def attend(self, P: Prepared, Q, K, Vt, residual: torch.Tensor, res_rows: int, shared_q: bool) -> torch.Tensor:
+        """x = residual[(row % res_rows)] + fc(attention); x += mlp(LN x).  Returns fp32 [B*Lq, C]."""
+        a = self.attn
+        B, Lq = K.shape[0], Q.shape[2]
+        o = torch.empty((B * Lq, a.dim), dtype=P.dtype, device=Q.device)
+        ops.attention(Q, K, Vt, o, shared_q=shared_q)
+        x = torch.empty((B * Lq, a.dim), dtype=torch.float32, device=Q.device)
+        ops.gemm(o, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=residual, res_rows=res_rows)
+        return _mlp_residual(P, self.norm2, self.mlp, x)
+
+    def run(self, P: Prepared, query: torch.Tensor, kv: torch.Tensor, B: int, Lq: int, Lk: int) -> torch.Tensor:
+        Q = self.project_q(P, query, B, Lq)
+        K, Vt = self.project_kv(P, kv, B, Lk)
+        return self.attend(P, Q, K, Vt, query, 0, shared_q=False)
+
+    def forward(self, query, key, value=None):
+        if value is not None and value is not key:
+            raise NotImplementedError("the HIP path fuses the k/v projections of one tensor (as both reference call sites do)")
+        B, Lq, C = query.shape
+        Lk = key.shape[1]
+        P = Prepared.for_module(self, query.device)
+        out = self.run(P, query.detach().float().reshape(B * Lq, C).contiguous(),
+                       key.detach().float().reshape(B * Lk, -1).contiguous(), B, Lq, Lk)
+        return out.reshape(B, Lq, C)

@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP device); run with -m gpu")
+
+
+def has_gpu() -> bool:
+    return torch.cuda.is_available()
+
+
+def pytest_collection_modifyitems(config, items):
+    if has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+# configs of the committed golden cases (must match tests/golden/make_golden.py::CASES)
+CASES = {
+    "tiny": dict(dims=dict(d=192, d_head=64, tokens=8, pcd_layers=1, n_layer=2, frames=3, dino_depth=2),
+                 shape=(2, 3, 40, 100, 64)),
+    "tiny_resize": dict(dims=dict(d=192, d_head=64, tokens=8, pcd_layers=1, n_layer=2, frames=5, dino_depth=2),
+                        shape=(1, 2, 33, 70, 96)),
+    "c1": dict(dims=dict(frames=12), shape=(1, 4, 512, 4096, 256)),
+    "c2": dict(dims=dict(frames=32), shape=(1, 32, 2048, 4096, 512)),
+}
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+_SD_CACHE = {}
+
+
+def synth_sd(dims_kwargs):
+    """Cached synthetic state dict (numpy) for a Dims kwargs dict."""
+    from motion324_amd import synth
+    key = tuple(sorted(dims_kwargs.items()))
+    if key not in _SD_CACHE:
+        _SD_CACHE[key] = synth.synth_state_dict(synth.Dims(**dims_kwargs), seed=0)
+    return _SD_CACHE[key]

@@ -1,0 +1,302 @@
+"""GPU parity of every libm324 entry point (called through the C ABI via motion324_amd.ops) against
+plain torch fp64/fp32 CPU math of the same op.  fp32 kernels: <= 1e-4 relative (f32 MFMA = fmaf chain);
+bf16 kernels: inputs are pre-rounded to bf16 so the only error left is the bf16 rounding of the output
+(<= 2^-8 relative per element) and of P in attention -- bands stated per test."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DT = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from motion324_amd import ops
+    return ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32) * scale
+
+
+def _q(t, dtype):
+    """round to the kernel's operand dtype (and back to fp32 for the reference)"""
+    return t.to(dtype).to(torch.float32)
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 6e-3}
+
+
+# ------------------------------------------------------------------------------------------- gemm
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 192), (1, 768, 64), (257 * 3, 2304, 768), (2048, 768, 3072),
+                                   (130, 576, 256)])
+def test_gemm_plain(dtype, M, N, K):
+    ops = _ops()
+    a, w = _q(_rand((M, K), 1), dtype), _q(_rand((N, K), 2, 0.05), dtype)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), out)
+    ref = a.double() @ w.double().T
+    assert rel_err(out.float(), ref) < TOL[dtype]
+    if dtype == torch.bfloat16:          # element-wise: bf16 rounding of an (almost) exact fp32 sum
+        assert torch.allclose(out.float().cpu(), ref.float(), rtol=2 ** -7, atol=1e-6)
+
+
+def test_gemm_transpose_detecting():
+    """A = identity-like selector with an asymmetric W catches a swapped C layout (rows <-> cols)."""
+    ops = _ops()
+    M = N = 128
+    K = 128
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / (N * K)
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), out)
+    assert torch.allclose(out.cpu(), a @ w.T, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_epilogue_full(dtype):
+    """bias -> GELU -> gamma -> residual (broadcast over row groups) -> row remap, fp32 out, in place residual."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    M, N, K = 3 * 50, 192, 128
+    a, w = _q(_rand((M, K), 3), dtype), _q(_rand((N, K), 4, 0.1), dtype)
+    bias, gamma, res = _rand((N,), 5), 1 + 0.1 * _rand((N,), 6), _rand((50, N), 7)
+    gin, gout, off = 50, 53, 2
+    out = torch.zeros((3 * 53, N), dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), out, bias=bias.to(DEV), act=ACT_GELU, gamma=gamma.to(DEV),
+             residual=res.to(DEV), res_rows=50, row_map=(gin, gout, off))
+    v = a.double() @ w.double().T + bias.double()
+    v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+    v = v * gamma.double() + res.double().repeat(3, 1)
+    ref = torch.zeros(3 * 53, N, dtype=torch.float64)
+    rows = torch.arange(M)
+    ref[(rows // gin) * gout + rows % gin + off] = v
+    assert rel_err(out, ref) < (1e-5 if dtype == torch.float32 else 2e-5)   # fp32 accumulate, fp32 out in both modes
+    # untouched rows stay zero
+    mask = torch.ones(3 * 53, dtype=torch.bool)
+    mask[(rows // gin) * gout + rows % gin + off] = False
+    assert float(out.cpu()[mask].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_inplace_residual(dtype):
+    ops = _ops()
+    M, N, K = 200, 256, 192
+    a, w = _q(_rand((M, K), 8), dtype), _q(_rand((N, K), 9, 0.1), dtype)
+    x0 = _rand((M, N), 10)
+    x = x0.clone().to(DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), x, residual=x)
+    assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
+
+
+def test_gemm_rejects_bad_k():
+    ops = _ops()
+    from motion324_amd.lib import M324Error
+    a = torch.zeros((8, 40), dtype=torch.float32, device=DEV)
+    w = torch.zeros((128, 40), dtype=torch.float32, device=DEV)
+    with pytest.raises(M324Error, match="K=40"):
+        ops.gemm(a, w, torch.empty((8, 128), dtype=torch.float32, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------- layernorm
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C,with_bias,eps", [(768, False, 1e-5), (768, True, 1e-6), (192, True, 1e-5)])
+def test_layernorm(dtype, C, with_bias, eps):
+    ops = _ops()
+    rows = 77
+    x = _rand((rows, C), 11) * 3 + 0.5
+    w, b = 1 + 0.1 * _rand((C,), 12), (_rand((C,), 13) if with_bias else None)
+    out = torch.empty((rows, C), dtype=dtype, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), eps, out)
+    ref = torch.nn.functional.layer_norm(x.double(), (C,), w.double(), None if b is None else b.double(), eps)
+    assert rel_err(out.float(), ref) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+def test_layernorm_row_gather():
+    ops = _ops()
+    C, gin, gout, off = 192, 8, 20, 4
+    x = _rand((3 * gout, C), 14)
+    w = 1 + 0.1 * _rand((C,), 15)
+    out = torch.empty((3 * gin, C), dtype=torch.float32, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), None, 1e-5, out, row_map=(gin, gout, off))
+    sel = x.reshape(3, gout, C)[:, off:off + gin].reshape(-1, C)
+    ref = torch.nn.functional.layer_norm(sel.double(), (C,), w.double(), None, 1e-5)
+    assert rel_err(out, ref) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- qkv split
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,L,H,norm", [(2, 100, 3, True), (1, 324, 12, True), (3, 257, 12, False), (2, 64, 2, True)])
+def test_qkv_split(dtype, B, L, H, norm):
+    ops = _ops()
+    C = H * 64
+    qkv = _q(_rand((B * L, 3 * C), 16), dtype)
+    qw, kw = 1 + 0.1 * _rand((64,), 17), 1 + 0.1 * _rand((64,), 18)
+    d = qkv.to(dtype).to(DEV)
+    Q, K, Vt = ops.qkv_split(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], qw.to(DEV) if norm else None,
+                             kw.to(DEV) if norm else None, 1e-5, B, L, H, dtype)
+    q, k, v = (t.reshape(B, L, H, 64).double() for t in qkv.chunk(3, dim=-1))
+    if norm:
+        q = q * torch.rsqrt((q * q).mean(-1, keepdim=True) + 1e-5) * qw.double()
+        k = k * torch.rsqrt((k * k).mean(-1, keepdim=True) + 1e-5) * kw.double()
+    tol = 1e-6 if dtype == torch.float32 else 4e-3
+    assert rel_err(Q.float(), q.permute(0, 2, 1, 3)) < tol
+    assert rel_err(K.float(), k.permute(0, 2, 1, 3)) < tol
+    Lp = (L + 63) // 64 * 64
+    assert Vt.shape == (B, H, 64, Lp)
+    assert rel_err(Vt.float()[..., :L], v.permute(0, 2, 3, 1)) < 1e-7     # pure data movement: exact
+    assert float(Vt.float()[..., L:].abs().max()) == 0.0 if Lp > L else True
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale):
+    s = torch.einsum("bhqd,bhkd->bhqk", q.double(), k.double()) * scale
+    return torch.einsum("bhqk,bhkd->bqhd", torch.softmax(s, dim=-1), v.double())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 64, 64), (2, 3, 100, 100), (1, 12, 324, 324), (2, 12, 257, 257), (1, 2, 64, 4096),
+                                       (1, 3, 1000, 70), (1, 1, 1, 1), (1, 2, 129, 65)])
+def test_attention(dtype, B, H, Lq, Lk):
+    ops = _ops()
+    q, k, v = (_q(_rand((B, H, L, 64), s, sc), dtype) for L, s, sc in ((Lq, 19, 1.5), (Lk, 20, 1.5), (Lk, 21, 1.0)))
+    Lkp = (Lk + 63) // 64 * 64
+    vt = torch.zeros((B, H, 64, Lkp))
+    vt[..., :Lk] = v.transpose(2, 3)
+    out = torch.full((B * Lq, H * 64), float("nan"), dtype=dtype, device=DEV)
+    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), vt.to(dtype).to(DEV), out)
+    ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(B * Lq, H * 64)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_shared_q(dtype):
+    """decoder pattern: one query set, per-frame K/V of 64 latent tokens (reference Pcd_motion.py:539-560)."""
+    ops = _ops()
+    T, H, Lq, Lk = 5, 3, 200, 64
+    q, k, v = _q(_rand((1, H, Lq, 64), 22), dtype), _q(_rand((T, H, Lk, 64), 23), dtype), _q(_rand((T, H, Lk, 64), 24), dtype)
+    out = torch.empty((T * Lq, H * 64), dtype=dtype, device=DEV)
+    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), v.transpose(2, 3).contiguous().to(dtype).to(DEV), out, shared_q=True)
+    ref = _attn_ref(q.expand(T, -1, -1, -1), k, v, 64 ** -0.5).reshape(T * Lq, H * 64)
+    assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_online_softmax_rescale(dtype):
+    """A late key with a much larger score forces the running-max rescale of every earlier tile."""
+    ops = _ops()
+    B, H, L = 1, 1, 320
+    q, k, v = _q(_rand((B, H, L, 64), 25), dtype), _q(_rand((B, H, L, 64), 26), dtype), _q(_rand((B, H, L, 64), 27), dtype)
+    k[0, 0, 300] = _q(q[0, 0, 7] * 4.0, dtype)           # q7 . k300 >> everything else, in the 5th tile
+    out = torch.empty((L, 64), dtype=dtype, device=DEV)
+    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), v.transpose(2, 3).contiguous().to(dtype).to(DEV), out)
+    ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(L, 64)
+    assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+    assert rel_err(out.float()[7], ref[7]) < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+def test_attention_nan_propagates():
+    """No silent clamping: a NaN key poisons the rows that see it (failure detection)."""
+    ops = _ops()
+    q, k, v = _rand((1, 1, 64, 64), 28), _rand((1, 1, 64, 64), 29), _rand((1, 1, 64, 64), 30)
+    k[0, 0, 3, 5] = float("nan")
+    out = torch.empty((64, 64), dtype=torch.float32, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), v.transpose(2, 3).contiguous().to(DEV), out)
+    assert torch.isnan(out).all()
+
+
+# ------------------------------------------------------------------------------------------- patchify
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Hin", [64, 224, 512])
+def test_patchify(dtype, Hin):
+    ops = _ops()
+    Fr, size, patch, Kp = 2, 224, 14, 640
+    g = torch.Generator().manual_seed(31)
+    video = torch.rand((Fr, Hin, Hin, 3), generator=g)
+    out = ops.patchify(video.to(DEV), size, patch, Kp, dtype).float().cpu()
+    img = torch.nn.functional.interpolate(video.permute(0, 3, 1, 2), (size, size), mode="bilinear", align_corners=False)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    img = (img - mean) / std
+    ref = torch.nn.functional.unfold(img, kernel_size=patch, stride=patch).transpose(1, 2).reshape(Fr * 256, 588)
+    assert rel_err(out[:, :588], ref) < (2e-6 if dtype == torch.float32 else 4e-3)
+    assert float(out[:, 588:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- points
+@pytest.mark.parametrize("dtype", DT)
+def test_point_encode_and_concat(dtype):
+    ops = _ops()
+    P, C, Kp = 333, 192, 256
+    g = torch.Generator().manual_seed(32)
+    xyz = torch.rand((P, 3), generator=g) - 0.5
+    enc = ops.point_encode(xyz.to(DEV), dtype).float().cpu()
+    e = (2.0 ** torch.arange(8, dtype=torch.float32)) * math.pi
+    proj = torch.cat([xyz[:, i:i + 1] * e for i in range(3)], dim=1)           # fp32 products, like the reference einsum
+    ref = torch.cat([proj.double().sin(), proj.double().cos(), xyz.double()], dim=1)
+    assert rel_err(enc[:, :51], ref) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert float(enc[:, 51:].abs().max()) == 0.0
+    feat = torch.full((P, Kp), 7.0, dtype=dtype, device=DEV)
+    nrm, rgb = _rand((P, 3), 33), torch.rand((P, 3), generator=g)
+    ops.point_concat(nrm.to(DEV), rgb.to(DEV), feat, C)
+    f = feat.float().cpu()
+    assert float((f[:, :C] - 7.0).abs().max()) == 0.0
+    assert rel_err(f[:, C:C + 6], torch.cat([nrm, rgb], dim=1)) < (1e-7 if dtype == torch.float32 else 4e-3)
+    assert float(f[:, C + 6:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- assemble
+def test_assemble_tokens():
+    ops = _ops()
+    B, T, K, Pn, C = 2, 3, 8, 16, 192
+    dino_x = _rand((B * T * (Pn + 1), C), 34) * 2
+    dw, db = 1 + 0.1 * _rand((C,), 35), 0.1 * _rand((C,), 36)
+    pos, sp0, spr, mesh = _rand((T * Pn, C), 37), _rand((4, C), 38), _rand((4, C), 39), _rand((B * K, C), 40)
+    lw = 1 + 0.1 * _rand((C,), 41)
+    out = ops.assemble_tokens(dino_x.to(DEV), dw.to(DEV), db.to(DEV), 1e-6, pos.to(DEV), sp0.to(DEV), spr.to(DEV),
+                              mesh.to(DEV), lw.to(DEV), 1e-5, B, T, K, Pn)
+    LN = torch.nn.functional.layer_norm
+    dn = LN(dino_x.double().reshape(B, T, Pn + 1, C)[:, :, 1:], (C,), dw.double(), db.double(), 1e-6)
+    vid = dn + pos.double().reshape(1, T, Pn, C)
+    special = torch.stack([sp0] + [spr] * (T - 1), dim=0).double().unsqueeze(0).expand(B, -1, -1, -1)
+    tok = torch.cat([special, mesh.double().reshape(B, 1, K, C).expand(-1, T, -1, -1), vid], dim=2)
+    ref = LN(tok, (C,), lw.double(), None, 1e-5).reshape(-1, C)
+    assert rel_err(out, ref) < 1e-6
+
+
+def test_dino_cls_rows():
+    ops = _ops()
+    Fr, rpf, C = 3, 5, 192
+    x = torch.zeros((Fr * rpf, C), device=DEV)
+    cls, pos0 = _rand((C,), 42), _rand((C,), 43)
+    ops.dino_cls_rows(cls.to(DEV), pos0.to(DEV), x, Fr, rpf)
+    ref = torch.zeros(Fr, rpf, C)
+    ref[:, 0] = cls + pos0
+    assert torch.equal(x.cpu(), ref.reshape(-1, C))
+
+
+# ------------------------------------------------------------------------------------------- head / loss
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_n3(dtype):
+    ops = _ops()
+    M, K = 1001, 768
+    a, w, b = _q(_rand((M, K), 44), dtype), _rand((3, K), 45, 0.05), _rand((3,), 46)
+    out = torch.empty((M, 3), dtype=torch.float32, device=DEV)
+    ops.linear_n3(a.to(dtype).to(DEV), w.to(DEV), b.to(DEV), out)
+    assert rel_err(out, a.double() @ w.double().T + b.double()) < 1e-5
+
+
+def test_mse():
+    ops = _ops()
+    a, b = _rand((2, 3, 1000, 3), 47), _rand((2, 3, 1000, 3), 48)
+    out = ops.mse(a.to(DEV), b.to(DEV), 0.5)
+    assert abs(float(out) - 0.5 * float(((a.double() - b.double()) ** 2).mean())) < 1e-6
