@@ -64,7 +64,9 @@ def cpu_baseline(sd, sample_np, frames):
     """The CPU oracle (fp32 restatement of the reference path) timed on this host: ONE forward of the
     same 32-frame clip, all cores, no warm-up (about 10-30 s of CPU work)."""
     from oracle import ref_forward as oracle
-    threads = os.cpu_count() or 1
+    # torch's CPU kernels stop scaling (and then collapse) far below a 256-thread host: 32 threads is
+    # the measured sweet spot of this workload's GEMM / attention sizes; `cores` reports what was used
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     sample = oracle.to_torch(sample_np)
     t0 = time.perf_counter()
