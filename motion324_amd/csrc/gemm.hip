@@ -12,6 +12,7 @@
 // ds_read_b128 (bf16) and 2-way ds_read_b64 (fp32 parity mode).
 // Pipeline: global -> registers (issued before the MFMAs of the current tile) -> LDS (after them),
 // double-buffered LDS, one barrier per K-tile.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -29,7 +30,224 @@ struct Epilogue {
     int row_gin, row_gout, row_off;
 };
 
+// GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
+// bf16 rounding of the result); the fp32 parity path keeps erff.  ~12 VALU + 2 transcendental ops
+// instead of ocml's branchy erff -- the fc1 epilogue (128x128 GELUs per workgroup) is otherwise as
+// long as its whole K = 768 main loop.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 1 - erf(z), z >= 0
+    const float phi = x >= 0.f ? 1.0f - 0.5f * erfc_z : 0.5f * erfc_z;                       // Phi(x)
+    return x * phi;
+}
+
+template <typename TOUT>
+__device__ __forceinline__ float apply_gelu(float v) {
+    if constexpr (sizeof(TOUT) == 2) return gelu_fast(v);
+    else return gelu_erf(v);
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+
+// One K-tile of MFMAs for a wave's 64 x 64 block (2 x 2 accumulators of 32 x 32).
+// SWAP = false: acc[i][j] = A_i . W_j^T  (C layout: lane = column n, registers = rows m)
+// SWAP = true : acc[i][j] = W_j . A_i^T  (C layout: lane = row m, registers = 4-runs of columns n) --
+//               the transposed accumulator lets the epilogue read/write 4 consecutive columns per lane.
+template <typename TIN, bool SWAP = false>
+__device__ __forceinline__ void mma_tile(const unsigned char* sa, const unsigned char* sb, int arow0, int brow0, int hi,
+                                         f32x16 (&acc)[2][2]) {
+    if constexpr (sizeof(TIN) == 2) {
+        // bf16: 4 k-steps of 16; lane (row, hi) supplies k = ks*16 + hi*8 .. +7 = chunk ks*2 + hi
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(arow0 + i * 32, ks * 2 + hi));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(sb + lds_off(brow0 + i * 32, ks * 2 + hi));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+        // f32 parity mode: chunk c holds k = 4c..4c+3; lane hi reads the 8 bytes at hi*8 of it
+        // (k = 4c+2hi, 4c+2hi+1) and feeds them to two 32x32x2 MFMAs.  A and W use the same map,
+        // so each k is contracted exactly once.
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x2 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const f32x2*>(sa + lds_off(arow0 + i * 32, c) + hi * 8);
+                bfr[i] = *reinterpret_cast<const f32x2*>(sb + lds_off(brow0 + i * 32, c) + hi * 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[j][e], af[i][e], acc[i][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// Epilogue of a wave's 64 x 64 block.  32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+// Residual reads are issued as one batch of 16 unconditional loads per 32x32 block (indices clamped
+// into range) so they overlap instead of paying one HBM round trip per element; stores are predicated.
+// ACT: 0 none, 1 GELU, -1 decide at run time.  RES: 0 no residual / no row remap, 1 residual[m] (same row),
+// 2 generic (row-modulo residual and/or output row remap), -1 decide at run time.
+template <typename TOUT, int ACT, int RES>
+__device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], TOUT* C, long ldc, int M, int N, int mw, int nw,
+                                               int l31, int hi, const Epilogue& ep) {
+    const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
+    const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
+    const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
+    const bool gelu = ACT < 0 ? ep.act == M324_ACT_GELU : ACT == 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nw + j * 32 + l31;
+        const bool nok = n < N;
+        const int nc = nok ? n : N - 1;
+        const float bias = ep.bias ? ep.bias[nc] : 0.f;
+        const float gamma = ep.gamma ? ep.gamma[nc] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = mw + i * 32 + 4 * hi;
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int mc = min(mb + (r & 3) + 8 * (r >> 2), M - 1);
+                    if (res_mod) mc %= ep.res_rows;
+                    res[r] = ep.residual[(long)mc * ep.ldr + nc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bias;
+                if (gelu) v = apply_gelu<TOUT>(v);
+                v = fmaf(v, gamma, res[r]);
+                long orow = m;
+                if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
+                if (nok && m < M) Elem<TOUT>::store(C + orow * ldc + n, v);
+            }
+        }
+    }
+}
+
+
+// Epilogue for SWAPPED accumulators: lane = output row m (32 rows per block), registers = columns
+// n = 8*g + 4*hi + e (g = r >> 2, e = r & 3): every lane owns runs of 4 consecutive columns, so residual
+// reads are float4 loads and stores are 16-byte (fp32) / 8-byte (bf16) -- 4x fewer memory instructions
+// than the column-per-lane layout, all residual loads of a block in flight together.  Needs N % 4 == 0.
+template <typename TOUT>
+__device__ __forceinline__ void store4_out(TOUT* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4_out<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4_out<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+
+template <typename TOUT, int ACT, int RES>
+__device__ __forceinline__ void store_tile_out_t(const f32x16 (&acc)[2][2], TOUT* C, long ldc, int M, int N, int mw, int nw,
+                                                 int l31, int hi, const Epilogue& ep) {
+    const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
+    const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
+    const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
+    const bool gelu = ACT == 1;
+    // column of run (j, g): n = nw + 32 j + 8 g + 4 hi; clamped copy for the (unconditional) loads
+    int ncl[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ncl[j][g] = min(nw + j * 32 + 8 * g + 4 * hi, N - 4);
+
+    // ---- phase 1: every global read of the epilogue is issued before anything is consumed
+    float4 res[2][2][4], bi[2][4], ga[2][4];
+    TOUT* crow[2];
+    bool mok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mw + i * 32 + l31;
+        mok[i] = m < M;
+        long orow = m;
+        if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
+        crow[i] = C + orow * ldc;
+        if (has_res) {
+            int mr = mok[i] ? m : M - 1;
+            if (res_mod) mr %= ep.res_rows;
+            const float* rrow = ep.residual + (long)mr * ep.ldr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) res[i][j][g] = *reinterpret_cast<const float4*>(rrow + ncl[j][g]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) res[i][j][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (ep.bias) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bi[j][g] = *reinterpret_cast<const float4*>(ep.bias + ncl[j][g]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bi[j][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (ep.gamma) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ga[j][g] = *reinterpret_cast<const float4*>(ep.gamma + ncl[j][g]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ga[j][g] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+
+    // ---- phase 2: arithmetic + predicated wide stores
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nw + j * 32 + 8 * g + 4 * hi;
+                float v0 = acc[i][j][g * 4 + 0] + bi[j][g].x, v1 = acc[i][j][g * 4 + 1] + bi[j][g].y;
+                float v2 = acc[i][j][g * 4 + 2] + bi[j][g].z, v3 = acc[i][j][g * 4 + 3] + bi[j][g].w;
+                if (gelu) {
+                    v0 = apply_gelu<TOUT>(v0); v1 = apply_gelu<TOUT>(v1);
+                    v2 = apply_gelu<TOUT>(v2); v3 = apply_gelu<TOUT>(v3);
+                }
+                v0 = fmaf(v0, ga[j][g].x, res[i][j][g].x); v1 = fmaf(v1, ga[j][g].y, res[i][j][g].y);
+                v2 = fmaf(v2, ga[j][g].z, res[i][j][g].z); v3 = fmaf(v3, ga[j][g].w, res[i][j][g].w);
+                if (mok[i] && n < N) store4_out<TOUT>(crow[i] + n, v0, v1, v2, v3);
+            }
+}
 
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
@@ -99,79 +317,118 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TIN* __restrict__ A,
         if (more) load_tile(kt + 1);
         const unsigned char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
         const unsigned char* sb = sa + TILE_BYTES;
-        if constexpr (sizeof(TIN) == 2) {
-            // bf16: 4 k-steps of 16; lane (row, hi) supplies k = ks*16 + hi*8 .. +7 = chunk ks*2 + hi
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 af[2], bfr[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(arow0 + i * 32, ks * 2 + hi));
-                    bfr[i] = *reinterpret_cast<const bf16x8*>(sb + lds_off(brow0 + i * 32, ks * 2 + hi));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-            // f32 parity mode: chunk c holds k = 4c..4c+3; lane hi reads the 8 bytes at hi*8 of it
-            // (k = 4c+2hi, 4c+2hi+1) and feeds them to two 32x32x2 MFMAs.  A and W use the same map,
-            // so each k is contracted exactly once.
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                f32x2 af[2], bfr[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const f32x2*>(sa + lds_off(arow0 + i * 32, c) + hi * 8);
-                    bfr[i] = *reinterpret_cast<const f32x2*>(sb + lds_off(brow0 + i * 32, c) + hi * 8);
-                }
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
-            }
-        }
+        mma_tile<TIN>(sa, sb, arow0, brow0, hi, acc);
         if (more) store_tile((kt + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue.  32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int res_rows = ep.res_rows > 0 ? ep.res_rows : M;
+    store_tile_out<TOUT, -1, -1>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v2: same tile / LDS image / MFMA schedule, but the K-tiles are staged by LDS-DMA
+// (global_load_lds_dwordx4: HBM -> LDS without a VGPR round trip and without the ds_write pass that
+// made v1 LDS-bound: 32 KiB of ds_write_b128 per K-tile at ~79 B/clk/CU is ~415 cycles against 512
+// cycles of MFMA).  A wave-instruction writes 1 KiB = 8 tile rows linearly (LDS address = wave-uniform
+// base + lane * 16), so the XOR swizzle is applied to the SOURCE address: lane l fills row
+// r = 8*g + (l >> 3), slot p = l & 7, which must hold logical chunk c = p ^ ((r >> 1) & 7).
+// Rows past M (or N) are clamped to the last valid row instead of zero-filled: an output row depends
+// only on its own A row / W row, and rows >= M, columns >= N are never stored.
+// Double-buffered; the barrier at the top of iteration kt both publishes tile kt (hipcc drains the
+// LDS-DMA queue, vmcnt(0), before s_barrier) and retires every wave's reads of the buffer that tile
+// kt+1 is about to overwrite.
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef __attribute__((address_space(1))) const void glb_ptr_t;
+
+template <typename TIN, typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
+                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];   // A0 B0 A1 B1
+    constexpr int EPC = Elem<TIN>::PER16;
+    constexpr int BK = ROWB / sizeof(TIN);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // this wave stages row groups g = wave*4 + i (8 rows each) of both operands
+    const TIN* ga[4];
+    const TIN* gb[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
-        if (n >= N) continue;
-        const float bias = ep.bias ? ep.bias[n] : 0.f;
-        const float gamma = ep.gamma ? ep.gamma[n] : 1.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m >= M) continue;
-                float v = acc[i][j][r] + bias;
-                if (ep.act == M324_ACT_GELU) v = gelu_erf(v);
-                v *= gamma;
-                if (ep.residual) v += ep.residual[(long)(m % res_rows) * ep.ldr + n];
-                long orow = m;
-                if (ep.row_gin > 0) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
-                Elem<TOUT>::store(C + orow * ldc + n, v);
-            }
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c * EPC;
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c * EPC;
     }
+    auto issue_tile = [&](int kt, int buf) {
+        unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave * 4096;
+        unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)kt * BK), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)kt * BK), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    const int arow0 = wm * 64 + l31, brow0 = wn * 64 + l31;
+    issue_tile(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
+        const unsigned char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
+        mma_tile<TIN, true>(sa, sa + TILE_BYTES, arow0, brow0, hi, acc);
+    }
+    store_tile_out_t<TOUT, ACT, RES>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+}
+
+// the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
+static bool vec_ok(const m324_gemm_args* a) {
+    const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
+    auto al = [](const void* p, int b) { return ((uintptr_t)p % b) == 0; };
+    return a->N % 4 == 0 && a->N >= 4 && (a->ldc * osz) % (4 * osz) == 0 && al(a->C, 4 * osz) &&
+           (!a->residual || (a->ldr % 4 == 0 && al(a->residual, 16))) && (!a->bias || al(a->bias, 16)) &&
+           (!a->gamma || al(a->gamma, 16));
+}
+
+// M324_GEMM=v1 selects the register-staged kernel (kept for A/B measurements)
+static bool use_v1() {
+    static const bool v = [] { const char* e = getenv("M324_GEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
+    return v;
 }
 
 template <typename TIN, typename TOUT>
 int launch(const m324_gemm_args* a, hipStream_t s) {
     Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
-    hipLaunchKernelGGL((gemm_kernel<TIN, TOUT>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda, (const TIN*)a->W,
-                       a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
+    if (use_v1() || !vec_ok(a))
+        hipLaunchKernelGGL((gemm_kernel<TIN, TOUT>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda, (const TIN*)a->W,
+                           a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
+    else {
+        const int res = !a->residual && a->row_gin <= 0 ? 0
+                        : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
+#define M324_GLDS(ACT, RES)                                                                                              \
+    hipLaunchKernelGGL((gemm_glds_kernel<TIN, TOUT, ACT, RES>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda,         \
+                       (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep)
+        if (a->act == M324_ACT_GELU) {
+            if (res == 0) M324_GLDS(1, 0); else M324_GLDS(1, 2);
+        } else {
+            if (res == 0) M324_GLDS(0, 0); else if (res == 1) M324_GLDS(0, 1); else M324_GLDS(0, 2);
+        }
+#undef M324_GLDS
+    }
     M324_CHECK_LAUNCH("m324_gemm");
     return M324_OK;
 }
