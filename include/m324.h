@@ -82,9 +82,11 @@ int m324_layernorm(const float* x, long ldx, const float* w, const float* b, flo
  *   row b*L + l, columns h*64 .. h*64+63.  q_w / k_w: RMSNorm weights [64] or NULL (DINO: no qk-norm).
  *   Outputs (same dtype): Q[B,H,L,64], K[B,H,L,64], Vt[B,H,64,Lp] with Lp = round_up(L, 64);
  *   Vt columns L..Lp-1 are written as zeros.  head_dim is fixed at 64 (config d_head).
+ *   q_scale multiplies the (normalised) q before it is rounded to `dtype`: pass softmax_scale * log2(e)
+ *   and call m324_attention with q_prescaled = 1 (saves one multiply per score in the kernel), or 1.0f.
  * ------------------------------------------------------------------------------------------ */
 int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, const void* v_src, long ldv,
-                   const float* q_w, const float* k_w, float eps,
+                   const float* q_w, const float* k_w, float eps, float q_scale,
                    void* Q, void* K, void* Vt, int B, int L, int H, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -94,9 +96,10 @@ int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, con
  *   Q[Bq,H,Lq,64] (q_bstride elements between batches; 0 = one query set shared by every batch, as the
  *   decoder does with the mesh points, Pcd_motion.py:534-560), K[B,H,Lk,64], Vt[B,H,64,Lkp]
  *   (Lkp = round_up(Lk,64), zero padded).  O[B, Lq, H*64] token-major (ldo = row stride), same dtype.
+ *   q_prescaled != 0: Q already holds q * scale * log2(e) (see m324_qkv_split) and `scale` is ignored.
  * ------------------------------------------------------------------------------------------ */
 int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo,
-                   int B, int H, int Lq, int Lk, float scale, int dtype, void* stream);
+                   int B, int H, int Lq, int Lk, float scale, int q_prescaled, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * m324_patchify: video frames -> DINOv2 patch rows.

@@ -16,7 +16,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libm324.so")
 SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "elementwise.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "m324.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified 512-entry file), which removes the
+# v_accvgpr_read/write shuffling around every softmax / epilogue access of an accumulator
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc() -> str:

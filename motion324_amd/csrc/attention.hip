@@ -28,8 +28,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 // ------------------------------------------------------------------------------------------- bf16
 __device__ __forceinline__ int k_off(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
-__device__ __forceinline__ int v_off(int row, int c8) { return row * 128 + ((c8 ^ ((row >> 1) & 15)) << 3); }
+// the key also folds in bit 5 of the row so that rows d and d+32 are NOT a constant offset apart: otherwise
+// hipcc fuses their reads into ds_read2st64_b64, which is half-rate and banked mod 32 (2-way conflicts)
+__device__ __forceinline__ int v_off(int row, int c8) { return row * 128 + ((c8 ^ (((row >> 1) ^ (row >> 5)) & 15)) << 3); }
 
+// PRESCALED: Q already carries scale * log2(e) (m324_qkv_split's q_scale), so scores are log2-domain.
+template <bool PRESCALED>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
@@ -85,7 +89,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;   // running max (log2 domain) and this lane's partial row sum
+    // Online softmax with a LAZY reference maximum (log2 domain).  m_ref is the value the scores are
+    // measured against; it is folded into the MFMA accumulator's initial value (s' = K.Q - m_ref comes
+    // straight out of the matrix core) and is only moved when some score of the tile exceeds it by more
+    // than THR -- so the common tile costs one exp2, one add and half a max3 / cvt per score and never
+    // touches the O accumulators.  P <= 2^THR keeps everything far inside fp32 / bf16 range.
+    constexpr float THR = 8.0f;
+    float m_ref = 0.f, l_run = 0.f;     // l_run: this lane's partial row sum (its 32 of the tile's 64 keys)
+    bool first = true;
 
     const int nt = (Lk + KV - 1) / KV;
     load_tile(0);
@@ -98,20 +109,25 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         const unsigned char* sk = smem + (t & 1) * 16384;
         const unsigned char* sv = sk + 8192;
 
-        // ---- S^T = K Q^T : two 32-key blocks
+        // ---- S'^T = K Q^T - m_ref : two 32-key blocks
+        const float init = PRESCALED ? -m_ref : -m_ref / scale_log2e;
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[kb][r] = init;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
-
-        // ---- online softmax (log2 domain).  Lane holds keys kv = kb*32 + (r&3) + 8*(r>>2) + 4*hi
+        if (!PRESCALED) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] *= scale_log2e;
+        }
         const int kv0 = t * KV;
         if (kv0 + KV > Lk) {   // ragged last tile: mask keys >= Lk (wave-uniform branch)
 #pragma unroll
@@ -126,30 +142,38 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * scale_log2e);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float rs = 0.f;
+        // move the reference only when needed (wave-uniform decision; NaN scores also take this path)
+        if (first || !__all(mx <= THR)) {
+            const float shift = first ? mx : fmaxf(mx, 0.f);      // new m_ref = m_ref + shift (never decreases)
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-shift);
+            m_ref += shift;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= shift;
+            first = false;
+        }
+        f32x2 rs2 = {0.f, 0.f};
         bf16x8 pf[4];   // P^T fragments, k-step j = kb*2 + (r>>3)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             uint32_t pk[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][r], scale_log2e, -m_new));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][r + 1], scale_log2e, -m_new));
-                rs += p0 + p1;
-                pk[r >> 1] = pack_bf16x2(p0, p1);
+                f32x2 p = {__builtin_amdgcn_exp2f(s[kb][r]), __builtin_amdgcn_exp2f(s[kb][r + 1])};
+                rs2 += p;
+                pk[r >> 1] = pack_bf16x2(p[0], p[1]);
             }
             uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             pf[kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
             pf[kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
         }
-        l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_run += rs2[0] + rs2[1];
 
         // ---- O^T += Vt P^T.  k-step j covers keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}
 #pragma unroll
@@ -304,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 }  // namespace
 
 extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B,
-                              int H, int Lq, int Lk, float scale, int dtype, void* stream) {
+                              int H, int Lq, int Lk, float scale, int q_prescaled, int dtype, void* stream) {
     M324_REQUIRE(Q && K && Vt && O, "m324_attention: null pointer");
     M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "m324_attention: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
     M324_REQUIRE(ldo >= (long)H * 64, "m324_attention: ldo too small");
@@ -312,11 +336,15 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
     const int Lkp = (Lk + 63) / 64 * 64;
     dim3 grid(ceil_div(Lq, QB), H, B);
     hipStream_t s = (hipStream_t)stream;
-    const float sl = scale * LOG2E;
+    const float sl = q_prescaled ? 1.0f : scale * LOG2E;
     if (dtype == M324_BF16) {
         M324_REQUIRE((ldo * 2) % 8 == 0, "m324_attention: ldo misaligned");
-        hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K,
-                           (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl);
+        if (q_prescaled)
+            hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K,
+                               (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl);
+        else
+            hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)Q, q_bstride,
+                               (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl);
     } else if (dtype == M324_F32) {
         M324_REQUIRE(ldo % 4 == 0, "m324_attention: ldo misaligned");
         hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, s, (const float*)Q, q_bstride, (const float*)K,

@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs, long ldq, const T* __restrict__ ks, long ldk,
                                                         const T* __restrict__ vs, long ldv, const float* __restrict__ qw,
-                                                        const float* __restrict__ kw, float eps, T* __restrict__ Q,
-                                                        T* __restrict__ K, T* __restrict__ Vt, int L, int H, int Lp) {
+                                                        const float* __restrict__ kw, float eps, float q_scale,
+                                                        T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vt, int L, int H,
+                                                        int Lp) {
     __shared__ float tile[64][65];
     const int t = threadIdx.x, tok = t >> 2, part = t & 3;
     const int b = blockIdx.z, h = blockIdx.y, l0 = blockIdx.x * 64;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
     const long srow = (long)b * L + l;
     const long hbase = ((long)b * H + h);
 
-    auto do_qk = [&](const T* src, long ld, const float* w, T* dst) {
+    auto do_qk = [&](const T* src, long ld, const float* w, T* dst, float post) {
         float v[16];
         if (ok) {
             const T* p = src + srow * ld + h * 64 + part * 16;
@@ -112,14 +113,18 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = v[i] * r * w[part * 16 + i];
         }
+        if (post != 1.0f) {   // softmax scale * log2(e) folded into Q before its (single) rounding
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] *= post;
+        }
         if (ok) {
             T* o = dst + (hbase * L + l) * 64 + part * 16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) store4<T>(o + i * 4, v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
         }
     };
-    if (qs) do_qk(qs, ldq, qw, Q);
-    if (ks) do_qk(ks, ldk, kw, K);
+    if (qs) do_qk(qs, ldq, qw, Q, q_scale);
+    if (ks) do_qk(ks, ldk, kw, K, 1.0f);
     if (vs) {
         if (ok) {
             const T* p = vs + srow * ldv + h * 64 + part * 16;
@@ -336,8 +341,8 @@ extern "C" int m324_layernorm(const float* x, long ldx, const float* w, const fl
 }
 
 extern "C" int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, const void* v_src, long ldv,
-                              const float* q_w, const float* k_w, float eps, void* Q, void* K, void* Vt, int B, int L, int H,
-                              int dtype, void* stream) {
+                              const float* q_w, const float* k_w, float eps, float q_scale, void* Q, void* K, void* Vt, int B,
+                              int L, int H, int dtype, void* stream) {
     M324_REQUIRE(B > 0 && L > 0 && H > 0, "m324_qkv_split: empty problem");
     M324_REQUIRE((!q_src || Q) && (!k_src || K) && (!v_src || Vt), "m324_qkv_split: missing output");
     M324_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "m324_qkv_split: leading dims must be multiples of 4");
@@ -346,7 +351,7 @@ extern "C" int m324_qkv_split(const void* q_src, long ldq, const void* k_src, lo
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, "m324_qkv_split",
                    hipLaunchKernelGGL(qkv_split_kernel<T>, grid, dim3(256), 0, s, (const T*)q_src, ldq, (const T*)k_src, ldk,
-                                      (const T*)v_src, ldv, q_w, k_w, eps, (T*)Q, (T*)K, (T*)Vt, L, H, Lp));
+                                      (const T*)v_src, ldv, q_w, k_w, eps, q_scale, (T*)Q, (T*)K, (T*)Vt, L, H, Lp));
     M324_CHECK_LAUNCH("m324_qkv_split");
     return M324_OK;
 }

@@ -142,8 +142,9 @@ class DinoEncoder(nn.Module):
         for blk in m.blocks:
             ops.layernorm(x, P.vec(blk.norm1.weight), P.vec(blk.norm1.bias), DINO_EPS, h)
             ops.gemm(h, P.mat(blk.attn.qkv.weight), qkv, bias=P.vec(blk.attn.qkv.bias))
-            Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, None, 0.0, Fr, Lt, H, P.dtype)
-            ops.attention(Q, K, Vt, h)
+            Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, None, 0.0, Fr, Lt, H, P.dtype,
+                                     q_scale=ops.Q_PRESCALE)
+            ops.attention(Q, K, Vt, h, prescaled=True)
             ops.gemm(h, P.mat(blk.attn.proj.weight), x, bias=P.vec(blk.attn.proj.bias), gamma=P.vec(blk.ls1.gamma),
                      residual=x)
             ops.layernorm(x, P.vec(blk.norm2.weight), P.vec(blk.norm2.bias), DINO_EPS, h)

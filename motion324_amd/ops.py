@@ -106,8 +106,12 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: 
     return out
 
 
+LOG2E = 1.4426950408889634
+Q_PRESCALE = (64 ** -0.5) * LOG2E      # softmax scale of head_dim 64, log2 domain
+
+
 def qkv_split(q_src, k_src, v_src, q_w, k_w, eps: float, B: int, Lq: int, H: int, dtype: torch.dtype, *,
-              q_out=None, k_out=None, vt_out=None):
+              q_scale: float = 1.0, q_out=None, k_out=None, vt_out=None):
     """Head-major Q[B,H,L,64], K[B,H,L,64], Vt[B,H,64,Lp] from token-major sources (any may be None).
 
     All given sources share B and L (use separate calls for cross-attention's q and k/v)."""
@@ -131,14 +135,14 @@ def qkv_split(q_src, k_src, v_src, q_w, k_w, eps: float, B: int, Lq: int, H: int
     pk, ldk = src(k_src, "k_src")
     pv, ldv = src(v_src, "v_src")
     L.check(L.load().m324_qkv_split(pq, ldq, pk, ldk, pv, ldv, _vec(q_w, 64, "q_w"), _vec(k_w, 64, "k_w"), eps,
-                                    _p(Q), _p(K), _p(Vt), B, Lq, H, code_of(dtype), _stream()), "m324_qkv_split")
+                                    q_scale, _p(Q), _p(K), _p(Vt), B, Lq, H, code_of(dtype), _stream()), "m324_qkv_split")
     return Q, K, Vt
 
 
 def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Tensor, *, shared_q: bool = False,
-              scale: Optional[float] = None) -> torch.Tensor:
+              scale: Optional[float] = None, prescaled: bool = False) -> torch.Tensor:
     """out[B*Lq, H*64] = softmax(Q K^T scale) V.  Q[Bq,H,Lq,64] (Bq == 1 with shared_q), K[B,H,Lk,64],
-    Vt[B,H,64,Lkp]."""
+    Vt[B,H,64,Lkp].  prescaled: Q was produced with qkv_split(q_scale=Q_PRESCALE)."""
     B, H, Lk, D = K.shape
     Lq = Q.shape[2]
     if D != 64 or Q.shape[3] != 64 or Q.shape[1] != H or Vt.shape[:3] != (B, H, 64) or Vt.shape[3] != (Lk + 63) // 64 * 64:
@@ -157,8 +161,8 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     esz = Q.element_size()
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
               esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq)):
-        L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, code_of(Q.dtype),
-                                        _stream()), "m324_attention")
+        L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, int(prescaled),
+                                        code_of(Q.dtype), _stream()), "m324_attention")
     return out
 
 

@@ -127,8 +127,9 @@ class QK_Norm_TransformerBlock(nn.Module):
         qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)
         ops.gemm(h, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
         qw, kw = a._qk_w(P)
-        Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads, P.dtype)
-        ops.attention(Q, K, Vt, h)                                       # h reused as the attention output
+        Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads, P.dtype,
+                                 q_scale=ops.Q_PRESCALE)
+        ops.attention(Q, K, Vt, h, prescaled=True)                                       # h reused as the attention output
         ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
         return _mlp_residual(P, self.norm2, self.mlp, x)
 
@@ -164,7 +165,7 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         q = torch.empty(query.shape, dtype=P.dtype, device=query.device)
         ops.gemm(qn, P.mat(a.to_q.weight), q, bias=P.vec(a.to_q.bias))
         qw, _ = a._qk_w(P)
-        Q, _, _ = ops.qkv_split(q, None, None, qw, None, RMS_EPS, B, Lq, a.num_heads, P.dtype)
+        Q, _, _ = ops.qkv_split(q, None, None, qw, None, RMS_EPS, B, Lq, a.num_heads, P.dtype, q_scale=ops.Q_PRESCALE)
         return Q
 
     def project_kv(self, P: Prepared, kv: torch.Tensor, B: int, Lk: int, row_map=(0, 0, 0)):
@@ -185,7 +186,7 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         a = self.attn
         B, Lq = K.shape[0], Q.shape[2]
         o = torch.empty((B * Lq, a.dim), dtype=P.dtype, device=Q.device)
-        ops.attention(Q, K, Vt, o, shared_q=shared_q)
+        ops.attention(Q, K, Vt, o, shared_q=shared_q, prescaled=True)
         x = torch.empty((B * Lq, a.dim), dtype=torch.float32, device=Q.device)
         ops.gemm(o, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=residual, res_rows=res_rows)
         return _mlp_residual(P, self.norm2, self.mlp, x)

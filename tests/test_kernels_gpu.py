@@ -150,6 +150,8 @@ def test_qkv_split(dtype, B, L, H, norm):
     tol = 1e-6 if dtype == torch.float32 else 4e-3
     assert rel_err(Q.float(), q.permute(0, 2, 1, 3)) < tol
     assert rel_err(K.float(), k.permute(0, 2, 1, 3)) < tol
+    Q2, _, _ = ops.qkv_split(d[:, :C], None, None, qw.to(DEV) if norm else None, None, 1e-5, B, L, H, dtype, q_scale=0.25)
+    assert rel_err(Q2.float(), 0.25 * q.permute(0, 2, 1, 3)) < tol        # power-of-two scale: same rounding
     Lp = (L + 63) // 64 * 64
     assert Vt.shape == (B, H, 64, Lp)
     assert rel_err(Vt.float()[..., :L], v.permute(0, 2, 3, 1)) < 1e-7     # pure data movement: exact
@@ -176,6 +178,45 @@ def test_attention(dtype, B, H, Lq, Lk):
     ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(B * Lq, H * 64)
     assert torch.isfinite(out.float()).all()
     assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 200, 333), (2, 3, 324, 324), (1, 1, 40, 1000)])
+def test_attention_prescaled_q(dtype, B, H, Lq, Lk):
+    """Q carrying scale*log2(e) (m324_qkv_split q_scale) + q_prescaled=1 == plain softmax attention."""
+    ops = _ops()
+    q, k, v = (_rand((B, H, L, 64), s, 1.5) for L, s in ((Lq, 51), (Lk, 52), (Lk, 53)))
+    k, v = _q(k, dtype), _q(v, dtype)
+    qs = _q(q * ops.Q_PRESCALE, dtype)                       # what qkv_split would store
+    Lkp = (Lk + 63) // 64 * 64
+    vt = torch.zeros((B, H, 64, Lkp))
+    vt[..., :Lk] = v.transpose(2, 3)
+    out = torch.empty((B * Lq, H * 64), dtype=dtype, device=DEV)
+    ops.attention(qs.to(dtype).to(DEV), k.to(dtype).to(DEV), vt.to(dtype).to(DEV), out, prescaled=True)
+    sc = torch.einsum("bhqd,bhkd->bhqk", qs.double(), k.double()) * math.log(2.0)     # exp2(x) = exp(x ln 2)
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, dim=-1), v.double()).reshape(B * Lq, H * 64)
+    assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_lazy_max_growth(dtype):
+    """Scores that keep growing along the key axis force the lazy reference maximum to move many times,
+    by more and by less than its threshold, and a block of very negative scores must not disturb it."""
+    ops = _ops()
+    B, H, L = 1, 1, 640
+    q = _rand((B, H, 96, 64), 54)
+    k = _rand((B, H, L, 64), 55)
+    ramp = torch.linspace(0.2, 6.0, L)                       # later keys align more and more with q
+    k = k * 0.3 + q[0, 0, 5][None, None, None, :] * ramp[None, None, :, None] / 8
+    k[0, 0, 200:264] = -k[0, 0, 200:264] * 3                # one tile of strongly negative scores for q5
+    v = _rand((B, H, L, 64), 56)
+    q, k, v = _q(q, dtype), _q(k, dtype), _q(v, dtype)
+    out = torch.empty((96, 64), dtype=dtype, device=DEV)
+    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), v.transpose(2, 3).contiguous().to(dtype).to(DEV), out)
+    ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(96, 64)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+    assert rel_err(out.float()[5], ref[5]) < (1e-5 if dtype == torch.float32 else 1e-2)
 
 
 @pytest.mark.parametrize("dtype", DT)
