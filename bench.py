@@ -133,6 +133,7 @@ def main():
     with rec:
         for _ in range(args.steps):
             out = step()
+    t_enq = time.perf_counter() - t0          # host time to enqueue all steps (diagnostic)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -163,6 +164,7 @@ def main():
             "config": {"workload": "Motion_Latent_Model.forward inference, B=1 x 32 frames x 2048 points x 512x512 video, "
                                    "4096 surface samples, training.frames=32, random-init weights (one clip per GPU)",
                        "parallelism": f"clip-parallel x{world}"},
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             "end_to_end_tflops": round(flops * world * args.steps / dt / 1e12, 1),
             "end_to_end_frac_of_bf16_peak": round(flops * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roof,

@@ -343,7 +343,8 @@ typedef __attribute__((address_space(1))) const void glb_ptr_t;
 
 template <typename TIN, typename TOUT, int ACT, int RES>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
-                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep) {
+                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep,
+                                                           int ntn, int xcd_remap) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];   // A0 B0 A1 B1
     constexpr int EPC = Elem<TIN>::PER16;
     constexpr int BK = ROWB / sizeof(TIN);
@@ -352,7 +353,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): give every
+    // XCD a contiguous range of logical tiles = whole A row-panels with all their column tiles, so a panel
+    // is pulled into ONE XCD's L2 and re-used by its ntn column tiles instead of being fetched by all eight.
+    int lid = blockIdx.x;
+    if (xcd_remap) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
 
     // this wave stages row groups g = wave*4 + i (8 rows each) of both operands
     const TIN* ga[4];
@@ -394,6 +403,90 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
     store_tile_out_t<TOUT, ACT, RES>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v3: 256 x 128 tile, 8 waves (4 x 2, each 64 x 64), THREE LDS stages of 48 KiB and counted waits.
+// v2 has one K-tile of prefetch distance: a wave computes 512 cycles of MFMA per tile, far less than
+// the 1-2 us an LDS-DMA fill takes under load, so every iteration stalls on the fill it issued one
+// iteration earlier.  Here tile kt+2 is issued while tile kt is computed and the wait before the
+// barrier is `s_waitcnt vmcnt(6)` -- "everything but my 6 newest DMA pieces" -- so two tiles
+// (96 KiB per CU) stay in flight across the barrier.  A raw s_barrier is used because
+// __syncthreads() would drain the DMA queue (vmcnt(0)).
+//   RAW: a wave's own pieces of tile kt have landed (counted wait), then the barrier -> all pieces.
+//   WAR: the stage refilled in iteration kt was last read in iteration kt-1; every wave has consumed
+//        those ds_reads (its MFMAs waited for them) before it arrives at iteration kt's barrier.
+constexpr int BM3 = 256;
+constexpr int STAGE3 = (BM3 + BN) * ROWB;   // 48 KiB
+
+template <typename TIN, typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(512, 2) void gemm_glds3_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
+                                                            long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep,
+                                                            int ntn, int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE3];
+    constexpr int EPC = Elem<TIN>::PER16;
+    constexpr int BK = ROWB / sizeof(TIN);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lid = blockIdx.x;
+    if (xcd_remap) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * BM3, n0 = (lid % ntn) * BN;
+
+    // staging: A row groups g = wave*4 + i (i < 4), W row groups g = wave*2 + i (i < 2); 8 rows per group
+    const TIN* ga[4];
+    const TIN* gb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + ((lane & 7) ^ ((r >> 1) & 7)) * EPC;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + ((lane & 7) ^ ((r >> 1) & 7)) * EPC;
+    }
+    auto issue_tile = [&](int kt, int stage) {
+        unsigned char* sa = smem + stage * STAGE3 + wave * 4096;
+        unsigned char* sb = smem + stage * STAGE3 + BM3 * ROWB + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)kt * BK), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)kt * BK), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    const int arow0 = wm * 64 + l31, brow0 = wn * 64 + l31;
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue_tile(kt + 2, stage >= 1 ? stage - 1 : 2);      // (stage + 2) % 3
+        const unsigned char* sa = smem + stage * STAGE3;
+        mma_tile<TIN, true>(sa, sa + BM3 * ROWB, arow0, brow0, hi, acc);
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    store_tile_out_t<TOUT, ACT, RES>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+}
+
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
 static bool vec_ok(const m324_gemm_args* a) {
     const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
@@ -403,25 +496,50 @@ static bool vec_ok(const m324_gemm_args* a) {
            (!a->gamma || al(a->gamma, 16));
 }
 
-// M324_GEMM=v1 selects the register-staged kernel (kept for A/B measurements)
-static bool use_v1() {
-    static const bool v = [] { const char* e = getenv("M324_GEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
+static int xcd_remap() {
+    static const int v = [] { const char* e = getenv("M324_XCD"); return e ? atoi(e) : 1; }();
     return v;
+}
+
+// Kernel choice.  M324_GEMM=v1|v2|v3 forces a variant (A/B measurements); otherwise the 8-wave 3-stage kernel
+// is used when its 256 x 128 tiles fill the 256 CUs about as well as the 128 x 128 tiles of v2 would.
+static int forced_variant() {
+    static const int v = [] { const char* e = getenv("M324_GEMM"); return (e && e[0] == 'v') ? atoi(e + 1) : 0; }();
+    return v;
+}
+
+static int pick_variant(const m324_gemm_args* a) {
+    if (!vec_ok(a)) return 1;
+    const int f = forced_variant();
+    if (f >= 1 && f <= 3) return f;
+    const long t2 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM), t3 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM3);
+    const double e2 = (double)t2 / (double)(((t2 + 511) / 512) * 512), e3 = (double)t3 / (double)(((t3 + 255) / 256) * 256);
+    return (t3 >= 128 && e3 >= e2 - 0.05) ? 3 : 2;
 }
 
 template <typename TIN, typename TOUT>
 int launch(const m324_gemm_args* a, hipStream_t s) {
     Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
-    if (use_v1() || !vec_ok(a))
+    const int variant = pick_variant(a);
+    if (variant == 1) {
         hipLaunchKernelGGL((gemm_kernel<TIN, TOUT>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda, (const TIN*)a->W,
                            a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
-    else {
+    } else {
         const int res = !a->residual && a->row_gin <= 0 ? 0
                         : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
+        const int ntm3 = ceil_div(a->M, BM3);
 #define M324_GLDS(ACT, RES)                                                                                              \
-    hipLaunchKernelGGL((gemm_glds_kernel<TIN, TOUT, ACT, RES>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda,         \
-                       (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep)
+    do {                                                                                                                 \
+        if (variant == 3)                                                                                                \
+            hipLaunchKernelGGL((gemm_glds3_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * ntm3), dim3(512), 0, s,           \
+                               (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
+                               a->K, ep, (int)grid.x, xcd_remap());                                                      \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gemm_glds_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * grid.y), dim3(256), 0, s,          \
+                               (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
+                               a->K, ep, (int)grid.x, xcd_remap());                                                      \
+    } while (0)
         if (a->act == M324_ACT_GELU) {
             if (res == 0) M324_GLDS(1, 0); else M324_GLDS(1, 2);
         } else {
