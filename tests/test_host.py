@@ -1,0 +1,137 @@
+"""Host-side contract of the drop-in (no GPU): state-dict manifest, module semantics, return type, weight cache."""
+import pytest
+import torch
+
+from motion324_amd import synth
+
+
+def small_model(**kw):
+    import motion324_amd as m
+    cfg = synth.make_config(frames=3, d=192, tokens=8, pcd_layers=1, n_layer=2, **kw)
+    cfg["model"]["dino"] = {"depth": 2}
+    return m.Motion_Latent_Model(cfg)
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    import motion324_amd as m
+    return m.Motion_Latent_Model(synth.make_config(frames=12))
+
+
+def test_state_dict_manifest_matches_reference(full_model):
+    """196 trainable tensors (157.04 M) + 2 buffers outside DINO, hub-named DINOv2 ViT-B/14 (86.58 M)."""
+    sd = full_model.state_dict()
+    spec = synth.state_dict_spec(synth.Dims(frames=12))
+    assert set(sd) == set(spec) | {"pos_embed", "point_embed.basis"}
+    for k, (shape, _) in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    non_dino = [k for k in sd if not k.startswith("image_encoder.")]
+    assert len(non_dino) == 198
+    trainable = [(n, p) for n, p in full_model.named_parameters() if p.requires_grad]
+    assert len(trainable) == 196 and all(not n.startswith("image_encoder.") for n, _ in trainable)
+    assert round(sum(p.numel() for _, p in trainable) / 1e6, 2) == 157.04
+    assert round(sum(p.numel() for n, p in full_model.named_parameters() if n.startswith("image_encoder.")) / 1e6, 2) == 86.58
+    assert tuple(sd["pos_embed"].shape) == (1, 12 * 256, 768) and tuple(sd["point_embed.basis"].shape) == (3, 24)
+    assert tuple(sd["image_encoder.model.pos_embed"].shape) == (1, 1370, 768)
+    assert tuple(sd["image_encoder.model.patch_embed.proj.weight"].shape) == (768, 3, 14, 14)
+    # optimizer grouping of the reference (utils/training_utils.py:39-47): 1-D params get no weight decay
+    assert sum(1 for _, p in trainable if p.dim() == 1) > 0
+
+
+def test_buffers_match_oracle_restatement(full_model):
+    from oracle import ref_forward as oracle
+    assert torch.equal(full_model.pos_embed, oracle.generate_pos_embed(12, 16, 16, 768))
+    assert torch.equal(full_model.point_embed.basis, oracle.point_basis())
+    from motion324_amd.Pcd_motion import resize_pos_embed
+    a = resize_pos_embed(full_model.pos_embed, (12, 16, 16), (4, 16, 16))
+    assert torch.equal(a, oracle.resize_pos_embed(full_model.pos_embed, (12, 16, 16), (4, 16, 16)))
+    pe = full_model.image_encoder.model.pos_embed.detach()
+    assert torch.allclose(full_model.image_encoder.model.interpolated_pos(16), oracle.dino_pos_embed(pe, 16)[0])
+
+
+def test_train_eval_semantics():
+    model = small_model()
+    assert model.training
+    model.eval()                      # statement use, as every reference caller does
+    assert not model.training and not model.image_encoder.model.training
+    model.train()
+    assert model.training and not model.image_encoder.model.training      # DINO stays in eval (dinov2.py:126-131)
+    assert all(not p.requires_grad for p in model.image_encoder.parameters())
+    ddp_ready = [p for p in model.parameters() if p.requires_grad]
+    assert len(ddp_ready) == len(list(model.parameters())) - len(list(model.image_encoder.parameters()))
+
+
+def test_cpu_forward_fails_loudly():
+    from motion324_amd.lib import M324Error
+    model = small_model().eval()
+    s = {k: torch.from_numpy(v) for k, v in synth.synth_inputs(1, 3, 8, 16, 32).items()}
+    with pytest.raises(M324Error, match="no CPU fallback"):
+        model(s)
+
+
+def test_config_attribute_style_and_missing_loss_weight():
+    import motion324_amd as m
+    cfg = m.EasyDict(synth.make_config(frames=3, d=192, tokens=8, pcd_layers=1, n_layer=2))
+    cfg.model.dino = {"depth": 1}
+    model = m.Motion_Latent_Model(cfg)           # attribute-style config like the reference's EasyDict
+    assert model.video_length == 3 and model.num_learnable_tokens == 8 and model.drop_rate == 0.0
+    del cfg["training"]["coord_mse_loss_weight"]
+    with pytest.raises(ValueError, match="coord_mse_loss_weight"):
+        m.Motion_Latent_Model(cfg)
+
+
+def test_easydict_contract():
+    from motion324_amd import EasyDict
+    lm = EasyDict()
+    lm.loss = torch.tensor(1.5)
+    out = EasyDict(input_data={"a": 1}, pcd_moved=torch.zeros(1), loss_metrics=lm)
+    assert isinstance(out, dict) and "pcd_moved" in out and out.loss_metrics.loss.item() == 1.5
+    assert [k for k, _ in out.loss_metrics.items()] == ["loss"]
+    out.loss_metrics.loss.data = torch.tensor(0.0)          # train.py:174 assigns .data
+    assert out["loss_metrics"]["loss"].item() == 0.0
+    with pytest.raises(AttributeError):
+        out.nope
+
+
+def test_prepared_cache_pads_converts_and_invalidates():
+    from motion324_amd.prepared import Prepared, pad_k
+    assert pad_k(588) == 640 and pad_k(51) == 64 and pad_k(774) == 832 and pad_k(768) == 768
+    lin = torch.nn.Linear(51, 8)
+    P = Prepared(torch.device("cpu"), torch.bfloat16)
+    w = P.mat(lin.weight)
+    assert w.shape == (8, 64) and w.dtype == torch.bfloat16 and float(w[:, 51:].abs().max()) == 0.0
+    assert P.mat(lin.weight) is w                                   # cached
+    with torch.no_grad():
+        lin.weight.add_(1.0)                                        # optimizer-style in-place update
+    w2 = P.mat(lin.weight)
+    assert w2 is not w and torch.equal(w2[:, :51], lin.weight.detach().to(torch.bfloat16))
+    conv = torch.nn.Conv2d(3, 4, 14, 14)
+    assert P.mat(conv.weight).shape == (4, 640)
+    assert P.vec(None) is None and P.vec(lin.bias).dtype == torch.float32
+    cat = P.cat_rows((lin.weight, lin.weight))
+    assert cat.shape == (16, 64)
+
+
+def test_precision_follows_override_and_env(monkeypatch):
+    import motion324_amd as m
+    assert m.compute_dtype() == torch.float32
+    m.set_precision("bf16")
+    assert m.compute_dtype() == torch.bfloat16
+    m.set_precision(None)
+    monkeypatch.setenv("M324_PRECISION", "bf16")
+    assert m.compute_dtype() == torch.bfloat16
+    monkeypatch.delenv("M324_PRECISION")
+    assert m.compute_dtype() == torch.float32
+
+
+def test_unsupported_configurations_are_rejected_not_approximated():
+    from motion324_amd.transformer import MLP, QK_Norm_SelfAttention
+    with pytest.raises(NotImplementedError):
+        QK_Norm_SelfAttention(192, 32)                  # head_dim != 64
+    with pytest.raises(NotImplementedError):
+        MLP(192, dropout=0.1)
+    model = small_model(drop_rate=0.1)
+    model.train()
+    s = {k: torch.from_numpy(v) for k, v in synth.synth_inputs(1, 3, 8, 16, 32).items()}
+    with pytest.raises(Exception):
+        model(s)
