@@ -166,46 +166,21 @@ __device__ __forceinline__ void store4_out<bf16_t>(bf16_t* p, float a, float b, 
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
 }
 
-template <typename TOUT, int ACT, int RES>
-__device__ __forceinline__ void store_tile_out_t(const f32x16 (&acc)[2][2], TOUT* C, long ldc, int M, int N, int mw, int nw,
+template <typename TOUT, int ACT, int RES, int MI>
+__device__ __forceinline__ void store_tile_out_t(const f32x16 (&acc)[MI][2], TOUT* C, long ldc, int M, int N, int mw, int nw,
                                                  int l31, int hi, const Epilogue& ep) {
     const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
     const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
     const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
     const bool gelu = ACT == 1;
+    const bool has_gamma = ep.gamma != nullptr;
     // column of run (j, g): n = nw + 32 j + 8 g + 4 hi; clamped copy for the (unconditional) loads
     int ncl[2][4];
+    float4 bi[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) ncl[j][g] = min(nw + j * 32 + 8 * g + 4 * hi, N - 4);
-
-    // ---- phase 1: every global read of the epilogue is issued before anything is consumed
-    float4 res[2][2][4], bi[2][4], ga[2][4];
-    TOUT* crow[2];
-    bool mok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = mw + i * 32 + l31;
-        mok[i] = m < M;
-        long orow = m;
-        if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
-        crow[i] = C + orow * ldc;
-        if (has_res) {
-            int mr = mok[i] ? m : M - 1;
-            if (res_mod) mr %= ep.res_rows;
-            const float* rrow = ep.residual + (long)mr * ep.ldr;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) res[i][j][g] = *reinterpret_cast<const float4*>(rrow + ncl[j][g]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) res[i][j][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     if (ep.bias) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -217,21 +192,29 @@ __device__ __forceinline__ void store_tile_out_t(const f32x16 (&acc)[2][2], TOUT
 #pragma unroll
             for (int g = 0; g < 4; ++g) bi[j][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (ep.gamma) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i) {
+        const int m = mw + i * 32 + l31;
+        const bool mok = m < M;
+        long orow = m;
+        if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
+        TOUT* crow = C + orow * ldc;
+        // every residual read of this row block is issued before anything is consumed
+        float4 res[2][4];
+        if (has_res) {
+            int mr = mok ? m : M - 1;
+            if (res_mod) mr %= ep.res_rows;
+            const float* rrow = ep.residual + (long)mr * ep.ldr;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) ga[j][g] = *reinterpret_cast<const float4*>(ep.gamma + ncl[j][g]);
-    } else {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+                for (int g = 0; g < 4; ++g) res[j][g] = *reinterpret_cast<const float4*>(rrow + ncl[j][g]);
+        } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) ga[j][g] = make_float4(1.f, 1.f, 1.f, 1.f);
-    }
-
-    // ---- phase 2: arithmetic + predicated wide stores
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+                for (int g = 0; g < 4; ++g) res[j][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -243,10 +226,14 @@ __device__ __forceinline__ void store_tile_out_t(const f32x16 (&acc)[2][2], TOUT
                     v0 = apply_gelu<TOUT>(v0); v1 = apply_gelu<TOUT>(v1);
                     v2 = apply_gelu<TOUT>(v2); v3 = apply_gelu<TOUT>(v3);
                 }
-                v0 = fmaf(v0, ga[j][g].x, res[i][j][g].x); v1 = fmaf(v1, ga[j][g].y, res[i][j][g].y);
-                v2 = fmaf(v2, ga[j][g].z, res[i][j][g].z); v3 = fmaf(v3, ga[j][g].w, res[i][j][g].w);
-                if (mok[i] && n < N) store4_out<TOUT>(crow[i] + n, v0, v1, v2, v3);
+                if (has_gamma) {   // LayerScale (DINO only): L1-resident after the first row block
+                    const float4 ga = *reinterpret_cast<const float4*>(ep.gamma + ncl[j][g]);
+                    v0 *= ga.x; v1 *= ga.y; v2 *= ga.z; v3 *= ga.w;
+                }
+                v0 += res[j][g].x; v1 += res[j][g].y; v2 += res[j][g].z; v3 += res[j][g].w;
+                if (mok && n < N) store4_out<TOUT>(crow + n, v0, v1, v2, v3);
             }
+    }
 }
 
 template <typename TIN, typename TOUT>
@@ -400,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
         const unsigned char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
         mma_tile<TIN, true>(sa, sa + TILE_BYTES, arow0, brow0, hi, acc);
     }
-    store_tile_out_t<TOUT, ACT, RES>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+    store_tile_out_t<TOUT, ACT, RES, 2>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
 }
 
 
@@ -484,7 +471,107 @@ __global__ __launch_bounds__(512, 2) void gemm_glds3_kernel(const TIN* __restric
         mma_tile<TIN, true>(sa, sa + BM3 * ROWB, arow0, brow0, hi, acc);
         stage = stage == 2 ? 0 : stage + 1;
     }
-    store_tile_out_t<TOUT, ACT, RES>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+    store_tile_out_t<TOUT, ACT, RES, 2>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// v5: 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block = 4 x 2 accumulators
+// (128 VGPR).  Per K-tile a wave issues 32 MFMAs (1024 matrix-pipe cycles) against 24 fragment reads,
+// and the workgroup moves 64 KiB by LDS-DMA per 8.4 MFLOP -- half the LDS traffic per FLOP of the
+// 128-wide tiles and twice the work per barrier.  Two LDS stages of 64 KiB (one workgroup per CU).
+// Used where 256-wide column tiles quantise well (N % 256 == 0) and the grid still fills the chip.
+constexpr int BM5 = 256, BN5 = 256;
+constexpr int STAGE5 = (BM5 + BN5) * ROWB;   // 64 KiB
+
+template <typename TIN, typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
+                                                            long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep,
+                                                            int ntn, int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE5];
+    constexpr int EPC = Elem<TIN>::PER16;
+    constexpr int BK = ROWB / sizeof(TIN);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lid = blockIdx.x;
+    if (xcd_remap) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * BM5, n0 = (lid % ntn) * BN5;
+
+    // staging: 32 row groups of 8 rows per operand; wave w takes groups w*4 .. w*4+3 of A and of W
+    const TIN* ga[4];
+    const TIN* gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c * EPC;
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c * EPC;
+    }
+    auto issue_tile = [&](int kt, int buf) {
+        unsigned char* sa = smem + buf * STAGE5 + wave * 4096;
+        unsigned char* sb = sa + BM5 * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)kt * BK), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)kt * BK), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    const int arow0 = wm * 128 + l31, brow0 = wn * 64 + l31;
+    issue_tile(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
+        const unsigned char* sa = smem + (kt & 1) * STAGE5;
+        const unsigned char* sb = sa + BM5 * ROWB;
+        if constexpr (sizeof(TIN) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af[4], bfr[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(brow0 + j * 32, ks * 2 + hi));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(arow0 + i * 32, ks * 2 + hi));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                f32x2 af[4], bfr[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const f32x2*>(sb + lds_off(brow0 + j * 32, c) + hi * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f32x2*>(sa + lds_off(arow0 + i * 32, c) + hi * 8);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[j][e], af[i][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    store_tile_out_t<TOUT, ACT, RES, 4>(acc, C, ldc, M, N, m0 + wm * 128, n0 + wn * 64, l31, hi, ep);
 }
 
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
@@ -511,7 +598,12 @@ static int forced_variant() {
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
     const int f = forced_variant();
-    if (f >= 1 && f <= 3) return f;
+    if (f >= 1 && f <= 5 && f != 4) return f;
+    // 256 x 256 tiles (v5) halve the LDS traffic per FLOP and double the work per barrier: fastest whenever the
+    // column count quantises (N % 256 == 0) and the tiles still fill most of the 256 CUs in whole rounds
+    const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
+    const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
+    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) return 5;
     const long t2 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM), t3 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM3);
     const double e2 = (double)t2 / (double)(((t2 + 511) / 512) * 512), e3 = (double)t3 / (double)(((t3 + 255) / 256) * 256);
     return (t3 >= 128 && e3 >= e2 - 0.05) ? 3 : 2;
@@ -531,7 +623,12 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
         const int ntm3 = ceil_div(a->M, BM3);
 #define M324_GLDS(ACT, RES)                                                                                              \
     do {                                                                                                                 \
-        if (variant == 3)                                                                                                \
+        if (variant == 5)                                                                                                \
+            hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
+                               dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
+                               a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,              \
+                               ceil_div(a->N, BN5), xcd_remap());                                                        \
+        else if (variant == 3)                                                                                           \
             hipLaunchKernelGGL((gemm_glds3_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * ntm3), dim3(512), 0, s,           \
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
                                a->K, ep, (int)grid.x, xcd_remap());                                                      \
