@@ -16,6 +16,7 @@
 // XOR-swizzled 16-byte (K) / 8-byte (Vt) chunks so the per-row fragment reads are conflict-free;
 // double buffered, global -> register -> LDS staging overlapped with the MFMAs, one barrier per tile.
 // The fp32 parity variant uses v_mfma_f32_32x32x2_f32 on padded fp32 tiles (single buffered).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -33,7 +34,10 @@ __device__ __forceinline__ int k_off(int row, int c16) { return row * 128 + ((c1
 __device__ __forceinline__ int v_off(int row, int c8) { return row * 128 + ((c8 ^ (((row >> 1) ^ (row >> 5)) & 15)) << 3); }
 
 // PRESCALED: Q already carries scale * log2(e) (m324_qkv_split's q_scale), so scores are log2-domain.
-template <bool PRESCALED>
+// NQ: 32-row query blocks per wave (1 or 2).  With NQ = 2 every K / Vt fragment read from LDS feeds two
+// MFMAs, a wave issues 32 MFMAs per barrier instead of 16, and the two blocks' softmax chains are
+// independent, so the scheduler can run one block's exp2 / pack work under the other block's MFMAs.
+template <bool PRESCALED, int NQ>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
@@ -42,21 +46,22 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * QB + wave * QW;
+    const int q0 = (blockIdx.x * NW + wave) * (QW * NQ);
 
     const bf16_t* Qh = Q + (long)b * q_bstride + (long)h * Lq * 64;
     const bf16_t* Kh = K + ((long)b * H + h) * (long)Lk * 64;
     const bf16_t* Vh = Vt + ((long)b * H + h) * 64 * (long)Lkp;
 
     // Q fragments (B operand): lane (q = l31, hi) holds Q[q][ks*16 + hi*8 .. +7] for ks = 0..3
-    bf16x8 qf[4];
-    {
-        const int q = q0 + l31;
+    bf16x8 qf[NQ][4];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int q = q0 + n * QW + l31;
         const bool ok = q < Lq;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 v = ok ? *reinterpret_cast<const uint4*>(Qh + (long)q * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
-            qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+            qf[n][ks] = *reinterpret_cast<bf16x8*>(&v);
         }
     }
 
@@ -84,18 +89,22 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         }
     };
 
-    f32x16 o[2];
+    f32x16 o[NQ][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int n = 0; n < NQ; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[n][i][r] = 0.f;
     // Online softmax with a LAZY reference maximum (log2 domain).  m_ref is the value the scores are
     // measured against; it is folded into the MFMA accumulator's initial value (s' = K.Q - m_ref comes
     // straight out of the matrix core) and is only moved when some score of the tile exceeds it by more
     // than THR -- so the common tile costs one exp2, one add and half a max3 / cvt per score and never
     // touches the O accumulators.  P <= 2^THR keeps everything far inside fp32 / bf16 range.
     constexpr float THR = 8.0f;
-    float m_ref = 0.f, l_run = 0.f;     // l_run: this lane's partial row sum (its 32 of the tile's 64 keys)
+    float m_ref[NQ], l_run[NQ];     // l_run: this lane's partial row sum (its 32 of the tile's 64 keys)
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) m_ref[n] = 0.f, l_run[n] = 0.f;
     bool first = true;
 
     const int nt = (Lk + KV - 1) / KV;
@@ -109,71 +118,93 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         const unsigned char* sk = smem + (t & 1) * 16384;
         const unsigned char* sv = sk + 8192;
 
-        // ---- S'^T = K Q^T - m_ref : two 32-key blocks
-        const float init = PRESCALED ? -m_ref : -m_ref / scale_log2e;
-        f32x16 s[2];
+        // ---- S'^T = K Q^T - m_ref : two 32-key blocks per query block
+        f32x16 s[NQ][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = init;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-            }
-        }
-        if (!PRESCALED) {
+        for (int n = 0; n < NQ; ++n) {
+            const float init = PRESCALED ? -m_ref[n] : -m_ref[n] / scale_log2e;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] *= scale_log2e;
+                for (int r = 0; r < 16; ++r) s[n][kb][r] = init;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
+#pragma unroll
+                for (int n = 0; n < NQ; ++n)
+                    s[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[n][ks], s[n][kb], 0, 0, 0);
+            }
+        if (!PRESCALED) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[n][kb][r] *= scale_log2e;
         }
         const int kv0 = t * KV;
         if (kv0 + KV > Lk) {   // ragged last tile: mask keys >= Lk (wave-uniform branch)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int n = 0; n < NQ; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[kb][r] = -INFINITY;
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[n][kb][r] = -INFINITY;
         }
-        float mx = -INFINITY;
+        float mx[NQ];
+        bool calm = true;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // move the reference only when needed (wave-uniform decision; NaN scores also take this path)
-        if (first || !__all(mx <= THR)) {
-            const float shift = first ? mx : fmaxf(mx, 0.f);      // new m_ref = m_ref + shift (never decreases)
-            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-shift);
-            m_ref += shift;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int n = 0; n < NQ; ++n) {
+            float v = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] -= shift;
+                for (int r = 0; r < 16; ++r) v = fmaxf(v, s[n][kb][r]);
+            mx[n] = fmaxf(v, __shfl_xor(v, 32, 64));
+            calm = calm && (mx[n] <= THR);
+        }
+        // move the reference only when needed (wave-uniform decision)
+        if (first || !__all(calm)) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const float shift = first ? mx[n] : fmaxf(mx[n], 0.f);     // m_ref never decreases
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-shift);
+                m_ref[n] += shift;
+                l_run[n] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[n][i][r] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[n][kb][r] -= shift;
+            }
             first = false;
         }
-        f32x2 rs2 = {0.f, 0.f};
-        bf16x8 pf[4];   // P^T fragments, k-step j = kb*2 + (r>>3)
+        bf16x8 pf[NQ][4];   // P^T fragments, k-step j = kb*2 + (r>>3)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            uint32_t pk[8];
+        for (int n = 0; n < NQ; ++n) {
+            f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 p = {__builtin_amdgcn_exp2f(s[kb][r]), __builtin_amdgcn_exp2f(s[kb][r + 1])};
-                rs2 += p;
-                pk[r >> 1] = pack_bf16x2(p[0], p[1]);
+            for (int kb = 0; kb < 2; ++kb) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 p = {__builtin_amdgcn_exp2f(s[n][kb][r]), __builtin_amdgcn_exp2f(s[n][kb][r + 1])};
+                    rs2 += p;
+                    pk[r >> 1] = pack_bf16x2(p[0], p[1]);
+                }
+                uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                pf[n][kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
+                pf[n][kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
             }
-            uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-            pf[kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
-            pf[kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
+            l_run[n] += rs2[0] + rs2[1];
         }
-        l_run += rs2[0] + rs2[1];
 
         // ---- O^T += Vt P^T.  k-step j covers keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}
 #pragma unroll
@@ -184,7 +215,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
                 uint2 a0 = *reinterpret_cast<const uint2*>(sv + v_off(d, 4 * j + hi));
                 uint2 a1 = *reinterpret_cast<const uint2*>(sv + v_off(d, 4 * j + 2 + hi));
                 uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av), pf[j], o[db], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NQ; ++n)
+                    o[n][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av), pf[n][j], o[n][db], 0, 0, 0);
             }
         }
 
@@ -192,21 +225,24 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         __syncthreads();
     }
 
-    // ---- normalise and store.  o[db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + l31;
-    if (q < Lq) {
-        bf16_t* orow = O + ((long)b * Lq + q) * ldo + h * 64;
+    // ---- normalise and store.  o[n][db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int n = 0; n < NQ; ++n) {
+        const float l_tot = l_run[n] + __shfl_xor(l_run[n], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + n * QW + l31;
+        if (q < Lq) {
+            bf16_t* orow = O + ((long)b * Lq + q) * ldo + h * 64;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack_bf16x2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
-                w.y = pack_bf16x2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + db * 32 + g * 8 + hi * 4) = w;
-            }
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = pack_bf16x2(o[n][db][g * 4 + 0] * inv, o[n][db][g * 4 + 1] * inv);
+                    w.y = pack_bf16x2(o[n][db][g * 4 + 2] * inv, o[n][db][g * 4 + 3] * inv);
+                    *reinterpret_cast<uint2*>(orow + db * 32 + g * 8 + hi * 4) = w;
+                }
+        }
     }
 }
 
@@ -339,12 +375,22 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
     const float sl = q_prescaled ? 1.0f : scale * LOG2E;
     if (dtype == M324_BF16) {
         M324_REQUIRE((ldo * 2) % 8 == 0, "m324_attention: ldo misaligned");
-        if (q_prescaled)
-            hipLaunchKernelGGL(attn_bf16_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl);
-        else
-            hipLaunchKernelGGL(attn_bf16_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)Q, q_bstride,
-                               (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl);
+        // NQ = 2 (two query blocks per wave) measured slower than NQ = 1 on MI355X (254 VGPRs -> one wave per
+        // SIMD); it stays selectable for experiments only.
+        const bool nq2 = getenv("M324_ATTN_NQ2") != nullptr && Lq >= 1024;
+        dim3 g2(ceil_div(Lq, nq2 ? 2 * QB : QB), H, B);
+        // Co-residency: the NQ = 1 kernel fits 3 workgroups per CU (168 VGPRs, 32 KiB LDS).  Interleaved A/B on
+        // MI355X: 3 per CU beats 2 per CU (422 vs 453 us on the 10 368-token global attention) even though the
+        // grid then ends in a partly filled round -- latency hiding wins over round quantisation.
+        // M324_ATTN_OCC=2 pads the LDS allocation to force two per CU (experiments only).
+        const char* focc = getenv("M324_ATTN_OCC");
+        const unsigned pad = (focc && atoi(focc) == 2) ? 24 * 1024 : 0;
+#define M324_ATTN(PS, NQ)                                                                                                \
+    hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ>), g2, dim3(256), pad, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K, \
+                       (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl)
+        if (q_prescaled) { if (nq2) M324_ATTN(true, 2); else M324_ATTN(true, 1); }
+        else { if (nq2) M324_ATTN(false, 2); else M324_ATTN(false, 1); }
+#undef M324_ATTN
     } else if (dtype == M324_F32) {
         M324_REQUIRE(ldo % 4 == 0, "m324_attention: ldo misaligned");
         hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, s, (const float*)Q, q_bstride, (const float*)K,

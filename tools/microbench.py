@@ -12,12 +12,29 @@ ap.add_argument("what", nargs="?", default="all")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--ab", default="", help="ENV=a,b : interleaved A/B of an environment switch read per launch")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = "cuda"
 
 
 def timeit(fn, iters):
+    if args.ab:
+        var, vals = args.ab.split("=")
+        vals = vals.split(",")
+        res = {v: [] for v in vals}
+        for rnd in range(6):
+            for v in vals:
+                os.environ[var] = v
+                res[v].append(_timeit(fn, max(3, iters // 4)))
+        os.environ.pop(var, None)
+        med = {v: sorted(t)[len(t) // 2] for v, t in res.items()}
+        print("   A/B " + "  ".join(f"{var}={v}: {m * 1e3:.1f} us" for v, m in med.items()))
+        return min(med.values())
+    return _timeit(fn, iters)
+
+
+def _timeit(fn, iters):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
