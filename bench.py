@@ -158,8 +158,17 @@ def main():
         d = summ[dom]
         peak = PEAK_BF16_TFLOPS if dom.endswith("bf16") else PEAK_F32_TFLOPS
         achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel class: PMC counters cannot be read in-process, so the figure comes
+        # from the committed rocprofv3 passes (profiles/r01_traffic.json; see tools/pmc.sh, tools/pmc_traffic.py)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+            traffic = tj.get(dom, {}).get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
                 "launches_per_step": d["launches"] // args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
                 "by_kernel": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 3),
                                   "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
