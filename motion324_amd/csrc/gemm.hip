@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
     // XCD a contiguous range of logical tiles = whole A row-panels with all their column tiles, so a panel
     // is pulled into ONE XCD's L2 and re-used by its ntn column tiles instead of being fetched by all eight.
     int lid = blockIdx.x;
-    if (xcd_remap) {
+    if (xcd_remap & 1) {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
         lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
     }
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds3_kernel(const TIN* __restric
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     int lid = blockIdx.x;
-    if (xcd_remap) {
+    if (xcd_remap & 1) {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
         lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
     }
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
     int lid = blockIdx.x;
-    if (xcd_remap) {
+    if (xcd_remap & 1) {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
         lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
     }
@@ -574,6 +574,135 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
     store_tile_out_t<TOUT, ACT, RES, 4>(acc, C, ldc, M, N, m0 + wm * 128, n0 + wn * 64, l31, hi, ep);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v6: 256 x 256 tile with a STAGGERED two-group schedule (bf16 only).
+// Waves 0-3 (group A, rows 0..127) and 4-7 (group B, rows 128..255) share every SIMD pairwise (wave w and
+// w+4).  Work is cut into phases of one k-step = 8 MFMAs per wave (256 matrix-pipe cycles).  A phase is
+//     [ds_read the 6 fragments of the k-step | issue LDS-DMA]  s_barrier  [8 MFMAs]  s_barrier
+// and group B runs ONE barrier behind group A, so between any two barriers one wave of each SIMD is
+// feeding the matrix pipe while its partner fetches fragments / issues DMA: the pipe never waits for the
+// LDS, and no wave ever waits at a barrier for work it could have overlapped.
+// K is streamed in half-tiles of 32 (one 32 KiB LDS slot = A[256][32] + W[256][32], 64-byte rows with chunk
+// swizzle c ^ ((row >> 2) & 3)); 4 slots form a ring, three half-tiles are in flight, waits are counted.
+//   barrier numbering (after the prologue barrier #0): group A's phase Q uses barriers 2Q+1, 2Q+2;
+//   group B first takes barrier #1 alone, then its phase Q uses 2Q+2, 2Q+3; A takes one extra at the end.
+//   RAW: half-tile h is first read after barrier 4h.  Every wave waits (counted vmcnt) for its own DMA
+//        pieces of half-tile h+1 in the odd phase of half-tile h, before that phase's first barrier
+//        (#4h+3 for A, #4h+4 for B) -- both <= 4(h+1).
+//   WAR: the DMA for half-tile h+3 (slot of half-tile h-1) is issued in the odd phase of half-tile h, i.e.
+//        after barrier 4h+2 (A) / 4h+3 (B); the last reads of half-tile h-1 retire right after barrier
+//        4h-1 (A) / 4h (B): at least two barriers earlier.
+constexpr int ROWB6 = 64;                        // bytes of K per LDS row in a half-tile
+constexpr int PART6 = 256 * ROWB6;               // 16 KiB: one operand's half-tile
+constexpr int SLOT6 = 2 * PART6;                 // 32 KiB
+__device__ __forceinline__ int lds_off6(int row, int chunk) { return row * ROWB6 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+#define M324_BARRIER()                             \
+    do {                                           \
+        asm volatile("s_barrier" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16_t* __restrict__ A, long lda,
+                                                           const bf16_t* __restrict__ W, long ldw, TOUT* C, long ldc, int M,
+                                                           int N, int K, Epilogue ep, int ntn, int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT6];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;     // wm = group (0 = A, 1 = B)
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lid = blockIdx.x;
+    if (xcd_remap & 1) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * BM5, n0 = (lid % ntn) * BN5;
+
+    // DMA: a wave-instruction fills 16 rows x 64 B.  Per half-tile each wave moves row groups
+    // g = wave*2 + i (i < 2) of A and of W.
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c * 8;
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c * 8;
+    }
+    auto issue_half = [&](int h) {
+        unsigned char* sa = smem + (h & 3) * SLOT6 + wave * 2048;
+        unsigned char* sb = sa + PART6;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)h * 32), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)h * 32), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
+        }
+    };
+    auto wait_dma = [&](int halves_in_flight) {     // allow that many later half-tiles (4 pieces each) in flight
+        if (halves_in_flight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (halves_in_flight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int NH = K / 32;
+    const int arow0 = wm * 128 + l31, brow0 = wn * 64 + l31;
+    bf16x8 fa[4], fb[2];
+    auto load_frags = [&](int h, int ks) {
+        const unsigned char* sa = smem + (h & 3) * SLOT6;
+        const unsigned char* sb = sa + PART6;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off6(brow0 + j * 32, ks * 2 + hi));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off6(arow0 + i * 32, ks * 2 + hi));
+    };
+    auto mma8 = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: three half-tiles in flight, half-tile 0 landed everywhere
+    const int pre = NH < 3 ? NH : 3;
+    for (int h = 0; h < pre; ++h) issue_half(h);
+    wait_dma(pre - 1);
+    M324_BARRIER();                 // #0
+    if (wm == 1) M324_BARRIER();    // group B starts one barrier late
+
+    for (int h = 0; h < NH; ++h) {
+        // ---- even phase: k-step 0 of half-tile h
+        load_frags(h, 0);
+        M324_BARRIER();
+        mma8();
+        M324_BARRIER();
+        // ---- odd phase: k-step 1; refill the slot of half-tile h-1 with half-tile h+3
+        load_frags(h, 1);
+        if (h + 3 < NH) issue_half(h + 3);
+        {
+            const int last = (h + 3 < NH ? h + 3 : NH - 1);      // newest half-tile issued so far
+            wait_dma(last - (h + 1));                            // half-tile h+1 landed (this wave's pieces)
+        }
+        M324_BARRIER();
+        mma8();
+        M324_BARRIER();
+    }
+    if (wm == 0) M324_BARRIER();    // group A's matching extra barrier
+    store_tile_out_t<TOUT, ACT, RES, 4>(acc, C, ldc, M, N, m0 + wm * 128, n0 + wn * 64, l31, hi, ep);
+}
+
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
 static bool vec_ok(const m324_gemm_args* a) {
     const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
@@ -583,30 +712,38 @@ static bool vec_ok(const m324_gemm_args* a) {
            (!a->gamma || al(a->gamma, 16));
 }
 
+// XCD-aware tile order (default on; M324_XCD=0 disables)
 static int xcd_remap() {
-    static const int v = [] { const char* e = getenv("M324_XCD"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("M324_XCD"); return e ? (atoi(e) & 1) : 1; }();
     return v;
 }
 
 // Kernel choice.  M324_GEMM=v1|v2|v3 forces a variant (A/B measurements); otherwise the 8-wave 3-stage kernel
 // is used when its 256 x 128 tiles fill the 256 CUs about as well as the 128 x 128 tiles of v2 would.
-static int forced_variant() {
-    static const int v = [] { const char* e = getenv("M324_GEMM"); return (e && e[0] == 'v') ? atoi(e + 1) : 0; }();
-    return v;
+static int forced_variant() {      // read per call: lets one process A/B-toggle the variant
+    const char* e = getenv("M324_GEMM");
+    return (e && e[0] == 'v') ? atoi(e + 1) : 0;
 }
 
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
     const int f = forced_variant();
-    if (f >= 1 && f <= 5 && f != 4) return f;
+    if (f >= 1 && f <= 6 && f != 4) return (f == 6 && a->in_dtype != M324_BF16) ? 5 : f;
     // 256 x 256 tiles (v5) halve the LDS traffic per FLOP and double the work per barrier: fastest whenever the
     // column count quantises (N % 256 == 0) and the tiles still fill most of the 256 CUs in whole rounds
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
-    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) return 5;
+    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) return (a->in_dtype == M324_BF16 && a->K >= 96) ? 6 : 5;
     const long t2 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM), t3 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM3);
     const double e2 = (double)t2 / (double)(((t2 + 511) / 512) * 512), e3 = (double)t3 / (double)(((t3 + 255) / 256) * 256);
     return (t3 >= 128 && e3 >= e2 - 0.05) ? 3 : 2;
+}
+
+template <typename TOUT, int ACT, int RES>
+static void launch_stag(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep) {
+    hipLaunchKernelGGL((gemm_stag_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+                       (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
+                       ceil_div(a->N, BN5), xcd_remap());
 }
 
 template <typename TIN, typename TOUT>
@@ -623,7 +760,9 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
         const int ntm3 = ceil_div(a->M, BM3);
 #define M324_GLDS(ACT, RES)                                                                                              \
     do {                                                                                                                 \
-        if (variant == 5)                                                                                                \
+        if (variant == 6)                                                                                                \
+            launch_stag<TOUT, ACT, RES>(a, s, ep);                                                                      \
+        else if (variant == 5)                                                                                           \
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
                                dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
                                a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,              \
