@@ -82,6 +82,8 @@ int m324_layernorm(const float* x, long ldx, const float* w, const float* b, flo
  *   row b*L + l, columns h*64 .. h*64+63.  q_w / k_w: RMSNorm weights [64] or NULL (DINO: no qk-norm).
  *   Outputs (same dtype): Q[B,H,L,64], K[B,H,L,64], Vt[B,H,64,Lp] with Lp = round_up(L, 64);
  *   Vt columns L..Lp-1 are written as zeros.  head_dim is fixed at 64 (config d_head).
+ *   Vt key order: inside every aligned group of 16 keys the columns are stored as keys 0-3, 8-11, 4-7, 12-15
+ *   (the order the attention MFMA contracts them in); m324_attention expects exactly this layout.
  *   q_scale multiplies the (normalised) q before it is rounded to `dtype`: pass softmax_scale * log2(e)
  *   and call m324_attention with q_prescaled = 1 (saves one multiply per score in the kernel), or 1.0f.
  * ------------------------------------------------------------------------------------------ */
@@ -156,6 +158,16 @@ int m324_linear_n3(const void* A, long lda, const float* W, const float* bias, f
  * ------------------------------------------------------------------------------------------ */
 int m324_mse(const float* pred, const float* target, long n, float weight, float* partial, float* out,
              void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * m324_smooth_trajectories: the caller-side jitter filter applied to pcd_moved, on the GPU.
+ *   replaces: smooth_trajectories(method='combined'|'threshold'|'gaussian') (utils/inference_utils.py:99-148),
+ *   a Python triple loop over B*N*3 on the CPU in the reference.
+ *   trajs/out [B,T,N,3] fp32, tmp same size (scratch).  threshold < 0 skips the threshold pass, sigma <= 0 skips
+ *   the gaussian pass (scipy.ndimage.gaussian_filter1d semantics: truncate 4, mode 'nearest').
+ * ------------------------------------------------------------------------------------------ */
+int m324_smooth_trajectories(const float* trajs, float* tmp, float* out, int B, int T, int N,
+                             float threshold, float sigma, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,9 +12,13 @@
 //   O^T[d, q]  = Vt[d, kv] . P^T[kv, q]    MFMA A = Vt rows (from LDS), B = P^T = the lane's own S^T
 //       registers (the contraction index kv may be visited in any order as long as A and B agree, so
 //       Vt fragments are simply gathered in the C-layout's kv order: two 8-byte LDS reads per MFMA).
-// LDS per stage: K tile [64 kv][64 d] and Vt tile [64 d][64 kv], rows of 128 bytes (bf16) with
-// XOR-swizzled 16-byte (K) / 8-byte (Vt) chunks so the per-row fragment reads are conflict-free;
-// double buffered, global -> register -> LDS staging overlapped with the MFMAs, one barrier per tile.
+// Vt key order: within every aligned group of 16 keys the columns are stored as 0-3, 8-11, 4-7, 12-15
+// (m324_qkv_split writes them so): that is the order in which the swapped MFMA contracts keys, so a lane's
+// 8-key A fragment is ONE contiguous 16-byte chunk.
+// LDS per stage: K tile [64 kv][64 d] and Vt tile [64 d][64 kv], rows of 128 bytes (bf16), 16-byte chunks
+// XOR-swizzled (chunk ^ ((row >> 1) & 7)) so fragment reads are conflict-free ds_read_b128.  Tiles are
+// staged by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the source address) into a 3-stage ring:
+// two tiles in flight, counted vmcnt + raw s_barrier, no ds_write pass and no staging registers.
 // The fp32 parity variant uses v_mfma_f32_32x32x2_f32 on padded fp32 tiles (single buffered).
 #include <stdlib.h>
 #include "common.h"
@@ -29,9 +33,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 // ------------------------------------------------------------------------------------------- bf16
 __device__ __forceinline__ int k_off(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
-// the key also folds in bit 5 of the row so that rows d and d+32 are NOT a constant offset apart: otherwise
-// hipcc fuses their reads into ds_read2st64_b64, which is half-rate and banked mod 32 (2-way conflicts)
-__device__ __forceinline__ int v_off(int row, int c8) { return row * 128 + ((c8 ^ (((row >> 1) ^ (row >> 5)) & 15)) << 3); }
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef __attribute__((address_space(1))) const void glb_ptr_t;
+constexpr int ASTAGE = 16384;   // K tile (8 KiB) + Vt tile (8 KiB)
 
 // PRESCALED: Q already carries scale * log2(e) (m324_qkv_split's q_scale), so scores are log2-domain.
 // NQ: 32-row query blocks per wave (1 or 2).  With NQ = 2 every K / Vt fragment read from LDS feeds two
@@ -42,8 +46,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
                                                         int Lkp, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 8192];   // [stage][K | Vt]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * ASTAGE];   // [stage][K | Vt]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q0 = (blockIdx.x * NW + wave) * (QW * NQ);
@@ -65,28 +70,23 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         }
     }
 
-    // staging: K tile = 512 chunks of 16 B (row = kv, 8 chunks), Vt tile = 512 chunks (row = d, 8 chunks)
-    uint4 rk[2], rv[2];
-    auto load_tile = [&](int t) {
+    // LDS-DMA staging.  A wave-instruction fills 8 tile rows (1 KiB); wave w moves row groups 2w, 2w+1 of the
+    // K tile and of the Vt tile.  Lane l fills row r = 8g + (l >> 3), slot l & 7, which holds chunk
+    // (l & 7) ^ ((r >> 1) & 7).  K rows past Lk are clamped (their scores are masked); Vt is zero padded.
+    const int srow0 = (wave * 2) * 8 + (lane >> 3), srow1 = srow0 + 8;
+    const int sc0 = ((lane & 7) ^ ((srow0 >> 1) & 7)) * 8, sc1 = ((lane & 7) ^ ((srow1 >> 1) & 7)) * 8;
+    const bf16_t* gv0 = Vh + (long)srow0 * Lkp + sc0;
+    const bf16_t* gv1 = Vh + (long)srow1 * Lkp + sc1;
+    auto issue_tile = [&](int t) {
         const int kv0 = t * KV;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-            rk[i] = (kv0 + row < Lk) ? *reinterpret_cast<const uint4*>(Kh + (long)(kv0 + row) * 64 + c * 8)
-                                     : make_uint4(0, 0, 0, 0);
-            rv[i] = *reinterpret_cast<const uint4*>(Vh + (long)row * Lkp + kv0 + c * 8);   // padded: in range
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* sk = smem + buf * 16384;
+        unsigned char* sk = smem + (t % 3) * ASTAGE + wave * 2048;
         unsigned char* sv = sk + 8192;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-            *reinterpret_cast<uint4*>(sk + k_off(row, c)) = rk[i];
-            *reinterpret_cast<uint2*>(sv + v_off(row, 2 * c)) = make_uint2(rv[i].x, rv[i].y);
-            *reinterpret_cast<uint2*>(sv + v_off(row, 2 * c + 1)) = make_uint2(rv[i].z, rv[i].w);
-        }
+        const bf16_t* gk0 = Kh + (long)min(kv0 + srow0, Lk - 1) * 64 + sc0;
+        const bf16_t* gk1 = Kh + (long)min(kv0 + srow1, Lk - 1) * 64 + sc1;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)gk0, (lds_ptr_t*)sk, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)gk1, (lds_ptr_t*)(sk + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gv0 + kv0), (lds_ptr_t*)sv, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gv1 + kv0), (lds_ptr_t*)(sv + 1024), 16, 0, 0);
     };
 
     f32x16 o[NQ][2];
@@ -108,14 +108,18 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     bool first = true;
 
     const int nt = (Lk + KV - 1) / KV;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    issue_tile(0);
+    if (nt > 1) issue_tile(1);
 
     for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt;
-        if (more) load_tile(t + 1);
-        const unsigned char* sk = smem + (t & 1) * 16384;
+        // tile t landed (this wave's 4 pieces; tile t+1's may still fly), then the barrier publishes every
+        // wave's pieces and retires all reads of the stage that tile t+2 is about to overwrite
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < nt) issue_tile(t + 2);
+        const unsigned char* sk = smem + (t % 3) * ASTAGE;
         const unsigned char* sv = sk + 8192;
 
         // ---- S'^T = K Q^T - m_ref : two 32-key blocks per query block
@@ -206,23 +210,19 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
             l_run[n] += rs2[0] + rs2[1];
         }
 
-        // ---- O^T += Vt P^T.  k-step j covers keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}
+        // ---- O^T += Vt P^T.  k-step j contracts keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}: with the permuted
+        //      key order of Vt that is the single 16-byte chunk 2j + hi of row d
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int d = db * 32 + l31;
-                uint2 a0 = *reinterpret_cast<const uint2*>(sv + v_off(d, 4 * j + hi));
-                uint2 a1 = *reinterpret_cast<const uint2*>(sv + v_off(d, 4 * j + 2 + hi));
-                uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + k_off(db * 32 + l31, 2 * j + hi));
 #pragma unroll
                 for (int n = 0; n < NQ; ++n)
-                    o[n][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&av), pf[n][j], o[n][db], 0, 0, 0);
+                    o[n][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[n][j], o[n][db], 0, 0, 0);
             }
         }
 
-        if (more) store_tile((t + 1) & 1);
-        __syncthreads();
     }
 
     // ---- normalise and store.  o[n][db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
@@ -290,7 +290,9 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 vx = *reinterpret_cast<const float4*>(Vh + (long)row * Lkp + kv0 + c * 4);
             float* pk = sk + row * FLD + c * 4;
-            float* pv = sv + row * FLD + c * 4;
+            // Vt is stored with the key quarters of each 16-key group in the order 0,2,1,3: restore key order
+            const int qd = c & 3, lq = qd == 1 ? 2 : (qd == 2 ? 1 : qd);
+            float* pv = sv + row * FLD + (c >> 2) * 16 + lq * 4;
             pk[0] = kx.x; pk[1] = kx.y; pk[2] = kx.z; pk[3] = kx.w;
             pv[0] = vx.x; pv[1] = vx.y; pv[2] = vx.z; pv[3] = vx.w;
         }

@@ -142,11 +142,15 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
         }
         __syncthreads();
         const int d = t >> 2;   // output row d, 16 tokens (t & 3) * 16
+        // key quarters of every 16-key group are stored in the order 0,2,1,3 (the order m324_attention's MFMA
+        // contracts them in): quarter i goes to slot perm(i)
         T* o = Vt + (hbase * 64 + d) * (long)Lp + l0 + part * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            store4<T>(o + i * 4, tile[d][part * 16 + i * 4], tile[d][part * 16 + i * 4 + 1], tile[d][part * 16 + i * 4 + 2],
+        for (int i = 0; i < 4; ++i) {
+            const int slot = i == 1 ? 2 : (i == 2 ? 1 : i);
+            store4<T>(o + slot * 4, tile[d][part * 16 + i * 4], tile[d][part * 16 + i * 4 + 1], tile[d][part * 16 + i * 4 + 2],
                       tile[d][part * 16 + i * 4 + 3]);
+        }
     }
 }
 
@@ -319,6 +323,52 @@ __global__ __launch_bounds__(64) void mse_final_kernel(const float* __restrict__
     if (threadIdx.x == 0) *out = weight * (s / (float)n);
 }
 
+
+// ----------------------------------------------------------------------------------- trajectory smoothing
+// Post-processing of the predicted trajectories (reference utils/inference_utils.py:99-148, a CPU triple loop
+// over B*N*3): pass 1 freezes points whose frame-to-frame displacement (of the ORIGINAL trajectory) is below
+// the threshold -- sequential in t because frame t copies the already-smoothed frame t-1; pass 2 is
+// scipy.ndimage.gaussian_filter1d along t (radius int(4 sigma + 0.5), weights exp(-x^2 / 2 sigma^2)
+// normalised, mode='nearest' = clamped indices).  One thread per (batch, point): fully coalesced over n.
+__global__ __launch_bounds__(256) void smooth_threshold_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                               int T, int N, float thr) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * N) return;
+    const int b = (int)(idx / N), n = (int)(idx % N);
+    const float* p = in + ((long)b * T * N + n) * 3;
+    float* q = out + ((long)b * T * N + n) * 3;
+    float ox = p[0], oy = p[1], oz = p[2];          // original frame t-1
+    float sx = ox, sy = oy, sz = oz;                // smoothed frame t-1
+    q[0] = sx; q[1] = sy; q[2] = sz;
+    for (int t = 1; t < T; ++t) {
+        const long o = (long)t * N * 3;
+        const float x = p[o], y = p[o + 1], z = p[o + 2];
+        const float dx = x - ox, dy = y - oy, dz = z - oz;
+        const bool still = thr >= 0.f && sqrtf(dx * dx + dy * dy + dz * dz) < thr;
+        if (!still) { sx = x; sy = y; sz = z; }
+        q[o] = sx; q[o + 1] = sy; q[o + 2] = sz;
+        ox = x; oy = y; oz = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void smooth_gauss_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int T,
+                                                           int N, float sigma, int radius) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one thread per (b, t, n)
+    if (idx >= (long)B * T * N) return;
+    const int n = (int)(idx % N), t = (int)((idx / N) % T), b = (int)(idx / ((long)N * T));
+    float wsum = 0.f;
+    for (int r = -radius; r <= radius; ++r) wsum += expf(-0.5f * (float)(r * r) / (sigma * sigma));
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int r = -radius; r <= radius; ++r) {
+        const int tt = min(max(t + r, 0), T - 1);
+        const float w = expf(-0.5f * (float)(r * r) / (sigma * sigma)) / wsum;
+        const float* p = in + (((long)b * T + tt) * N + n) * 3;
+        ax += w * p[0]; ay += w * p[1]; az += w * p[2];
+    }
+    float* q = out + idx * 3;
+    q[0] = ax; q[1] = ay; q[2] = az;
+}
+
 }  // namespace
 
 #define DISPATCH_DTYPE(dtype, name, ...)                                  \
@@ -433,5 +483,23 @@ extern "C" int m324_mse(const float* pred, const float* target, long n, float we
     hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, s, pred, target, n, partial);
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, s, partial, nb, n, weight, out);
     M324_CHECK_LAUNCH("m324_mse");
+    return M324_OK;
+}
+
+extern "C" int m324_smooth_trajectories(const float* trajs, float* tmp, float* out, int B, int T, int N, float threshold,
+                                        float sigma, void* stream) {
+    M324_REQUIRE(trajs && tmp && out && B > 0 && T > 0 && N > 0, "m324_smooth_trajectories: bad arguments");
+    M324_REQUIRE(trajs != out && tmp != out && trajs != tmp, "m324_smooth_trajectories: buffers must not alias");
+    hipStream_t s = (hipStream_t)stream;
+    const bool gauss = sigma > 0.f;
+    float* stage1 = gauss ? tmp : out;
+    hipLaunchKernelGGL(smooth_threshold_kernel, dim3(ceil_div((long)B * N, 256)), dim3(256), 0, s, trajs, stage1, B, T, N,
+                       threshold);
+    if (gauss) {
+        const int radius = (int)(4.0f * sigma + 0.5f);
+        hipLaunchKernelGGL(smooth_gauss_kernel, dim3(ceil_div((long)B * T * N, 256)), dim3(256), 0, s, stage1, out, B, T, N,
+                           sigma, radius);
+    }
+    M324_CHECK_LAUNCH("m324_smooth_trajectories");
     return M324_OK;
 }

@@ -54,6 +54,7 @@ SIGNATURES = {
     "m324_assemble_tokens": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
     "m324_linear_n3": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
     "m324_mse": [_P, _P, _L, _F, _P, _P, _P],
+    "m324_smooth_trajectories": [_P, _P, _P, _I, _I, _I, _F, _F, _P],
 }
 
 _lib = None

@@ -240,3 +240,15 @@ def mse(pred: torch.Tensor, target: torch.Tensor, weight: float) -> torch.Tensor
     out = torch.empty((), dtype=torch.float32, device=pred.device)
     L.check(L.load().m324_mse(_p(pred), _p(target), pred.numel(), weight, _p(partial), _p(out), _stream()), "m324_mse")
     return out
+
+
+def smooth_trajectories(trajs: torch.Tensor, threshold: float, sigma: float) -> torch.Tensor:
+    """[B,T,N,3] fp32 -> thresholded (threshold >= 0) and/or gaussian-filtered (sigma > 0) trajectories."""
+    if trajs.dim() != 4 or trajs.shape[3] != 3:
+        raise L.M324Error(f"smooth_trajectories: expected [B,T,N,3], got {tuple(trajs.shape)}")
+    x = trajs.detach().to(torch.float32).contiguous()
+    B, T, N, _ = x.shape
+    tmp, out = torch.empty_like(x), torch.empty_like(x)
+    L.check(L.load().m324_smooth_trajectories(_p(x), _p(tmp), _p(out), B, T, N, threshold, sigma, _stream()),
+            "m324_smooth_trajectories")
+    return out

@@ -59,3 +59,14 @@ def synth_sd(dims_kwargs):
     if key not in _SD_CACHE:
         _SD_CACHE[key] = synth.synth_state_dict(synth.Dims(**dims_kwargs), seed=0)
     return _SD_CACHE[key]
+
+
+def vt_layout(v: torch.Tensor) -> torch.Tensor:
+    """V [B,H,Lk,64] -> the Vt operand m324_attention expects: [B,H,64,round_up(Lk,64)], zero padded, with the
+    key quarters of every aligned 16-key group stored in the order 0,2,1,3 (include/m324.h, m324_qkv_split)."""
+    B, H, Lk, D = v.shape
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros((B, H, D, Lp), dtype=v.dtype)
+    vt[..., :Lk] = v.transpose(2, 3)
+    vt = vt.reshape(B, H, D, Lp // 16, 4, 4)[..., [0, 2, 1, 3], :]
+    return vt.reshape(B, H, D, Lp).contiguous()

@@ -135,3 +135,36 @@ def test_unsupported_configurations_are_rejected_not_approximated():
     s = {k: torch.from_numpy(v) for k, v in synth.synth_inputs(1, 3, 8, 16, 32).items()}
     with pytest.raises(Exception):
         model(s)
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """ckpt_{step:016}.pt with the reference's dict layout; pos_embed dropped on load so a model built for another
+    clip length accepts it (utils/inference_utils.py:36-49)."""
+    from motion324_amd import checkpoint as ck
+    src = small_model()                                   # frames = 3
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(0.01)
+    path = ck.save_checkpoint(str(tmp_path), src, param_update_step=60000, fwdbwd_pass_step=60000)
+    assert path.endswith("ckpt_0000000000060000.pt")
+    ck.save_checkpoint(str(tmp_path), src, param_update_step=10000, fwdbwd_pass_step=10000)
+    assert ck.find_latest(str(tmp_path)) == path
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {"model", "optimizer", "lr_scheduler", "fwdbwd_pass_step", "param_update_step"}
+    assert "pos_embed" in raw["model"] and "image_encoder.model.blocks.0.attn.qkv.weight" in raw["model"]
+
+    import motion324_amd as m
+    cfg = synth.make_config(frames=7, d=192, tokens=8, pcd_layers=1, n_layer=2)      # different clip length
+    cfg["model"]["dino"] = {"depth": 2}
+    dst = m.Motion_Latent_Model(cfg)
+    info = ck.load_checkpoint(path, dst, "cpu")
+    assert info == {"fwdbwd_pass_step": 60000, "param_update_step": 60000}
+    a, b = src.state_dict(), dst.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a if k != "pos_embed")
+    assert b["pos_embed"].shape[1] == 7 * 256                                          # regenerated, not loaded
+
+    bad = dict(raw)
+    bad["model"] = {k: v for k, v in raw["model"].items() if "decoder_cross_attn" not in k}
+    torch.save(bad, path)
+    with pytest.raises(RuntimeError, match="does not match"):
+        ck.load_checkpoint(path, dst, "cpu")

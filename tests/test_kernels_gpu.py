@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import rel_err, vt_layout
 
 pytestmark = pytest.mark.gpu
 
@@ -154,8 +154,7 @@ def test_qkv_split(dtype, B, L, H, norm):
     assert rel_err(Q2.float(), 0.25 * q.permute(0, 2, 1, 3)) < tol        # power-of-two scale: same rounding
     Lp = (L + 63) // 64 * 64
     assert Vt.shape == (B, H, 64, Lp)
-    assert rel_err(Vt.float()[..., :L], v.permute(0, 2, 3, 1)) < 1e-7     # pure data movement: exact
-    assert float(Vt.float()[..., L:].abs().max()) == 0.0 if Lp > L else True
+    assert torch.equal(Vt.float().cpu(), vt_layout(v.permute(0, 2, 1, 3).float()))   # pure data movement: exact
 
 
 # ------------------------------------------------------------------------------------------- attention
@@ -170,9 +169,7 @@ def _attn_ref(q, k, v, scale):
 def test_attention(dtype, B, H, Lq, Lk):
     ops = _ops()
     q, k, v = (_q(_rand((B, H, L, 64), s, sc), dtype) for L, s, sc in ((Lq, 19, 1.5), (Lk, 20, 1.5), (Lk, 21, 1.0)))
-    Lkp = (Lk + 63) // 64 * 64
-    vt = torch.zeros((B, H, 64, Lkp))
-    vt[..., :Lk] = v.transpose(2, 3)
+    vt = vt_layout(v)
     out = torch.full((B * Lq, H * 64), float("nan"), dtype=dtype, device=DEV)
     ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), vt.to(dtype).to(DEV), out)
     ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(B * Lq, H * 64)
@@ -188,9 +185,7 @@ def test_attention_prescaled_q(dtype, B, H, Lq, Lk):
     q, k, v = (_rand((B, H, L, 64), s, 1.5) for L, s in ((Lq, 51), (Lk, 52), (Lk, 53)))
     k, v = _q(k, dtype), _q(v, dtype)
     qs = _q(q * ops.Q_PRESCALE, dtype)                       # what qkv_split would store
-    Lkp = (Lk + 63) // 64 * 64
-    vt = torch.zeros((B, H, 64, Lkp))
-    vt[..., :Lk] = v.transpose(2, 3)
+    vt = vt_layout(v)
     out = torch.empty((B * Lq, H * 64), dtype=dtype, device=DEV)
     ops.attention(qs.to(dtype).to(DEV), k.to(dtype).to(DEV), vt.to(dtype).to(DEV), out, prescaled=True)
     sc = torch.einsum("bhqd,bhkd->bhqk", qs.double(), k.double()) * math.log(2.0)     # exp2(x) = exp(x ln 2)
@@ -212,7 +207,7 @@ def test_attention_lazy_max_growth(dtype):
     v = _rand((B, H, L, 64), 56)
     q, k, v = _q(q, dtype), _q(k, dtype), _q(v, dtype)
     out = torch.empty((96, 64), dtype=dtype, device=DEV)
-    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), v.transpose(2, 3).contiguous().to(dtype).to(DEV), out)
+    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV), out)
     ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(96, 64)
     assert torch.isfinite(out.float()).all()
     assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
@@ -226,7 +221,7 @@ def test_attention_shared_q(dtype):
     T, H, Lq, Lk = 5, 3, 200, 64
     q, k, v = _q(_rand((1, H, Lq, 64), 22), dtype), _q(_rand((T, H, Lk, 64), 23), dtype), _q(_rand((T, H, Lk, 64), 24), dtype)
     out = torch.empty((T * Lq, H * 64), dtype=dtype, device=DEV)
-    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), v.transpose(2, 3).contiguous().to(dtype).to(DEV), out, shared_q=True)
+    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV), out, shared_q=True)
     ref = _attn_ref(q.expand(T, -1, -1, -1), k, v, 64 ** -0.5).reshape(T * Lq, H * 64)
     assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
 
@@ -239,7 +234,7 @@ def test_attention_online_softmax_rescale(dtype):
     q, k, v = _q(_rand((B, H, L, 64), 25), dtype), _q(_rand((B, H, L, 64), 26), dtype), _q(_rand((B, H, L, 64), 27), dtype)
     k[0, 0, 300] = _q(q[0, 0, 7] * 4.0, dtype)           # q7 . k300 >> everything else, in the 5th tile
     out = torch.empty((L, 64), dtype=dtype, device=DEV)
-    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), v.transpose(2, 3).contiguous().to(dtype).to(DEV), out)
+    ops.attention(q.to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV), out)
     ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(L, 64)
     assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
     assert rel_err(out.float()[7], ref[7]) < (1e-5 if dtype == torch.float32 else 8e-3)
@@ -251,7 +246,7 @@ def test_attention_nan_propagates():
     q, k, v = _rand((1, 1, 64, 64), 28), _rand((1, 1, 64, 64), 29), _rand((1, 1, 64, 64), 30)
     k[0, 0, 3, 5] = float("nan")
     out = torch.empty((64, 64), dtype=torch.float32, device=DEV)
-    ops.attention(q.to(DEV), k.to(DEV), v.transpose(2, 3).contiguous().to(DEV), out)
+    ops.attention(q.to(DEV), k.to(DEV), vt_layout(v).to(DEV), out)
     assert torch.isnan(out).all()
 
 
