@@ -169,6 +169,20 @@ class Motion_Latent_Model(nn.Module):
         return t.detach().to(torch.float32).contiguous()
 
     def forward(self, sample: Dict[str, torch.Tensor]):
+        return self._forward(sample, None)
+
+    def forward_frame_parallel(self, sample: Dict[str, torch.Tensor], group=None):
+        """One long clip, frames sharded over the ranks of `group` with EXACT single-GPU semantics
+        (BASELINE config 5; SURVEY.md 8(e) third row).  Every rank passes the same sample (full `rgb_video`
+        [B,T,H,W,3]); rank r encodes / decodes frames partition(T, world, r) only.  Per-frame stages (DINO, local
+        blocks, decoder) need no communication; each GLOBAL block all-gathers its token-major k|v projection
+        (RCCL over xGMI; 2 x T*324*768 bf16 = 255 MB assembled per block at T = 256) so local queries attend to the
+        whole clip; `pcd_moved` is all-gathered at the end and returned complete on every rank."""
+        from . import parallel
+        rank, world = parallel.world_info(group)
+        return self._forward(sample, (rank, world, group))
+
+    def _forward(self, sample: Dict[str, torch.Tensor], shard):
         ref_pcd = sample["ref_pcd"]
         dev = ref_pcd.device
         if dev.type != "cuda":
@@ -199,15 +213,28 @@ class Motion_Latent_Model(nn.Module):
             cap["mesh_feat"] = mesh.clone()
 
         # B. image encoder (reference :466-475): resize + normalise + patchify + ViT, frozen
-        video = self._f32c(sample["rgb_video"])
+        video = sample["rgb_video"]
+        T_full = video.shape[1]
+        t0, kv_gather = 0, None
+        if shard is not None:
+            from . import parallel
+            rank, world, group = shard
+            mine = parallel.partition(T_full, world, rank)
+            if len(mine) == 0:
+                raise M324Error(f"frame-parallel forward: {T_full} frames cannot feed {world} ranks")
+            t0 = mine.start
+            video = video[:, mine.start:mine.stop]
+        video = self._f32c(video)
         _, T, Hin, Win, _ = video.shape
         dino_x = self.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))
         Pn = self.num_patches_h * self.num_patches_w
 
         # C. DINO final norm + pos-embed + token assembly + input LN in one pass (reference :477-510)
         enc = self.image_encoder.model
-        tok = ops.assemble_tokens(dino_x, P.vec(enc.norm.weight), P.vec(enc.norm.bias), DINO_EPS, self._video_pos(P, T),
-                                  P.f32(self.special_token_0).reshape(4, C), P.f32(self.special_token_rest).reshape(4, C),
+        pos = self._video_pos(P, T_full)[t0 * Pn:(t0 + T) * Pn]
+        sp_rest = P.f32(self.special_token_rest).reshape(4, C)
+        sp_first = P.f32(self.special_token_0).reshape(4, C) if t0 == 0 else sp_rest     # only clip frame 0 is special
+        tok = ops.assemble_tokens(dino_x, P.vec(enc.norm.weight), P.vec(enc.norm.bias), DINO_EPS, pos, sp_first, sp_rest,
                                   mesh, P.vec(self.transformer_input_layernorm.weight),
                                   self.transformer_input_layernorm.eps, B, T, K, Pn)
         Lt = 4 + K + Pn
@@ -217,8 +244,23 @@ class Motion_Latent_Model(nn.Module):
             cap["dino_tokens"], cap["trunk_in"] = dn, tok.clone()
 
         # D. alternating global / local trunk (reference :394-409)
+        if shard is not None and shard[1] > 1:
+            rank, world, group = shard
+            frames = parallel.counts(T_full, world)
+
+            def kv_gather(kv_local):
+                """[B*T_local*Lt, 2C] (strided view) -> ([B*T_full*Lt, 2C], T_full*Lt), batch-major, rank order =
+                frame order (the order of keys does not matter to softmax, but it keeps V and K aligned)."""
+                mx = max(frames) * Lt
+                buf = torch.zeros((B, mx, kv_local.shape[1]), dtype=kv_local.dtype, device=dev)
+                buf[:, :T * Lt] = kv_local.reshape(B, T * Lt, -1)
+                parts = [torch.empty_like(buf) for _ in range(world)]
+                torch.distributed.all_gather(parts, buf, group=group)
+                full = torch.cat([p[:, :f * Lt] for p, f in zip(parts, frames)], dim=1)
+                return full.reshape(B * T_full * Lt, -1), T_full * Lt
+
         for gblk, lblk in zip(self.global_transformer_blocks, self.local_transformer_blocks):
-            gblk.run(P, tok, B, T * Lt)
+            gblk.run(P, tok, B, T * Lt, kv_gather=kv_gather)
             lblk.run(P, tok, B * T, Lt)
             if cap is not None and "trunk_block0" not in cap:
                 cap["trunk_block0"] = tok.clone()
@@ -255,6 +297,14 @@ class Motion_Latent_Model(nn.Module):
         if cap is not None and "decoder_out_t0" in cap:
             cap["decoder_out_t0"] = torch.stack(cap["decoder_out_t0"], dim=0)
 
+        if shard is not None and shard[1] > 1:
+            rank, world, group = shard
+            frames = parallel.counts(T_full, world)
+            buf = torch.zeros((max(frames), B, N, 3), dtype=torch.float32, device=dev)
+            buf[:T] = out.transpose(0, 1)
+            parts = [torch.empty_like(buf) for _ in range(world)]
+            torch.distributed.all_gather(parts, buf, group=group)
+            out = torch.cat([p[:f] for p, f in zip(parts, frames)], dim=0).transpose(0, 1).contiguous()
         result = edict(input_data=sample, pcd_moved=out)
         if "point_clouds" in sample:                                           # reference :582-592
             m = self.loss_computer(out, sample["point_clouds"].to(dev))

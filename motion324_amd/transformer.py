@@ -117,8 +117,11 @@ class QK_Norm_TransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim, bias=ln_bias)
         self.mlp = MLP(dim, mlp_ratio=mlp_ratio, bias=mlp_bias, dropout=mlp_dropout)
 
-    def run(self, P: Prepared, x: torch.Tensor, B: int, L: int) -> torch.Tensor:
-        """x: fp32 [B*L, C] residual stream, updated in place (x + attn(LN x); x + mlp(LN x))."""
+    def run(self, P: Prepared, x: torch.Tensor, B: int, L: int, kv_gather=None) -> torch.Tensor:
+        """x: fp32 [B*L, C] residual stream, updated in place (x + attn(LN x); x + mlp(LN x)).
+
+        kv_gather (frame-parallel global attention): callable mapping this rank's token-major k|v projection
+        [B*L, 2C] to (all ranks' [B*L_full, 2C], L_full); queries stay local, keys/values cover the whole clip."""
         rows, C = x.shape
         assert rows == B * L
         a = self.attn
@@ -127,8 +130,15 @@ class QK_Norm_TransformerBlock(nn.Module):
         qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)
         ops.gemm(h, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
         qw, kw = a._qk_w(P)
-        Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads, P.dtype,
-                                 q_scale=ops.Q_PRESCALE)
+        if kv_gather is None:
+            Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads,
+                                     P.dtype, q_scale=ops.Q_PRESCALE)
+        else:
+            kv_full, L_full = kv_gather(qkv[:, C:])
+            Q, _, _ = ops.qkv_split(qkv[:, :C], None, None, qw, None, RMS_EPS, B, L, a.num_heads, P.dtype,
+                                    q_scale=ops.Q_PRESCALE)
+            _, K, Vt = ops.qkv_split(None, kv_full[:, :C], kv_full[:, C:], None, kw, RMS_EPS, B, L_full, a.num_heads,
+                                     P.dtype)
         ops.attention(Q, K, Vt, h, prescaled=True)                                       # h reused as the attention output
         ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
         return _mlp_residual(P, self.norm2, self.mlp, x)
