@@ -169,6 +169,27 @@ int m324_mse(const float* pred, const float* target, long n, float weight, float
 int m324_smooth_trajectories(const float* trajs, float* tmp, float* out, int B, int T, int N,
                              float threshold, float sigma, void* stream);
 
+/* ==========================================================================================
+ * Training-side entry points (backward of the path; reference: torch autograd over the same modules,
+ * train.py:150-166).  The backward GEMMs reuse m324_gemm on transposed operands:
+ *   dA[M,K] = dC[M,N] . Wt[K,N]^T          (Wt = m324_transpose(W))
+ *   dW[N,K] (+)= dCt[N,Mp] . At[K,Mp]^T    (dCt, At = m324_transpose of the activations, Mp = round_up(M,64))
+ * ========================================================================================== */
+/* out[c][r] = in[r][c] for r < rows, zeros for rows <= r < rows_pad.  out is [cols, ld_out >= rows_pad]. */
+int m324_transpose(const void* in, long ld_in, void* out, long ld_out, int rows, int cols, int rows_pad,
+                   int dtype, void* stream);
+/* out[c] (+)= sum over rows of x[r][c] (fp32 accumulation): bias gradients. */
+int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
+/* h = gelu_erf(z);  dz = dh * gelu'(z)  (nn.GELU, transformer.py:58), elementwise over n values. */
+int m324_gelu(const void* z, void* h, long n, int dtype, void* stream);
+int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, void* stream);
+/* LayerNorm backward (weight-only or with bias; the statistics are recomputed from x):
+ *   dx[in_row(r)] (+)= d/dx ; partial[n_partial][2C] receives per-wave sums of dy*xhat | dy -- reduce with
+ *   m324_colsum(partial, 2C, ..., rows = n_partial) to get dw | db (two-stage = deterministic). */
+int m324_layernorm_bwd(const float* x, long ldx, const float* w, float eps, const void* dy, long ldy, int dy_dtype,
+                       float* dx, long lddx, int accumulate, float* partial, int n_partial, int rows, int C,
+                       int gin, int gout, int off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -369,6 +369,119 @@ __global__ __launch_bounds__(256) void smooth_gauss_kernel(const float* __restri
     q[0] = ax; q[1] = ay; q[2] = az;
 }
 
+// =====================================================================================================
+// Training-side kernels (backward of the HBM-bound ops + layout helpers for the backward GEMMs)
+// =====================================================================================================
+
+// out[c][r] = in[r][c]; rows beyond `rows` up to rows_pad are written as zeros (the backward GEMMs contract
+// over the token dimension, which must be a multiple of the K-tile).  64 x 64 tiles through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, long ld_in, T* __restrict__ out, long ld_out,
+                                                        int rows, int cols, int rows_pad) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int id = t + 256 * i, r = id >> 6, c = id & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? Elem<T>::load(in + (long)(r0 + r) * ld_in + c0 + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int id = t + 256 * i, c = id >> 6, r = id & 63;
+        if (c0 + c < cols && r0 + r < rows_pad) Elem<T>::store(out + (long)(c0 + c) * ld_out + r0 + r, tile[r][c]);
+    }
+}
+
+// out[c] (+)= sum_r x[r][c] : bias gradients and the second stage of LayerNorm weight gradients.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, float* __restrict__ out, int rows,
+                                                     int cols, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = w; r < rows; r += 4) s += Elem<T>::load(x + (long)r * ld + c);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < cols) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[c] = accumulate ? out[c] + v : v;
+    }
+}
+
+// GELU forward on a stored pre-activation and its backward: dz = dh * (Phi(z) + z * phi(z)).
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ z, T* __restrict__ h, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        Elem<T>::store(h + i, gelu_erf(Elem<T>::load(z + i)));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dh, T* __restrict__ dz,
+                                                       long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = Elem<T>::load(z + i);
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+        Elem<T>::store(dz + i, Elem<T>::load(dh + i) * (cdf + x * pdf));
+    }
+}
+
+// LayerNorm backward, one wave per row (grid-stride over rows):
+//   xh = (x - mean) * rstd ; g = dy * w ; dx += rstd * (g - mean(g) - xh * mean(g * xh))
+//   partial[wave][0:C] += dy * xh (dw), partial[wave][C:2C] += dy (db)  -> summed by m324_colsum (deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                            float eps, const T* __restrict__ dy, long ldy,
+                                                            float* __restrict__ dx, long lddx, int accumulate,
+                                                            float* __restrict__ partial, int rows, int C, int gin, int gout,
+                                                            int off) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    float4 pw[LN_MAXV], pb[LN_MAXV];
+    LN_FOR(i, c) { pw[i] = make_float4(0.f, 0.f, 0.f, 0.f); pb[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (long row = gw; row < rows; row += nw) {
+        const long xr = remap_row(row, gin, gout, off);
+        float4 v[LN_MAXV];
+        row_load(v, x + xr * ldx, lane, C);
+        float mean, rstd;
+        row_stats(v, lane, C, eps, mean, rstd);
+        float4 g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+        LN_FOR(i, c) {
+            const float4 d = load4<T>(dy + row * ldy + c);
+            const float4 ww = *reinterpret_cast<const float4*>(w + c);
+            v[i].x = (v[i].x - mean) * rstd; v[i].y = (v[i].y - mean) * rstd;
+            v[i].z = (v[i].z - mean) * rstd; v[i].w = (v[i].w - mean) * rstd;
+            pw[i].x += d.x * v[i].x; pw[i].y += d.y * v[i].y; pw[i].z += d.z * v[i].z; pw[i].w += d.w * v[i].w;
+            pb[i].x += d.x; pb[i].y += d.y; pb[i].z += d.z; pb[i].w += d.w;
+            g[i] = make_float4(d.x * ww.x, d.y * ww.y, d.z * ww.z, d.w * ww.w);
+            s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+            s2 += g[i].x * v[i].x + g[i].y * v[i].y + g[i].z * v[i].z + g[i].w * v[i].w;
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+        float* dr = dx + xr * lddx;
+        LN_FOR(i, c) {
+            float4 o = make_float4(rstd * (g[i].x - s1 - v[i].x * s2), rstd * (g[i].y - s1 - v[i].y * s2),
+                                   rstd * (g[i].z - s1 - v[i].z * s2), rstd * (g[i].w - s1 - v[i].w * s2));
+            if (accumulate) {
+                const float4 p = *reinterpret_cast<const float4*>(dr + c);
+                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
+            *reinterpret_cast<float4*>(dr + c) = o;
+        }
+    }
+    if (gw < nw) {
+        float* pr = partial + (long)gw * 2 * C;
+        LN_FOR(i, c) {
+            *reinterpret_cast<float4*>(pr + c) = pw[i];
+            *reinterpret_cast<float4*>(pr + C + c) = pb[i];
+        }
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_DTYPE(dtype, name, ...)                                  \
@@ -501,5 +614,62 @@ extern "C" int m324_smooth_trajectories(const float* trajs, float* tmp, float* o
                            sigma, radius);
     }
     M324_CHECK_LAUNCH("m324_smooth_trajectories");
+    return M324_OK;
+}
+
+extern "C" int m324_transpose(const void* in, long ld_in, void* out, long ld_out, int rows, int cols, int rows_pad, int dtype,
+                              void* stream) {
+    M324_REQUIRE(in && out && rows > 0 && cols > 0 && rows_pad >= rows && ld_in >= cols && ld_out >= rows_pad,
+                 "m324_transpose: bad arguments");
+    dim3 grid(ceil_div(cols, 64), ceil_div(rows_pad, 64));
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_transpose",
+                   hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, s, (const T*)in, ld_in, (T*)out, ld_out, rows, cols,
+                                      rows_pad));
+    M324_CHECK_LAUNCH("m324_transpose");
+    return M324_OK;
+}
+
+extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate, void* stream) {
+    M324_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "m324_colsum: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_colsum",
+                   hipLaunchKernelGGL(colsum_kernel<T>, dim3(ceil_div(cols, 64)), dim3(256), 0, s, (const T*)x, ld, out, rows, cols,
+                                      accumulate));
+    M324_CHECK_LAUNCH("m324_colsum");
+    return M324_OK;
+}
+
+extern "C" int m324_gelu(const void* z, void* h, long n, int dtype, void* stream) {
+    M324_REQUIRE(z && h && n > 0, "m324_gelu: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    DISPATCH_DTYPE(dtype, "m324_gelu", hipLaunchKernelGGL(gelu_fwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)z, (T*)h, n));
+    M324_CHECK_LAUNCH("m324_gelu");
+    return M324_OK;
+}
+
+extern "C" int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, void* stream) {
+    M324_REQUIRE(z && dh && dz && n > 0, "m324_gelu_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    DISPATCH_DTYPE(dtype, "m324_gelu_bwd",
+                   hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)z, (const T*)dh, (T*)dz, n));
+    M324_CHECK_LAUNCH("m324_gelu_bwd");
+    return M324_OK;
+}
+
+extern "C" int m324_layernorm_bwd(const float* x, long ldx, const float* w, float eps, const void* dy, long ldy, int dy_dtype,
+                                  float* dx, long lddx, int accumulate, float* partial, int n_partial, int rows, int C, int gin,
+                                  int gout, int off, void* stream) {
+    M324_REQUIRE(x && w && dy && dx && partial, "m324_layernorm_bwd: null pointer");
+    M324_REQUIRE(rows > 0 && C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV, "m324_layernorm_bwd: rows=%d C=%d unsupported", rows, C);
+    M324_REQUIRE(n_partial > 0 && n_partial % 4 == 0 && n_partial <= 4096, "m324_layernorm_bwd: n_partial must be a multiple of 4");
+    M324_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0, "m324_layernorm_bwd: leading dims must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dy_dtype, "m324_layernorm_bwd",
+                   hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(n_partial / 4), dim3(256), 0, s, x, ldx, w, eps, (const T*)dy,
+                                      ldy, dx, lddx, accumulate, partial, rows, C, gin, gout, off));
+    M324_CHECK_LAUNCH("m324_layernorm_bwd");
     return M324_OK;
 }

@@ -55,6 +55,11 @@ SIGNATURES = {
     "m324_linear_n3": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
     "m324_mse": [_P, _P, _L, _F, _P, _P, _P],
     "m324_smooth_trajectories": [_P, _P, _P, _I, _I, _I, _F, _F, _P],
+    "m324_transpose": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "m324_colsum": [_P, _L, _P, _I, _I, _I, _I, _P],
+    "m324_gelu": [_P, _P, _L, _I, _P],
+    "m324_gelu_bwd": [_P, _P, _P, _L, _I, _P],
+    "m324_layernorm_bwd": [_P, _L, _P, _F, _P, _L, _I, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 
 _lib = None

@@ -252,3 +252,58 @@ def smooth_trajectories(trajs: torch.Tensor, threshold: float, sigma: float) -> 
     L.check(L.load().m324_smooth_trajectories(_p(x), _p(tmp), _p(out), B, T, N, threshold, sigma, _stream()),
             "m324_smooth_trajectories")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ training side
+def transpose(x: torch.Tensor, rows_pad: Optional[int] = None) -> torch.Tensor:
+    """[R, C] -> [C, rows_pad] (rows_pad = round_up(R, 64) by default; the pad columns are zeros)."""
+    R, Cc = x.shape
+    px, ld = _rows(x, "x")
+    rp = (R + 63) // 64 * 64 if rows_pad is None else rows_pad
+    out = torch.empty((Cc, rp), dtype=x.dtype, device=x.device)
+    L.check(L.load().m324_transpose(px, ld, _p(out), rp, R, Cc, rp, code_of(x.dtype), _stream()), "m324_transpose")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    R, Cc = x.shape
+    px, ld = _rows(x, "x")
+    if out is None:
+        out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    L.check(L.load().m324_colsum(px, ld, _vec(out, Cc, "out"), R, Cc, code_of(x.dtype), int(accumulate), _stream()),
+            "m324_colsum")
+    return out
+
+
+def gelu(z: torch.Tensor) -> torch.Tensor:
+    assert z.is_contiguous()
+    h = torch.empty_like(z)
+    L.check(L.load().m324_gelu(_p(z), _p(h), z.numel(), code_of(z.dtype), _stream()), "m324_gelu")
+    return h
+
+
+def gelu_bwd(z: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
+    assert z.is_contiguous() and dh.is_contiguous() and z.shape == dh.shape and z.dtype == dh.dtype
+    dz = torch.empty_like(z)
+    L.check(L.load().m324_gelu_bwd(_p(z), _p(dh), _p(dz), z.numel(), code_of(z.dtype), _stream()), "m324_gelu_bwd")
+    return dz
+
+
+def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool,
+                  row_map=(0, 0, 0)):
+    """dx[in_row(r)] (+)= LN backward of row r; returns (dw [C], db [C]) fp32.  x, dx fp32; dy in the compute dtype."""
+    if x.dtype != torch.float32 or dx.dtype != torch.float32:
+        raise L.M324Error("layernorm_bwd: x and dx must be fp32")
+    rows, Cdim = dy.shape
+    px, ldx = _rows(x, "x")
+    pdy, ldy = _rows(dy, "dy")
+    pdx, lddx = _rows(dx, "dx")
+    n_partial = min(1024, (rows + 3) // 4 * 4)
+    partial = torch.empty((n_partial, 2 * Cdim), dtype=torch.float32, device=x.device)
+    gin, gout, off = row_map
+    L.check(L.load().m324_layernorm_bwd(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
+                                        int(accumulate), _p(partial), n_partial, rows, Cdim, gin, gout, off, _stream()),
+            "m324_layernorm_bwd")
+    both = colsum(partial)
+    return both[:Cdim], both[Cdim:]
