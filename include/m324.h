@@ -89,7 +89,11 @@ int m324_layernorm(const float* x, long ldx, const float* w, const float* b, flo
  * ------------------------------------------------------------------------------------------ */
 int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, const void* v_src, long ldv,
                    const float* q_w, const float* k_w, float eps, float q_scale,
-                   void* Q, void* K, void* Vt, int B, int L, int H, int dtype, void* stream);
+                   void* Q, void* K, void* V, void* Qt, void* Kt, void* Vt,
+                   int B, int L, int H, int dtype, void* stream);
+/*   Each source may be emitted row-major (Q, K, V: [B,H,L,64]) and/or transposed (Qt, Kt, Vt: [B,H,64,Lp], the
+ *   permuted, zero-padded layout described above); NULL outputs are skipped.  Inference uses Q, K, Vt; the attention
+ *   backward also uses V, Qt, Kt and the same kernel on dO. */
 
 /* ------------------------------------------------------------------------------------------
  * m324_attention: O = softmax(Q K^T * scale) V, flash-style (no L x L matrix in HBM).
@@ -101,7 +105,8 @@ int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, con
  *   q_prescaled != 0: Q already holds q * scale * log2(e) (see m324_qkv_split) and `scale` is ignored.
  * ------------------------------------------------------------------------------------------ */
 int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo,
-                   int B, int H, int Lq, int Lk, float scale, int q_prescaled, int dtype, void* stream);
+                   int B, int H, int Lq, int Lk, float scale, int q_prescaled, float* lse, int dtype, void* stream);
+/*   lse (optional, [B,H,Lq] fp32): log2-domain log-sum-exp of every score row, saved for the backward pass. */
 
 /* ------------------------------------------------------------------------------------------
  * m324_patchify: video frames -> DINOv2 patch rows.
@@ -189,6 +194,40 @@ int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, vo
 int m324_layernorm_bwd(const float* x, long ldx, const float* w, float eps, const void* dy, long ldy, int dy_dtype,
                        float* dx, long lddx, int accumulate, float* partial, int n_partial, int rows, int C,
                        int gin, int gout, int off, void* stream);
+
+/* out = in converted between fp32 / bf16 (rows x cols, leading dims in elements). */
+int m324_cast(const void* in, long ld_in, int in_dtype, void* out, long ld_out, int out_dtype, int rows, int cols,
+              void* stream);
+/* Attention backward (flash-attention backward of transformer.py:134-139,209-214 under autograd).
+ *   m324_attention_delta: D[B,H,L] = rowsum(dO * O) over each head's 64 columns (token-major O, dO, ld >= H*64).
+ *   m324_attention_bwd:   Qs[Bq,H,Lq,64] (pre-scaled q, q_bstride 0 = shared), K, V [B,H,Lk,64] row-major, dO [B,H,Lq,64]
+ *                         head-major, lse / D [B,H,Lq] -> dQ [B,H,Lq,64] (w.r.t. the UNSCALED normalised q; per batch even when
+ *                         q is shared: sum over batches afterwards), dK, dV [B,H,Lk,64].  fp32 arithmetic. */
+int m324_attention_delta(const void* O, const void* dO, long ld, float* D, int B, int H, int L, int dtype, void* stream);
+int m324_attention_bwd(const void* Qs, long q_bstride, const void* K, const void* V, const void* dO, const float* lse,
+                       const float* D, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, float scale,
+                       int dtype, void* stream);
+/* Backward of m324_qkv_split: head-major dQ/dK/dV -> token-major gradients of the projections (RMSNorm backward for
+ * q, k when q_w / k_w are given; raw projections needed).  partial [n_partial][128]: per-block sums of the q_norm | k_norm
+ * weight gradients, reduce with m324_colsum. */
+int m324_qkv_split_bwd(const void* dQ, const void* dK, const void* dV, const void* q_raw, long ldq, const void* k_raw,
+                       long ldk, const float* q_w, const float* k_w, float eps, void* dq_out, long ldoq, void* dk_out,
+                       long ldok, void* dv_out, long ldov, float* partial, int n_partial, int B, int L, int H, int dtype,
+                       void* stream);
+/* Backward of m324_linear_n3: dA[M,K] = dout[M,3] . W[3,K]; partial [n_partial][3*K] = per-block sums of dout^T A
+ * (reduce with m324_colsum to get dW). */
+int m324_linear_n3_bwd(const void* A, long lda, const float* W, const float* dout, void* dA, long ldda, float* partial,
+                       int n_partial, int M, int K, int dtype, void* stream);
+/* d[i] = coef * (*grad_scale) * (pred[i] - target[i])  -- backward of m324_mse (coef = 2 * weight / n). */
+int m324_mse_bwd(const float* pred, const float* target, const float* grad_scale, float coef, float* d, long n,
+                 void* stream);
+/* torch.optim.AdamW step on one tensor (utils/training_utils.py:38-52: betas (0.9, 0.95), eps 1e-8, decoupled decay);
+ * grad_scale: optional device scalar multiplying the gradient (clipping coefficient, train.py:196). */
+int m324_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, const float* grad_scale, void* stream);
+/* *out (+)= sum g^2 (gradient-norm pieces); sanitize != 0 first applies nan_to_num(0, 1e-6, -1e-6) in place
+ * (train.py:181-183).  partial: >= 1024 floats of scratch. */
+int m324_grad_sumsq(float* g, long n, int sanitize, float* partial, float* out, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ template <bool PRESCALED, int NQ>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
-                                                        int Lkp, float scale_log2e) {
+                                                        int Lkp, float scale_log2e, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * ASTAGE];   // [stage][K | Vt]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         const float l_tot = l_run[n] + __shfl_xor(l_run[n], 32, 64);
         const float inv = 1.0f / l_tot;
         const int q = q0 + n * QW + l31;
+        if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_ref[n] + log2f(l_tot);   // log2-domain LSE
         if (q < Lq) {
             bf16_t* orow = O + ((long)b * Lq + q) * ldo + h * 64;
 #pragma unroll
@@ -252,7 +253,7 @@ constexpr int FLD = 65;   // padded row length (floats) of the fp32 tiles: confl
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ Q, long q_bstride,
                                                        const float* __restrict__ K, const float* __restrict__ Vt,
                                                        float* __restrict__ O, long ldo, int H, int Lq, int Lk, int Lkp,
-                                                       float scale_log2e) {
+                                                       float scale_log2e, float* __restrict__ lse) {
     __shared__ float sk[KV * FLD];   // [kv][d]
     __shared__ float sv[64 * FLD];   // [d][kv]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
+    if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_run + log2f(l_tot);
     if (q < Lq) {
         float* orow = O + ((long)b * Lq + q) * ldo + h * 64;
 #pragma unroll
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 }  // namespace
 
 extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B,
-                              int H, int Lq, int Lk, float scale, int q_prescaled, int dtype, void* stream) {
+                              int H, int Lq, int Lk, float scale, int q_prescaled, float* lse, int dtype, void* stream) {
     M324_REQUIRE(Q && K && Vt && O, "m324_attention: null pointer");
     M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "m324_attention: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
     M324_REQUIRE(ldo >= (long)H * 64, "m324_attention: ldo too small");
@@ -389,14 +391,14 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         const unsigned pad = (focc && atoi(focc) == 2) ? 24 * 1024 : 0;
 #define M324_ATTN(PS, NQ)                                                                                                \
     hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ>), g2, dim3(256), pad, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K, \
-                       (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl)
+                       (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse)
         if (q_prescaled) { if (nq2) M324_ATTN(true, 2); else M324_ATTN(true, 1); }
         else { if (nq2) M324_ATTN(false, 2); else M324_ATTN(false, 1); }
 #undef M324_ATTN
     } else if (dtype == M324_F32) {
         M324_REQUIRE(ldo % 4 == 0, "m324_attention: ldo misaligned");
         hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, s, (const float*)Q, q_bstride, (const float*)K,
-                           (const float*)Vt, (float*)O, ldo, H, Lq, Lk, Lkp, sl);
+                           (const float*)Vt, (float*)O, ldo, H, Lq, Lk, Lkp, sl, lse);
     } else {
         M324_FAIL(M324_ERR_UNSUPPORTED, "m324_attention: dtype %d", dtype);
     }

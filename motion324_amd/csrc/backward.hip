@@ -1,0 +1,319 @@
+// Backward / optimizer kernels of the training step (reference: torch autograd + torch.optim.AdamW(fused) over
+// the same modules; train.py:150-213, utils/training_utils.py:38-52).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p) { return Elem<T>::load(p); }
+
+// ----------------------------------------------------------------------------------- cast
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
+                                                   int rows, int cols) {
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cols, c = i % cols;
+        Elem<TO>::store(out + r * ld_out + c, Elem<TI>::load(in + r * ld_in + c));
+    }
+}
+
+// ----------------------------------------------------------------------------------- attention backward
+// D[b,h,q] = sum_d dO[q, h*64+d] * O[q, h*64+d]   (token-major O / dO, one wave per (token, head))
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__ dO, long ld,
+                                                         float* __restrict__ D, int B, int H, int L) {
+    const int lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long)B * L * H) return;
+    const int h = (int)(w % H);
+    const long row = w / H;                       // b * L + l
+    const float v = ld1(O + row * ld + h * 64 + lane) * ld1(dO + row * ld + h * 64 + lane);
+    const float s = wave_sum(v);
+    if (lane == 0) D[((row / L) * H + h) * L + row % L] = s;
+}
+
+// Reference-quality backward (fp32 arithmetic, one wave per row, lane = head dimension).  Used by the fp32 parity
+// mode and as the on-device check of the MFMA kernels.  Qs carries scale*log2(e) (scores are log2-domain):
+//   P = exp2(Qs.K - lse), dS = P * (dO.V - D);  dqhat = scale * dS K  (gradient w.r.t. the UNSCALED normalised q),
+//   dK = ln2 * dS^T Qs, dV = P^T dO.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ Qs, long q_bstride, const T* __restrict__ K,
+                                                          const T* __restrict__ V, const T* __restrict__ dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ D,
+                                                          T* __restrict__ dQ, int H, int Lq, int Lk, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Lq) return;
+    const long bh = (long)b * H + h;
+    const float qv = ld1(Qs + (long)b * q_bstride + ((long)h * Lq + q) * 64 + lane);
+    const float dov = ld1(dO + (bh * Lq + q) * 64 + lane);
+    const float l2 = lse[bh * Lq + q], dl = D[bh * Lq + q];
+    const T* Kh = K + bh * (long)Lk * 64;
+    const T* Vh = V + bh * (long)Lk * 64;
+    float acc = 0.f;
+    for (int j = 0; j < Lk; ++j) {
+        const float kv = ld1(Kh + (long)j * 64 + lane), vv = ld1(Vh + (long)j * 64 + lane);
+        const float s2 = wave_sum(qv * kv);
+        const float dp = wave_sum(dov * vv);
+        const float ds = exp2f(s2 - l2) * (dp - dl);
+        acc += ds * kv;
+    }
+    Elem<T>::store(dQ + (bh * Lq + q) * 64 + lane, acc * scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ Qs, long q_bstride, const T* __restrict__ K,
+                                                           const T* __restrict__ V, const T* __restrict__ dO,
+                                                           const float* __restrict__ lse, const float* __restrict__ D,
+                                                           T* __restrict__ dK, T* __restrict__ dV, int H, int Lq, int Lk) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= Lk) return;
+    const long bh = (long)b * H + h;
+    const float kv = ld1(K + (bh * Lk + j) * 64 + lane), vv = ld1(V + (bh * Lk + j) * 64 + lane);
+    const T* Qh = Qs + (long)b * q_bstride + (long)h * Lq * 64;
+    const T* dOh = dO + bh * (long)Lq * 64;
+    float dk = 0.f, dv = 0.f;
+    for (int i = 0; i < Lq; ++i) {
+        const float qv = ld1(Qh + (long)i * 64 + lane), dov = ld1(dOh + (long)i * 64 + lane);
+        const float p = exp2f(wave_sum(qv * kv) - lse[bh * Lq + i]);
+        const float ds = p * (wave_sum(dov * vv) - D[bh * Lq + i]);
+        dv += p * dov;
+        dk += ds * qv;
+    }
+    Elem<T>::store(dK + (bh * Lk + j) * 64 + lane, dk * 0.69314718055994530942f);
+    Elem<T>::store(dV + (bh * Lk + j) * 64 + lane, dv);
+}
+
+// ----------------------------------------------------------------------------------- qkv split backward
+// Head-major gradients (dQhat, dKhat: w.r.t. the RMS-normalised q / k; dV) -> token-major d(qkv); RMSNorm backward for
+// q and k needs the raw projections.  One wave per (token, head), lane = column.  w-gradients: per-block partial sums.
+//   y = x * r * w, r = rsqrt(mean(x^2) + eps):  dx = r * (g - xh * mean(g * xh)), g = dy * w, xh = x * r ; dw += dy * xh
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const T* __restrict__ dQ, const T* __restrict__ dK, const T* __restrict__ dV,
+                                                            const T* __restrict__ q_raw, long ldq, const T* __restrict__ k_raw, long ldk,
+                                                            const float* __restrict__ qw, const float* __restrict__ kw, float eps,
+                                                            T* __restrict__ dq_out, long ldoq, T* __restrict__ dk_out, long ldok,
+                                                            T* __restrict__ dv_out, long ldov, float* __restrict__ partial, int B, int L,
+                                                            int H) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float pq = 0.f, pk = 0.f;
+    const long total = (long)B * L * H;
+    for (long w = (long)blockIdx.x * 4 + wv; w < total; w += (long)gridDim.x * 4) {
+        const int h = (int)(w % H);
+        const long row = w / H;                   // b * L + l
+        const long b = row / L, l = row % L;
+        const long hm = ((b * H + h) * L + l) * 64 + lane;
+        auto norm_bwd = [&](const T* dy_p, const T* raw, long ld, const float* wgt, T* out, long ldo, float& pw) {
+            const float dy = ld1(dy_p + hm);
+            if (!wgt) { Elem<T>::store(out + row * ldo + h * 64 + lane, dy); return; }
+            const float x = ld1(raw + row * ld + h * 64 + lane);
+            const float r = rsqrtf(wave_sum(x * x) * (1.0f / 64.0f) + eps);
+            const float xh = x * r, g = dy * wgt[lane];
+            const float m = wave_sum(g * xh) * (1.0f / 64.0f);
+            pw += dy * xh;
+            Elem<T>::store(out + row * ldo + h * 64 + lane, r * (g - xh * m));
+        };
+        if (dQ) norm_bwd(dQ, q_raw, ldq, qw, dq_out, ldoq, pq);
+        if (dK) norm_bwd(dK, k_raw, ldk, kw, dk_out, ldok, pk);
+        if (dV) Elem<T>::store(dv_out + row * ldov + h * 64 + lane, ld1(dV + hm));
+    }
+    red[0][wv][lane] = pq;
+    red[1][wv][lane] = pk;
+    __syncthreads();
+    if (wv == 0) {
+        partial[(long)blockIdx.x * 128 + lane] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        partial[(long)blockIdx.x * 128 + 64 + lane] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    }
+}
+
+// ----------------------------------------------------------------------------------- 3-wide head backward
+// out = A W^T + b, W [3,K]:  dA[m,k] = sum_j dout[m,j] W[j,k] ; partial[blk][3*K] = sum_m dout[m,j] A[m,k]
+template <typename T>
+__global__ __launch_bounds__(256) void linear_n3_bwd_kernel(const T* __restrict__ A, long lda, const float* __restrict__ W,
+                                                            const float* __restrict__ dout, T* __restrict__ dA, long ldda,
+                                                            float* __restrict__ partial, int M, int K) {
+    const int t = threadIdx.x;
+    // each thread owns columns t, t+256, ... ; rows are strided over blocks
+    for (int k = t; k < K; k += 256) {
+        const float w0 = W[k], w1 = W[K + k], w2 = W[2 * (long)K + k];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (long m = blockIdx.x; m < M; m += gridDim.x) {
+            const float d0 = dout[m * 3], d1 = dout[m * 3 + 1], d2 = dout[m * 3 + 2];
+            const float a = ld1(A + m * lda + k);
+            s0 += d0 * a; s1 += d1 * a; s2 += d2 * a;
+            Elem<T>::store(dA + m * ldda + k, d0 * w0 + d1 * w1 + d2 * w2);
+        }
+        float* pr = partial + (long)blockIdx.x * 3 * K;
+        pr[k] = s0; pr[K + k] = s1; pr[2 * (long)K + k] = s2;
+    }
+}
+
+// ----------------------------------------------------------------------------------- loss backward
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const float* __restrict__ gscale, float coef, float* __restrict__ d, long n) {
+    const float g = coef * (gscale ? *gscale : 1.0f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) d[i] = g * (pred[i] - target[i]);
+}
+
+// ----------------------------------------------------------------------------------- optimizer
+// torch.optim.AdamW semantics (decoupled weight decay): p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  `gscale` (device scalar, may be NULL) multiplies the
+// gradient first (gradient clipping coefficient), `nan_to_num` applies train.py:181-183 (nan -> 0, +-inf -> +-1e-6).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pi;
+    }
+}
+
+__global__ __launch_bounds__(256) void grad_sanitize_sumsq_kernel(float* __restrict__ g, long n, int sanitize,
+                                                                  float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float x = g[i];
+        if (sanitize) {
+            if (x != x) x = 0.f;
+            else if (x == INFINITY) x = 1e-6f;
+            else if (x == -INFINITY) x = -1e-6f;
+            g[i] = x;
+        }
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(64) void sum_partial_kernel(const float* __restrict__ partial, int n, float* __restrict__ out,
+                                                         int accumulate) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *out = accumulate ? *out + s : s;
+}
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, name, ...)                                  \
+    if ((dtype) == M324_BF16) { using T = bf16_t; __VA_ARGS__; }          \
+    else if ((dtype) == M324_F32) { using T = float; __VA_ARGS__; }       \
+    else M324_FAIL(M324_ERR_UNSUPPORTED, name ": dtype %d", (int)(dtype))
+
+static int grid_for(long n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+extern "C" int m324_cast(const void* in, long ld_in, int in_dtype, void* out, long ld_out, int out_dtype, int rows, int cols,
+                         void* stream) {
+    M324_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= cols, "m324_cast: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = grid_for((long)rows * cols);
+    if (in_dtype == M324_F32 && out_dtype == M324_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, s, (const float*)in, ld_in, (bf16_t*)out, ld_out, rows, cols);
+    else if (in_dtype == M324_BF16 && out_dtype == M324_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, ld_in, (float*)out, ld_out, rows, cols);
+    else if (in_dtype == M324_F32 && out_dtype == M324_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(nb), dim3(256), 0, s, (const float*)in, ld_in, (float*)out, ld_out, rows, cols);
+    else if (in_dtype == M324_BF16 && out_dtype == M324_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, rows, cols);
+    else
+        M324_FAIL(M324_ERR_UNSUPPORTED, "m324_cast: dtypes %d -> %d", in_dtype, out_dtype);
+    M324_CHECK_LAUNCH("m324_cast");
+    return M324_OK;
+}
+
+extern "C" int m324_attention_delta(const void* O, const void* dO, long ld, float* D, int B, int H, int L, int dtype, void* stream) {
+    M324_REQUIRE(O && dO && D && B > 0 && H > 0 && L > 0 && ld >= (long)H * 64, "m324_attention_delta: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const long waves = (long)B * L * H;
+    DISPATCH_DTYPE(dtype, "m324_attention_delta",
+                   hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(ceil_div(waves, 4)), dim3(256), 0, s, (const T*)O, (const T*)dO, ld, D,
+                                      B, H, L));
+    M324_CHECK_LAUNCH("m324_attention_delta");
+    return M324_OK;
+}
+
+extern "C" int m324_attention_bwd(const void* Qs, long q_bstride, const void* K, const void* V, const void* dO, const float* lse,
+                                  const float* D, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, float scale,
+                                  int dtype, void* stream) {
+    M324_REQUIRE(Qs && K && V && dO && lse && D && dQ && dK && dV, "m324_attention_bwd: null pointer");
+    M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && H <= 65535 && B <= 65535, "m324_attention_bwd: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_attention_bwd", {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(ceil_div(Lq, 4), H, B), dim3(256), 0, s, (const T*)Qs, q_bstride, (const T*)K,
+                           (const T*)V, (const T*)dO, lse, D, (T*)dQ, H, Lq, Lk, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3(ceil_div(Lk, 4), H, B), dim3(256), 0, s, (const T*)Qs, q_bstride,
+                           (const T*)K, (const T*)V, (const T*)dO, lse, D, (T*)dK, (T*)dV, H, Lq, Lk);
+    });
+    M324_CHECK_LAUNCH("m324_attention_bwd");
+    return M324_OK;
+}
+
+extern "C" int m324_qkv_split_bwd(const void* dQ, const void* dK, const void* dV, const void* q_raw, long ldq, const void* k_raw,
+                                  long ldk, const float* q_w, const float* k_w, float eps, void* dq_out, long ldoq, void* dk_out,
+                                  long ldok, void* dv_out, long ldov, float* partial, int n_partial, int B, int L, int H, int dtype,
+                                  void* stream) {
+    M324_REQUIRE(partial && n_partial > 0 && n_partial <= 2048 && B > 0 && L > 0 && H > 0, "m324_qkv_split_bwd: bad arguments");
+    M324_REQUIRE((!dQ || (dq_out && (!q_w || q_raw))) && (!dK || (dk_out && (!k_w || k_raw))) && (!dV || dv_out),
+                 "m324_qkv_split_bwd: missing buffer");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_qkv_split_bwd",
+                   hipLaunchKernelGGL(qkv_split_bwd_kernel<T>, dim3(n_partial), dim3(256), 0, s, (const T*)dQ, (const T*)dK,
+                                      (const T*)dV, (const T*)q_raw, ldq, (const T*)k_raw, ldk, q_w, k_w, eps, (T*)dq_out, ldoq,
+                                      (T*)dk_out, ldok, (T*)dv_out, ldov, partial, B, L, H));
+    M324_CHECK_LAUNCH("m324_qkv_split_bwd");
+    return M324_OK;
+}
+
+extern "C" int m324_linear_n3_bwd(const void* A, long lda, const float* W, const float* dout, void* dA, long ldda, float* partial,
+                                  int n_partial, int M, int K, int dtype, void* stream) {
+    M324_REQUIRE(A && W && dout && dA && partial && n_partial > 0 && M > 0 && K > 0, "m324_linear_n3_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_linear_n3_bwd",
+                   hipLaunchKernelGGL(linear_n3_bwd_kernel<T>, dim3(n_partial), dim3(256), 0, s, (const T*)A, lda, W, dout, (T*)dA,
+                                      ldda, partial, M, K));
+    M324_CHECK_LAUNCH("m324_linear_n3_bwd");
+    return M324_OK;
+}
+
+extern "C" int m324_mse_bwd(const float* pred, const float* target, const float* grad_scale, float coef, float* d, long n,
+                            void* stream) {
+    M324_REQUIRE(pred && target && d && n > 0, "m324_mse_bwd: bad arguments");
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, grad_scale, coef, d, n);
+    M324_CHECK_LAUNCH("m324_mse_bwd");
+    return M324_OK;
+}
+
+extern "C" int m324_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, const float* grad_scale, void* stream) {
+    M324_REQUIRE(p && g && m && v && n > 0 && step >= 1, "m324_adamw: bad arguments");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, grad_scale);
+    M324_CHECK_LAUNCH("m324_adamw");
+    return M324_OK;
+}
+
+extern "C" int m324_grad_sumsq(float* g, long n, int sanitize, float* partial, float* out, int accumulate, void* stream) {
+    M324_REQUIRE(g && partial && out && n > 0, "m324_grad_sumsq: bad arguments");
+    const int nb = grid_for(n) < 1024 ? grid_for(n) : 1024;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(grad_sanitize_sumsq_kernel, dim3(nb), dim3(256), 0, s, g, n, sanitize, partial);
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(1), dim3(64), 0, s, partial, nb, out, accumulate);
+    M324_CHECK_LAUNCH("m324_grad_sumsq");
+    return M324_OK;
+}

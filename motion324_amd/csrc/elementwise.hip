@@ -76,11 +76,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // ----------------------------------------------------------------------------------- qkv split
 // One workgroup per (64-token tile, head, batch).  Thread t: token = t >> 2, 16 columns (t & 3) * 16.
+// Each of the three sources can be emitted row-major (head-major [B,H,L,64]) and / or transposed
+// ([B,H,64,Lp], key quarters of every 16-token group in the order 0,2,1,3, zero padded): inference needs
+// Q, K, Vt; the attention backward additionally needs V, Qt, Kt (and dO / dOt, produced by the same kernel).
 template <typename T>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs, long ldq, const T* __restrict__ ks, long ldk,
                                                         const T* __restrict__ vs, long ldv, const float* __restrict__ qw,
                                                         const float* __restrict__ kw, float eps, float q_scale,
-                                                        T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vt, int L, int H,
+                                                        T* __restrict__ Q, T* __restrict__ K, T* __restrict__ V,
+                                                        T* __restrict__ Qt, T* __restrict__ Kt, T* __restrict__ Vt, int L, int H,
                                                         int Lp) {
     __shared__ float tile[64][65];
     const int t = threadIdx.x, tok = t >> 2, part = t & 3;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
     const long srow = (long)b * L + l;
     const long hbase = ((long)b * H + h);
 
-    auto do_qk = [&](const T* src, long ld, const float* w, T* dst, float post) {
+    auto one = [&](const T* src, long ld, const float* w, float post, T* dst, T* dstT) {
         float v[16];
         if (ok) {
             const T* p = src + srow * ld + h * 64 + part * 16;
@@ -117,41 +121,29 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] *= post;
         }
-        if (ok) {
+        if (dst && ok) {
             T* o = dst + (hbase * L + l) * 64 + part * 16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) store4<T>(o + i * 4, v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
         }
-    };
-    if (qs) do_qk(qs, ldq, qw, Q, q_scale);
-    if (ks) do_qk(ks, ldk, kw, K, 1.0f);
-    if (vs) {
-        if (ok) {
-            const T* p = vs + srow * ldv + h * 64 + part * 16;
+        if (dstT) {
+            __syncthreads();   // previous user of the tile is done
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tile[part * 16 + i][tok] = v[i];     // zeros beyond L: the padding
+            __syncthreads();
+            const int d = t >> 2;   // output row d, 16 tokens (t & 3) * 16
+            T* o = dstT + (hbase * 64 + d) * (long)Lp + l0 + part * 16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float4 f = load4<T>(p + i * 4);
-                tile[part * 16 + i * 4 + 0][tok] = f.x;
-                tile[part * 16 + i * 4 + 1][tok] = f.y;
-                tile[part * 16 + i * 4 + 2][tok] = f.z;
-                tile[part * 16 + i * 4 + 3][tok] = f.w;
+                const int slot = i == 1 ? 2 : (i == 2 ? 1 : i);   // token quarter i of the 16-group -> slot perm(i)
+                store4<T>(o + slot * 4, tile[d][part * 16 + i * 4], tile[d][part * 16 + i * 4 + 1],
+                          tile[d][part * 16 + i * 4 + 2], tile[d][part * 16 + i * 4 + 3]);
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tile[part * 16 + i][tok] = 0.f;   // zero padding up to Lp
         }
-        __syncthreads();
-        const int d = t >> 2;   // output row d, 16 tokens (t & 3) * 16
-        // key quarters of every 16-key group are stored in the order 0,2,1,3 (the order m324_attention's MFMA
-        // contracts them in): quarter i goes to slot perm(i)
-        T* o = Vt + (hbase * 64 + d) * (long)Lp + l0 + part * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int slot = i == 1 ? 2 : (i == 2 ? 1 : i);
-            store4<T>(o + slot * 4, tile[d][part * 16 + i * 4], tile[d][part * 16 + i * 4 + 1], tile[d][part * 16 + i * 4 + 2],
-                      tile[d][part * 16 + i * 4 + 3]);
-        }
-    }
+    };
+    if (qs) one(qs, ldq, qw, q_scale, Q, Qt);
+    if (ks) one(ks, ldk, kw, 1.0f, K, Kt);
+    if (vs) one(vs, ldv, nullptr, 1.0f, V, Vt);
 }
 
 // ----------------------------------------------------------------------------------- patchify
@@ -504,17 +496,18 @@ extern "C" int m324_layernorm(const float* x, long ldx, const float* w, const fl
 }
 
 extern "C" int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, const void* v_src, long ldv,
-                              const float* q_w, const float* k_w, float eps, float q_scale, void* Q, void* K, void* Vt, int B,
-                              int L, int H, int dtype, void* stream) {
+                              const float* q_w, const float* k_w, float eps, float q_scale, void* Q, void* K, void* V, void* Qt,
+                              void* Kt, void* Vt, int B, int L, int H, int dtype, void* stream) {
     M324_REQUIRE(B > 0 && L > 0 && H > 0, "m324_qkv_split: empty problem");
-    M324_REQUIRE((!q_src || Q) && (!k_src || K) && (!v_src || Vt), "m324_qkv_split: missing output");
+    M324_REQUIRE((!q_src || Q || Qt) && (!k_src || K || Kt) && (!v_src || V || Vt), "m324_qkv_split: missing output");
     M324_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "m324_qkv_split: leading dims must be multiples of 4");
     const int Lp = (L + 63) / 64 * 64;
     dim3 grid(Lp / 64, H, B);
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, "m324_qkv_split",
                    hipLaunchKernelGGL(qkv_split_kernel<T>, grid, dim3(256), 0, s, (const T*)q_src, ldq, (const T*)k_src, ldk,
-                                      (const T*)v_src, ldv, q_w, k_w, eps, q_scale, (T*)Q, (T*)K, (T*)Vt, L, H, Lp));
+                                      (const T*)v_src, ldv, q_w, k_w, eps, q_scale, (T*)Q, (T*)K, (T*)V, (T*)Qt, (T*)Kt, (T*)Vt,
+                                      L, H, Lp));
     M324_CHECK_LAUNCH("m324_qkv_split");
     return M324_OK;
 }

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libm324.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class M324Error(RuntimeError):
@@ -45,8 +45,8 @@ SIGNATURES = {
     "m324_device_info": [C.c_char_p, _I],
     "m324_gemm": [C.POINTER(GemmArgs), _P],
     "m324_layernorm": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
-    "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P],
-    "m324_attention": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _I, _I, _P],
+    "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "m324_attention": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _I, _P, _I, _P],
     "m324_patchify": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "m324_point_encode": [_P, _I, _P, _L, _I, _P],
     "m324_point_concat": [_P, _P, _I, _P, _I, _I, _I, _P],
@@ -59,6 +59,14 @@ SIGNATURES = {
     "m324_colsum": [_P, _L, _P, _I, _I, _I, _I, _P],
     "m324_gelu": [_P, _P, _L, _I, _P],
     "m324_gelu_bwd": [_P, _P, _P, _L, _I, _P],
+    "m324_cast": [_P, _L, _I, _P, _L, _I, _I, _I, _P],
+    "m324_attention_delta": [_P, _P, _L, _P, _I, _I, _I, _I, _P],
+    "m324_attention_bwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "m324_qkv_split_bwd": [_P, _P, _P, _P, _L, _P, _L, _P, _P, _F, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "m324_linear_n3_bwd": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P],
+    "m324_mse_bwd": [_P, _P, _P, _F, _P, _L, _P],
+    "m324_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
+    "m324_grad_sumsq": [_P, _L, _I, _P, _P, _I, _P],
     "m324_layernorm_bwd": [_P, _L, _P, _F, _P, _L, _I, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 

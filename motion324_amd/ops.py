@@ -111,19 +111,26 @@ Q_PRESCALE = (64 ** -0.5) * LOG2E      # softmax scale of head_dim 64, log2 doma
 
 
 def qkv_split(q_src, k_src, v_src, q_w, k_w, eps: float, B: int, Lq: int, H: int, dtype: torch.dtype, *,
-              q_scale: float = 1.0, q_out=None, k_out=None, vt_out=None):
-    """Head-major Q[B,H,L,64], K[B,H,L,64], Vt[B,H,64,Lp] from token-major sources (any may be None).
+              q_scale: float = 1.0, train: bool = False):
+    """Head-major attention operands from token-major sources (any source may be None).
 
-    All given sources share B and L (use separate calls for cross-attention's q and k/v)."""
+    Inference (train=False): returns (Q[B,H,L,64], K[B,H,L,64], Vt[B,H,64,Lp]).
+    Training  (train=True):  returns a dict with Q, K, V (row-major) and Qt, Kt, Vt (transposed, permuted) for every
+    given source -- what m324_attention_bwd needs.  All given sources share B and L."""
     dev = next(t for t in (q_src, k_src, v_src) if t is not None).device
     Lp = (Lq + 63) // 64 * 64
-    Q = K = Vt = None
-    if q_src is not None:
-        Q = q_out if q_out is not None else torch.empty((B, H, Lq, 64), dtype=dtype, device=dev)
-    if k_src is not None:
-        K = k_out if k_out is not None else torch.empty((B, H, Lq, 64), dtype=dtype, device=dev)
-    if v_src is not None:
-        Vt = vt_out if vt_out is not None else torch.empty((B, H, 64, Lp), dtype=dtype, device=dev)
+
+    def row():
+        return torch.empty((B, H, Lq, 64), dtype=dtype, device=dev)
+
+    def tr():
+        return torch.empty((B, H, 64, Lp), dtype=dtype, device=dev)
+    Q = row() if q_src is not None else None
+    K = row() if k_src is not None else None
+    V = row() if (v_src is not None and train) else None
+    Qt = tr() if (q_src is not None and train) else None
+    Kt = tr() if (k_src is not None and train) else None
+    Vt = tr() if v_src is not None else None
 
     def src(t, name):
         if t is None:
@@ -134,13 +141,16 @@ def qkv_split(q_src, k_src, v_src, q_w, k_w, eps: float, B: int, Lq: int, H: int
     pq, ldq = src(q_src, "q_src")
     pk, ldk = src(k_src, "k_src")
     pv, ldv = src(v_src, "v_src")
-    L.check(L.load().m324_qkv_split(pq, ldq, pk, ldk, pv, ldv, _vec(q_w, 64, "q_w"), _vec(k_w, 64, "k_w"), eps,
-                                    q_scale, _p(Q), _p(K), _p(Vt), B, Lq, H, code_of(dtype), _stream()), "m324_qkv_split")
+    L.check(L.load().m324_qkv_split(pq, ldq, pk, ldk, pv, ldv, _vec(q_w, 64, "q_w"), _vec(k_w, 64, "k_w"), eps, q_scale,
+                                    _p(Q), _p(K), _p(V), _p(Qt), _p(Kt), _p(Vt), B, Lq, H, code_of(dtype), _stream()),
+            "m324_qkv_split")
+    if train:
+        return {"Q": Q, "K": K, "V": V, "Qt": Qt, "Kt": Kt, "Vt": Vt}
     return Q, K, Vt
 
 
 def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Tensor, *, shared_q: bool = False,
-              scale: Optional[float] = None, prescaled: bool = False) -> torch.Tensor:
+              scale: Optional[float] = None, prescaled: bool = False, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[B*Lq, H*64] = softmax(Q K^T scale) V.  Q[Bq,H,Lq,64] (Bq == 1 with shared_q), K[B,H,Lk,64],
     Vt[B,H,64,Lkp].  prescaled: Q was produced with qkv_split(q_scale=Q_PRESCALE)."""
     B, H, Lk, D = K.shape
@@ -161,7 +171,7 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     esz = Q.element_size()
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
               esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq)):
-        L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, int(prescaled),
+        L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, int(prescaled), _p(lse),
                                         code_of(Q.dtype), _stream()), "m324_attention")
     return out
 
@@ -307,3 +317,97 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
             "m324_layernorm_bwd")
     both = colsum(partial)
     return both[:Cdim], both[Cdim:]
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    R, Cc = x.shape
+    px, ld = _rows(x, "x")
+    if out is None:
+        out = torch.empty((R, Cc), dtype=dtype, device=x.device)
+    po, ldo = _rows(out, "out")
+    L.check(L.load().m324_cast(px, ld, code_of(x.dtype), po, ldo, code_of(out.dtype), R, Cc, _stream()), "m324_cast")
+    return out
+
+
+def attention_delta(O: torch.Tensor, dO: torch.Tensor, B: int, H: int, Lq: int) -> torch.Tensor:
+    po, ld = _rows(O, "O")
+    pd, ld2 = _rows(dO, "dO")
+    if ld != ld2 or O.dtype != dO.dtype:
+        raise L.M324Error("attention_delta: O and dO must share layout and dtype")
+    D = torch.empty((B, H, Lq), dtype=torch.float32, device=O.device)
+    L.check(L.load().m324_attention_delta(po, pd, ld, _p(D), B, H, Lq, code_of(O.dtype), _stream()), "m324_attention_delta")
+    return D
+
+
+def attention_bwd(Qs, K, V, dO, lse, D, *, shared_q: bool = False, scale: float = 64 ** -0.5):
+    """Head-major operands (see include/m324.h) -> (dQ [B,H,Lq,64] w.r.t. the unscaled normalised q, dK, dV)."""
+    B, H, Lk, _ = K.shape
+    Lq = Qs.shape[2]
+    for t in (Qs, K, V, dO):
+        if not t.is_contiguous() or t.dtype != K.dtype:
+            raise L.M324Error("attention_bwd: operands must be contiguous and share a dtype")
+    dQ = torch.empty((B, H, Lq, 64), dtype=K.dtype, device=K.device)
+    dK, dV = torch.empty_like(K), torch.empty_like(V)
+    L.check(L.load().m324_attention_bwd(_p(Qs), 0 if shared_q else H * Lq * 64, _p(K), _p(V), _p(dO), _p(lse), _p(D), _p(dQ),
+                                        _p(dK), _p(dV), B, H, Lq, Lk, scale, code_of(K.dtype), _stream()), "m324_attention_bwd")
+    return dQ, dK, dV
+
+
+def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: int, H: int, dq_out, dk_out, dv_out):
+    """Writes token-major gradients into dq_out / dk_out / dv_out (2-D views, any may be None with its dX);
+    returns (dq_norm_w [64] or None, dk_norm_w [64] or None)."""
+    dtype = next(t for t in (dQ, dK, dV) if t is not None).dtype
+    n_partial = min(1024, max(1, (B * Lq * H + 3) // 4))
+    dev = next(t for t in (dQ, dK, dV) if t is not None).device
+    partial = torch.empty((n_partial, 128), dtype=torch.float32, device=dev)
+
+    def rw(t):
+        return _rows(t, "view") if t is not None else (None, 0)
+    pq, ldq = rw(q_raw)
+    pk, ldk = rw(k_raw)
+    poq, ldoq = rw(dq_out)
+    pok, ldok = rw(dk_out)
+    pov, ldov = rw(dv_out)
+    L.check(L.load().m324_qkv_split_bwd(_p(dQ), _p(dK), _p(dV), pq, ldq, pk, ldk, _vec(q_w, 64, "q_w"), _vec(k_w, 64, "k_w"),
+                                        eps, poq, ldoq, pok, ldok, pov, ldov, _p(partial), n_partial, B, Lq, H, code_of(dtype),
+                                        _stream()), "m324_qkv_split_bwd")
+    both = colsum(partial)
+    return (both[:64] if (dQ is not None and q_w is not None) else None,
+            both[64:] if (dK is not None and k_w is not None) else None)
+
+
+def linear_n3_bwd(a: torch.Tensor, w: torch.Tensor, dout: torch.Tensor):
+    """Backward of linear_n3: returns (dA [M,K] in a.dtype, dW [3,K] fp32, db [3] fp32)."""
+    M, K = a.shape
+    pa, lda = _rows(a, "a")
+    dout = dout.reshape(M, 3)
+    if dout.dtype != torch.float32 or not dout.is_contiguous():
+        raise L.M324Error("linear_n3_bwd: dout must be contiguous fp32 [M,3]")
+    dA = torch.empty((M, K), dtype=a.dtype, device=a.device)
+    n_partial = min(512, M)
+    partial = torch.empty((n_partial, 3 * K), dtype=torch.float32, device=a.device)
+    L.check(L.load().m324_linear_n3_bwd(pa, lda, _p(w), _p(dout), _p(dA), K, _p(partial), n_partial, M, K, code_of(a.dtype),
+                                        _stream()), "m324_linear_n3_bwd")
+    return dA, colsum(partial).reshape(3, K), colsum(dout)
+
+
+def mse_bwd(pred: torch.Tensor, target: torch.Tensor, weight: float, grad_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    pred, target = pred.contiguous().float(), target.contiguous().float()
+    d = torch.empty_like(pred)
+    L.check(L.load().m324_mse_bwd(_p(pred), _p(target), _p(grad_scale), 2.0 * weight / pred.numel(), _p(d), pred.numel(),
+                                  _stream()), "m324_mse_bwd")
+    return d
+
+
+def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
+               eps: float, weight_decay: float, step: int, grad_scale: Optional[torch.Tensor] = None) -> None:
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+            raise L.M324Error("adamw_step: tensors must be contiguous fp32 of equal size")
+    L.check(L.load().m324_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                _p(grad_scale), _stream()), "m324_adamw")
+
+
+def grad_sumsq(g: torch.Tensor, out: torch.Tensor, partial: torch.Tensor, sanitize: bool, accumulate: bool) -> None:
+    L.check(L.load().m324_grad_sumsq(_p(g), g.numel(), int(sanitize), _p(partial), _p(out), int(accumulate), _stream()),
+            "m324_grad_sumsq")

@@ -58,7 +58,7 @@ def test_errors_are_reported_not_thrown_across_the_abi():
     args.A, args.W, args.C = 16, 16, 16
     args.M, args.N, args.K, args.lda, args.ldw, args.ldc = 4, 128, 40, 40, 40, 128
     assert h.m324_gemm(ctypes.byref(args), None) == -1 and "K=40" in lib.last_error()
-    assert h.m324_attention(16, 0, 16, 16, 16, 64, 1, 1, 4, 4, 0.125, 0, 7, None) == -3
+    assert h.m324_attention(16, 0, 16, 16, 16, 64, 1, 1, 4, 4, 0.125, 0, None, 7, None) == -3
     assert h.m324_layernorm(16, 768, 16, None, 1e-5, 16, 768, 0, 4, 770, 0, 0, 0, None) == -1
 
 

@@ -73,3 +73,129 @@ def test_layernorm_backward(dtype, rows, C):
     dx2 = torch.full((rows, C), float("nan"), device=DEV)
     ops.layernorm_bwd(x.to(DEV), w.to(DEV), 1e-5, dy.to(dtype).to(DEV), dx2, accumulate=False)
     assert rel_err(dx2, xt.grad) < 2e-6
+
+
+def _head_major(t, B, L, H):
+    return t.reshape(B, L, H, 64).permute(0, 2, 1, 3).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Lq,Lk,shared", [(2, 3, 70, 70, False), (1, 2, 33, 200, False), (3, 2, 50, 64, True)])
+def test_attention_backward_against_autograd(dtype, B, H, Lq, Lk, shared):
+    """forward (with saved LSE) + m324_attention_delta + m324_attention_bwd vs autograd of softmax(q k^T / 8) v."""
+    from motion324_amd import ops
+    from conftest import vt_layout
+    Bq = 1 if shared else B
+    qhat = _rand((Bq, H, Lq, 64), 11, 1.2)                                 # "normalised, unscaled" q
+    k, v = _q(_rand((B, H, Lk, 64), 12, 1.2), dtype), _q(_rand((B, H, Lk, 64), 13), dtype)
+    qs = _q(qhat * ops.Q_PRESCALE, dtype)                                  # what qkv_split stores
+    dO_tok = _q(_rand((B * Lq, H * 64), 14), dtype)
+    # reference in fp64 on the stored (rounded) operands; gradient w.r.t. qhat = qs / prescale
+    qh = (qs.double() / ops.Q_PRESCALE).requires_grad_(True)
+    kd, vd = k.double().requires_grad_(True), v.double().requires_grad_(True)
+    s = torch.einsum("bhqd,bhkd->bhqk", qh.expand(B, -1, -1, -1), kd) * (64 ** -0.5)
+    o = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(s, -1), vd).reshape(B * Lq, H * 64)
+    o.backward(dO_tok.double())
+
+    dev = lambda t: t.to(dtype).to(DEV)
+    out = torch.empty((B * Lq, H * 64), dtype=dtype, device=DEV)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=DEV)
+    ops.attention(dev(qs), dev(k), dev(vt_layout(v)), out, shared_q=shared, prescaled=True, lse=lse)
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    assert rel_err(out.float(), o.detach()) < tol
+    ref_lse = torch.logsumexp(s.detach(), -1) / math.log(2.0)
+    assert rel_err(lse, ref_lse) < 1e-5 if dtype == torch.float32 else rel_err(lse, ref_lse) < 1e-3
+    D = ops.attention_delta(out, dev(dO_tok), B, H, Lq)
+    dO_hm = _head_major(dO_tok, B, Lq, H)
+    dQ, dK, dV = ops.attention_bwd(dev(qs), dev(k), dev(v), dev(dO_hm), lse, D, shared_q=shared)
+    gtol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    dq_ref = qh.grad if not shared else qh.grad                              # autograd already summed over batches
+    got_dq = dQ.float().cpu().double()
+    if shared:
+        got_dq = got_dq.sum(0, keepdim=True)
+    assert rel_err(got_dq, dq_ref) < gtol
+    assert rel_err(dK.float(), kd.grad) < gtol and rel_err(dV.float(), vd.grad) < gtol
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_qkv_split_train_outputs_and_backward(dtype):
+    from motion324_amd import ops
+    from conftest import vt_layout
+    B, L, H = 2, 100, 3
+    C = H * 64
+    qkv = _q(_rand((B * L, 3 * C), 15), dtype)
+    qw, kw = 1 + 0.1 * _rand((64,), 16), 1 + 0.1 * _rand((64,), 17)
+    d = qkv.to(dtype).to(DEV)
+    outs = ops.qkv_split(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], qw.to(DEV), kw.to(DEV), 1e-5, B, L, H, dtype, q_scale=0.25,
+                         train=True)
+    # transposed copies are exactly vt_layout of the row-major ones
+    for a, b in (("Q", "Qt"), ("K", "Kt"), ("V", "Vt")):
+        assert torch.equal(outs[b].float().cpu(), vt_layout(outs[a].float().cpu()))
+    # backward vs autograd of rmsnorm
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (t.reshape(B, L, H, 64) for t in x.chunk(3, -1))
+    qwd, kwd = qw.double().requires_grad_(True), kw.double().requires_grad_(True)
+    qn = q * torch.rsqrt((q * q).mean(-1, keepdim=True) + 1e-5) * qwd
+    kn = k * torch.rsqrt((k * k).mean(-1, keepdim=True) + 1e-5) * kwd
+    gq, gk, gv = (_q(_rand((B, H, L, 64), s), dtype) for s in (18, 19, 20))
+    (qn.permute(0, 2, 1, 3) * gq.double()).sum().backward(retain_graph=True)
+    (kn.permute(0, 2, 1, 3) * gk.double()).sum().backward(retain_graph=True)
+    (v.permute(0, 2, 1, 3) * gv.double()).sum().backward()
+    dqkv = torch.zeros((B * L, 3 * C), dtype=dtype, device=DEV)
+    dqw, dkw = ops.qkv_split_bwd(gq.to(dtype).to(DEV), gk.to(dtype).to(DEV), gv.to(dtype).to(DEV), d[:, :C], d[:, C:2 * C],
+                                 qw.to(DEV), kw.to(DEV), 1e-5, B, L, H, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:])
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    assert rel_err(dqkv.float(), x.grad) < tol
+    assert rel_err(dqw, qwd.grad) < 1e-4 and rel_err(dkw, kwd.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_n3_backward(dtype):
+    from motion324_amd import ops
+    M, K = 999, 192
+    a, w = _q(_rand((M, K), 21), dtype), _rand((3, K), 22, 0.1)
+    dout = _rand((M, 3), 23)
+    at, wt = a.double().requires_grad_(True), w.double().requires_grad_(True)
+    bt = torch.zeros(3, dtype=torch.float64, requires_grad=True)
+    (at @ wt.T + bt).backward(dout.double())
+    dA, dW, db = ops.linear_n3_bwd(a.to(dtype).to(DEV), w.to(DEV), dout.to(DEV))
+    assert rel_err(dA.float(), at.grad) < (1e-6 if dtype == torch.float32 else 5e-3)
+    assert rel_err(dW, wt.grad) < 1e-5 and rel_err(db, bt.grad) < 1e-5
+
+
+def test_mse_backward_and_cast():
+    from motion324_amd import ops
+    p, t = _rand((2, 3, 50, 3), 24), _rand((2, 3, 50, 3), 25)
+    gs = torch.tensor(0.5, device=DEV)
+    d = ops.mse_bwd(p.to(DEV), t.to(DEV), 2.0, gs)
+    pt = p.double().requires_grad_(True)
+    (0.5 * 2.0 * ((pt - t.double()) ** 2).mean()).backward()
+    assert rel_err(d, pt.grad) < 1e-6
+    x = _rand((37, 100), 26)
+    b = ops.cast(x.to(DEV), torch.bfloat16)
+    assert torch.equal(b.cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast(b, torch.float32).cpu(), x.to(torch.bfloat16).float())
+
+
+def test_adamw_matches_torch_and_grad_norm():
+    from motion324_amd import ops
+    torch.manual_seed(0)
+    p0, g = _rand((1000,), 27), _rand((1000,), 28)
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([ref], lr=4e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        gi = g * step
+        ref.grad = gi.double()
+        opt.step()
+        ops.adamw_step(p, gi.to(DEV), m, v, 4e-4, 0.9, 0.95, 1e-8, 0.05, step)
+    assert rel_err(p, ref.detach()) < 1e-6
+    # gradient norm with sanitising
+    gg = g.clone()
+    gg[3], gg[5], gg[7] = float("nan"), float("inf"), float("-inf")
+    gd = gg.to(DEV)
+    out, partial = torch.zeros((), device=DEV), torch.empty(1024, device=DEV)
+    ops.grad_sumsq(gd, out, partial, sanitize=True, accumulate=False)
+    clean = torch.nan_to_num(gg, nan=0.0, posinf=1e-6, neginf=-1e-6)
+    assert torch.equal(gd.cpu(), clean)
+    assert abs(float(out) - float((clean.double() ** 2).sum())) < 1e-3
