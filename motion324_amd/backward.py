@@ -1,0 +1,214 @@
+"""Backward passes of the blocks, built from libm324 kernels (no torch autograd inside).
+
+Every function takes the block's saved INPUT (fp32 residual stream), recomputes the block's internal activations
+(the reference trains with activation checkpointing per block, Pcd_motion.py:375-448 -- same memory policy) and
+returns the gradient w.r.t. the input; parameter gradients are accumulated into a GradStore in fp32.
+
+Backward GEMMs reuse m324_gemm on transposed operands (include/m324.h "Training-side entry points"):
+    dA = dY . W      -> gemm(dY, Wt)          Wt = transposed weight, cached in Prepared
+    dW = dY^T . A    -> gemm(dYt, At)         transposes of the two activations, token dim padded to 64
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .prepared import Prepared
+
+RMS_EPS = 1e-5
+
+
+class GradStore:
+    """fp32 gradient accumulator keyed by parameter (what autograd's .grad would hold)."""
+
+    def __init__(self):
+        self.grads: Dict[int, torch.Tensor] = {}
+        self.params: Dict[int, torch.nn.Parameter] = {}
+
+    def add(self, param: Optional[torch.nn.Parameter], g: torch.Tensor) -> None:
+        if param is None or not param.requires_grad:
+            return
+        g = g.reshape(param.shape)
+        k = id(param)
+        if k in self.grads:
+            self.grads[k] += g          # accumulation of a few small tensors (shared weights): torch add on fp32
+        else:
+            self.grads[k] = g.float().clone() if g.dtype != torch.float32 or not g.is_contiguous() else g.clone()
+            self.params[k] = param
+
+    def get(self, param) -> Optional[torch.Tensor]:
+        return self.grads.get(id(param))
+
+
+def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
+    """[K', N_pad] transposed GEMM operand of a weight (for dgrad), cached like P.mat."""
+    return P.derived("matT", (weight,), lambda: ops.transpose(P.mat(weight)))
+
+
+def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: torch.Tensor, need_da: bool = True):
+    """y = a W^T + b.  a [M, Ka] and dy [M, N] in the compute dtype.  Returns da [M, Ka] (compute dtype) or None."""
+    M, N = dy.shape
+    if bias is not None:
+        G.add(bias, ops.colsum(dy))
+    dYt = ops.transpose(dy)                                   # [N, Mp]
+    At = ops.transpose(a)                                     # [Ka, Mp]
+    dW = torch.empty((N, a.shape[1]), dtype=torch.float32, device=dy.device)
+    ops.gemm(dYt, At, dW)
+    k_true = weight[0].numel()
+    G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
+    if not need_da:
+        return None
+    Wt = _wt(P, weight)                                       # [Kp, N_pad]
+    if Wt.shape[1] != N:
+        raise RuntimeError("linear_bwd: output width must be a multiple of 64")
+    da = torch.empty((M, Wt.shape[0]), dtype=dy.dtype, device=dy.device)
+    ops.gemm(dy, Wt, da)
+    return da
+
+
+def mlp_residual_bwd(P: Prepared, G: GradStore, norm2, mlp, x_mid: torch.Tensor, dx: torch.Tensor) -> None:
+    """x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))).  dx (fp32): grad w.r.t. x_out on entry, w.r.t. x_mid on exit."""
+    rows, C = x_mid.shape
+    fc1, fc2 = mlp.mlp[0], mlp.mlp[2]
+    h2 = torch.empty((rows, C), dtype=P.dtype, device=dx.device)
+    ops.layernorm(x_mid, P.vec(norm2.weight), P.vec(norm2.bias), norm2.eps, h2)
+    z = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=dx.device)
+    ops.gemm(h2, P.mat(fc1.weight), z, bias=P.vec(fc1.bias))
+    g = ops.gelu(z)
+    dxT = ops.cast(dx, P.dtype)
+    dg = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT)
+    dz = ops.gelu_bwd(z, dg)
+    dh2 = linear_bwd(P, G, fc1.weight, fc1.bias, h2, dz)
+    dw, db = ops.layernorm_bwd(x_mid, P.vec(norm2.weight), norm2.eps, dh2, dx, accumulate=True)
+    G.add(norm2.weight, dw)
+    G.add(norm2.bias, db)
+
+
+def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: torch.Tensor, B: int, L: int) -> None:
+    """Backward of QK_Norm_TransformerBlock.run.  dx: grad w.r.t. the block output on entry, w.r.t. x_in on exit."""
+    rows, C = x_in.shape
+    a = blk.attn
+    H = a.num_heads
+    dev = dx.device
+    # ---- recompute the attention half
+    h1 = torch.empty((rows, C), dtype=P.dtype, device=dev)
+    ops.layernorm(x_in, P.vec(blk.norm1.weight), P.vec(blk.norm1.bias), blk.norm1.eps, h1)
+    qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=dev)
+    ops.gemm(h1, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
+    qw, kw = a._qk_w(P)
+    sp = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, H, P.dtype,
+                       q_scale=ops.Q_PRESCALE, train=True)
+    o = torch.empty((rows, C), dtype=P.dtype, device=dev)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=dev)
+    ops.attention(sp["Q"], sp["K"], sp["Vt"], o, prescaled=True, lse=lse)
+    x_mid = torch.empty((rows, C), dtype=torch.float32, device=dev)
+    ops.gemm(o, P.mat(a.fc.weight), x_mid, bias=P.vec(a.fc.bias), residual=x_in)
+    # ---- MLP half
+    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx)                     # dx = d x_mid
+    # ---- attention half
+    dxT = ops.cast(dx, P.dtype)
+    do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)
+    D = ops.attention_delta(o, do, B, H, L)
+    dO_hm = ops.qkv_split(do, None, None, None, None, 0.0, B, L, H, P.dtype)[0]
+    dQ, dK, dV = ops.attention_bwd(sp["Q"], sp["K"], sp["V"], dO_hm, lse, D)
+    dqkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=dev)
+    dqw, dkw = ops.qkv_split_bwd(dQ, dK, dV, qkv[:, :C], qkv[:, C:2 * C], qw, kw, RMS_EPS, B, L, H, dqkv[:, :C],
+                                 dqkv[:, C:2 * C], dqkv[:, 2 * C:])
+    if a.use_qk_norm:
+        G.add(a.q_norm.weight, dqw)
+        G.add(a.k_norm.weight, dkw)
+    dh1 = linear_bwd(P, G, a.to_qkv.weight, a.to_qkv.bias, h1, dqkv)
+    dw, db = ops.layernorm_bwd(x_in, P.vec(blk.norm1.weight), blk.norm1.eps, dh1, dx, accumulate=True)
+    G.add(blk.norm1.weight, dw)
+    G.add(blk.norm1.bias, db)
+
+
+def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv: torch.Tensor, dx: torch.Tensor, B: int,
+                         Lq: int, Lk: int, kv_row_map=(0, 0, 0), shared_q: bool = False, d_kv: Optional[torch.Tensor] = None,
+                         need_dquery: bool = True) -> Optional[torch.Tensor]:
+    """Backward of QK_Norm_CrossAttentionBlock (project_q + project_kv + attend).
+
+    query fp32 [Bq*Lq, C] (Bq = 1 when shared_q: one query set for all B key/value batches, the decoder case);
+    kv fp32 rows read through kv_row_map; dx fp32 [B*Lq, C] = grad w.r.t. the block output (consumed).
+    d_kv: fp32 buffer shaped like kv that receives (+=) the gradient of the key/value rows (None: not needed).
+    Returns the gradient w.r.t. query (fp32 [Bq*Lq, C]) or None."""
+    a = blk.attn
+    C, H = a.dim, a.num_heads
+    dev = dx.device
+    Bq = 1 if shared_q else B
+    # ---- recompute
+    qn = torch.empty((Bq * Lq, C), dtype=P.dtype, device=dev)
+    ops.layernorm(query, P.vec(blk.norm_q.weight), P.vec(blk.norm_q.bias), blk.norm_q.eps, qn)
+    qp = torch.empty((Bq * Lq, C), dtype=P.dtype, device=dev)
+    ops.gemm(qn, P.mat(a.to_q.weight), qp, bias=P.vec(a.to_q.bias))
+    qw, kw = a._qk_w(P)
+    spq = ops.qkv_split(qp, None, None, qw, None, RMS_EPS, Bq, Lq, H, P.dtype, q_scale=ops.Q_PRESCALE, train=True)
+    kn = torch.empty((B * Lk, C), dtype=P.dtype, device=dev)
+    ops.layernorm(kv, P.vec(blk.norm_kv.weight), P.vec(blk.norm_kv.bias), blk.norm_kv.eps, kn, row_map=kv_row_map)
+    w_kv, b_kv = P.cat_rows((a.to_k.weight, a.to_v.weight)), P.cat_vecs((a.to_k.bias, a.to_v.bias))
+    kvp = torch.empty((B * Lk, 2 * C), dtype=P.dtype, device=dev)
+    ops.gemm(kn, w_kv, kvp, bias=b_kv)
+    spk = ops.qkv_split(None, kvp[:, :C], kvp[:, C:], None, kw, RMS_EPS, B, Lk, H, P.dtype, train=True)
+    o = torch.empty((B * Lq, C), dtype=P.dtype, device=dev)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev)
+    ops.attention(spq["Q"], spk["K"], spk["Vt"], o, shared_q=shared_q, prescaled=True, lse=lse)
+    x_mid = torch.empty((B * Lq, C), dtype=torch.float32, device=dev)
+    ops.gemm(o, P.mat(a.fc.weight), x_mid, bias=P.vec(a.fc.bias), residual=query, res_rows=Lq if shared_q else 0)
+    # ---- MLP half
+    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx)                     # dx = d x_mid  [B*Lq, C]
+    # ---- attention half
+    dxT = ops.cast(dx, P.dtype)
+    do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)
+    D = ops.attention_delta(o, do, B, H, Lq)
+    dO_hm = ops.qkv_split(do, None, None, None, None, 0.0, B, Lq, H, P.dtype)[0]
+    dQ, dK, dV = ops.attention_bwd(spq["Q"], spk["K"], spk["V"], dO_hm, lse, D, shared_q=shared_q)
+    # key / value path
+    dkvp = torch.empty((B * Lk, 2 * C), dtype=P.dtype, device=dev)
+    _, dkw = ops.qkv_split_bwd(None, dK, dV, None, kvp[:, :C], None, kw, RMS_EPS, B, Lk, H, None, dkvp[:, :C], dkvp[:, C:])
+    if a.use_qk_norm:
+        G.add(a.k_norm.weight, dkw)
+    if a.to_k.bias is not None:
+        bsum = ops.colsum(dkvp)
+        G.add(a.to_k.bias, bsum[:C])
+        G.add(a.to_v.bias, bsum[C:])
+    dYt, At = ops.transpose(dkvp), ops.transpose(kn)
+    dWkv = torch.empty((2 * C, C), dtype=torch.float32, device=dev)
+    ops.gemm(dYt, At, dWkv)
+    G.add(a.to_k.weight, dWkv[:C])
+    G.add(a.to_v.weight, dWkv[C:])
+    if d_kv is not None:
+        Wt = P.derived("catT", (a.to_k.weight, a.to_v.weight), lambda: ops.transpose(w_kv))      # [C, 2C]
+        dkn = torch.empty((B * Lk, C), dtype=P.dtype, device=dev)
+        ops.gemm(dkvp, Wt, dkn)
+        dw, db = ops.layernorm_bwd(kv, P.vec(blk.norm_kv.weight), blk.norm_kv.eps, dkn, d_kv, accumulate=True,
+                                   row_map=kv_row_map)
+    else:
+        # the weight gradient of norm_kv is still needed even when the kv rows themselves are inputs
+        Wt = P.derived("catT", (a.to_k.weight, a.to_v.weight), lambda: ops.transpose(w_kv))
+        dkn = torch.empty((B * Lk, C), dtype=P.dtype, device=dev)
+        ops.gemm(dkvp, Wt, dkn)
+        scratch = torch.empty_like(kv)
+        dw, db = ops.layernorm_bwd(kv, P.vec(blk.norm_kv.weight), blk.norm_kv.eps, dkn, scratch, accumulate=False,
+                                   row_map=kv_row_map)
+    G.add(blk.norm_kv.weight, dw)
+    G.add(blk.norm_kv.bias, db)
+    # query path
+    dQs = dQ
+    if shared_q:                                              # one query set: sum the per-batch gradients
+        dQs = ops.colsum(dQ.reshape(B, -1)).to(P.dtype).reshape(1, H, Lq, 64)
+    dqp = torch.empty((Bq * Lq, C), dtype=P.dtype, device=dev)
+    dqw, _ = ops.qkv_split_bwd(dQs, None, None, qp, None, qw, None, RMS_EPS, Bq, Lq, H, dqp, None, None)
+    if a.use_qk_norm:
+        G.add(a.q_norm.weight, dqw)
+    dqn = linear_bwd(P, G, a.to_q.weight, a.to_q.bias, qn, dqp)
+    # residual: x_mid = query (broadcast over B when shared) + fc(o)
+    if shared_q:
+        dquery = ops.colsum(dx.reshape(B, -1)).reshape(Lq, C).contiguous()
+    else:
+        dquery = dx
+    dw, db = ops.layernorm_bwd(query, P.vec(blk.norm_q.weight), blk.norm_q.eps, dqn, dquery, accumulate=True)
+    G.add(blk.norm_q.weight, dw)
+    G.add(blk.norm_q.bias, db)
+    return dquery if need_dquery else None

@@ -199,3 +199,78 @@ def test_adamw_matches_torch_and_grad_norm():
     clean = torch.nan_to_num(gg, nan=0.0, posinf=1e-6, neginf=-1e-6)
     assert torch.equal(gd.cpu(), clean)
     assert abs(float(out) - float((clean.double() ** 2).sum())) < 1e-3
+
+
+def _autograd_block(kind, sd, x, *args):
+    from oracle import ref_forward as oracle
+    sdd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    xs = [a.double().requires_grad_(True) for a in (x,) + args]
+    out = (oracle.self_attn_block(sdd, "b", xs[0], 64) if kind == "self"
+           else oracle.cross_attn_block(sdd, "b", xs[0], xs[1], 64))
+    return out, sdd, xs
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_self_attn_block_backward_vs_oracle_autograd(dtype):
+    from motion324_amd import backward as bw
+    from motion324_amd.prepared import Prepared
+    from motion324_amd.transformer import QK_Norm_TransformerBlock
+    torch.manual_seed(1)
+    B, L, C = 2, 75, 192
+    blk = QK_Norm_TransformerBlock(C, 64)
+    with torch.no_grad():
+        for n_, p in blk.named_parameters():
+            p.copy_(1 + 0.1 * torch.randn_like(p) if p.dim() == 1 else 0.05 * torch.randn_like(p))
+    x = _rand((B, L, C), 31)
+    dout = _rand((B, L, C), 32)
+    sd = {"b." + k: v.detach() for k, v in blk.state_dict().items()}
+    out, sdd, xs = _autograd_block("self", sd, x)
+    out.backward(dout.double())
+    blk = blk.to(DEV)
+    P = Prepared.for_module(blk, torch.device(DEV), dtype)
+    G = bw.GradStore()
+    dx = dout.reshape(B * L, C).clone().to(DEV)
+    bw.self_attn_block_bwd(blk, P, G, x.reshape(B * L, C).to(DEV), dx, B, L)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(dx, xs[0].grad.reshape(B * L, C)) < tol
+    for name, p in blk.named_parameters():
+        g = G.get(p)
+        assert g is not None, name
+        assert rel_err(g, sdd["b." + name].grad) < tol, (name, rel_err(g, sdd["b." + name].grad))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shared", [False, True])
+def test_cross_attn_block_backward_vs_oracle_autograd(dtype, shared):
+    from motion324_amd import backward as bw
+    from motion324_amd.prepared import Prepared
+    from motion324_amd.transformer import QK_Norm_CrossAttentionBlock
+    torch.manual_seed(2)
+    B, Lq, Lk, C = 3, 50, 64, 192
+    blk = QK_Norm_CrossAttentionBlock(C, 64, kv_dim=C)
+    with torch.no_grad():
+        for n_, p in blk.named_parameters():
+            p.copy_(1 + 0.1 * torch.randn_like(p) if p.dim() == 1 else 0.05 * torch.randn_like(p))
+    q = _rand((1 if shared else B, Lq, C), 33)
+    kv = _rand((B, Lk, C), 34)
+    dout = _rand((B, Lq, C), 35)
+    sd = {"b." + k: v.detach() for k, v in blk.state_dict().items()}
+    from oracle import ref_forward as oracle
+    sdd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    out = oracle.cross_attn_block(sdd, "b", qd.expand(B, -1, -1), kvd, 64)
+    out.backward(dout.double())
+    blk = blk.to(DEV)
+    P = Prepared.for_module(blk, torch.device(DEV), dtype)
+    G = bw.GradStore()
+    dx = dout.reshape(B * Lq, C).clone().to(DEV)
+    d_kv = torch.zeros((B * Lk, C), device=DEV)
+    dquery = bw.cross_attn_block_bwd(blk, P, G, q.reshape(-1, C).to(DEV), kv.reshape(-1, C).to(DEV), dx, B, Lq, Lk,
+                                     shared_q=shared, d_kv=d_kv)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(dquery, qd.grad.reshape(-1, C)) < tol
+    assert rel_err(d_kv, kvd.grad.reshape(-1, C)) < tol
+    for name, p in blk.named_parameters():
+        g = G.get(p)
+        assert g is not None, name
+        assert rel_err(g, sdd["b." + name].grad) < tol, (name, rel_err(g, sdd["b." + name].grad))
