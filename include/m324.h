@@ -143,7 +143,8 @@ int m324_dino_cls_rows(const float* cls, const float* pos0, float* x, int F, int
  *   replaces: DINOv2 final norm + CLS drop (model_dino.py:645, dinov2.py:99-103), pos-embed add
  *             (model/Pcd_motion.py:477-493), token stacking (:495-507) and transformer_input_layernorm (:509).
  *   dino_x [B*T, 1+P, C] fp32 (pre final-norm); dino_w/dino_b final-norm affine, eps_dino (1e-6);
- *   pos [T*P, C]; sp0/spr [4,C]; mesh [B,K,C]; ln_w [C], eps_in (1e-5).
+ *   pos [T*P, C]; sp0/spr [4,C]; mesh [B,K,C]; ln_w [C], eps_in (1e-5).  ln_w == NULL: the un-normalised
+ *   concatenation is written instead (needed by the backward of transformer_input_layernorm).
  * ------------------------------------------------------------------------------------------ */
 int m324_assemble_tokens(const float* dino_x, const float* dino_w, const float* dino_b, float eps_dino,
                          const float* pos, const float* sp0, const float* spr, const float* mesh,

@@ -258,9 +258,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
             v[i].w = (v[i].w - mean) * rstd * ww.w + bb.w + pp.w;
         }
     }
+    float* o = out + row * C;
+    if (!lw) {   // training: the un-normalised concatenation is needed by the input-LayerNorm backward
+        LN_FOR(i, c) *reinterpret_cast<float4*>(o + c) = v[i];
+        return;
+    }
     float mean, rstd;
     row_stats(v, lane, C, eps_in, mean, rstd);
-    float* o = out + row * C;
     LN_FOR(i, c) {
         float4 ww = *reinterpret_cast<const float4*>(lw + c);
         *reinterpret_cast<float4*>(o + c) = make_float4((v[i].x - mean) * rstd * ww.x, (v[i].y - mean) * rstd * ww.y,
@@ -560,7 +564,7 @@ extern "C" int m324_assemble_tokens(const float* dino_x, const float* dino_w, co
                                     const float* pos, const float* sp0, const float* spr, const float* mesh,
                                     const float* ln_w, float eps_in, float* out, int B, int T, int K, int P, int C,
                                     void* stream) {
-    M324_REQUIRE(dino_x && dino_w && dino_b && pos && sp0 && spr && mesh && ln_w && out, "m324_assemble_tokens: null pointer");
+    M324_REQUIRE(dino_x && dino_w && dino_b && pos && sp0 && spr && mesh && out, "m324_assemble_tokens: null pointer");
     M324_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV, "m324_assemble_tokens: C=%d unsupported", C);
     const long rows = (long)B * T * (4 + K + P);
     hipLaunchKernelGGL(assemble_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, dino_x, dino_w, dino_b,

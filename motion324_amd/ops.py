@@ -224,7 +224,7 @@ def assemble_tokens(dino_x, dino_w, dino_b, eps_dino, pos, sp0, spr, mesh, ln_w,
             raise L.M324Error(f"assemble_tokens: {name} {t.dtype}{tuple(t.shape)} (want {n} fp32)")
     out = torch.empty((B * T * (4 + K + P), Cdim), dtype=torch.float32, device=dino_x.device)
     L.check(L.load().m324_assemble_tokens(_p(dino_x), _vec(dino_w, Cdim, "dino_w"), _vec(dino_b, Cdim, "dino_b"), eps_dino,
-                                          _p(pos), _p(sp0), _p(spr), _p(mesh), _vec(ln_w, Cdim, "ln_w"), eps_in, _p(out),
+                                          _p(pos), _p(sp0), _p(spr), _p(mesh), _vec(ln_w, Cdim, "ln_w") if ln_w is not None else None, eps_in, _p(out),
                                           B, T, K, P, Cdim, _stream()), "m324_assemble_tokens")
     return out
 

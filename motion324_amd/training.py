@@ -1,0 +1,172 @@
+"""Training step of Motion_Latent_Model on libm324 kernels: forward with per-block checkpoints, hand-written
+backward (motion324_amd.backward), loss, and the optimizer / gradient plumbing of the reference's train.py:135-219.
+
+`forward_backward(model, sample)` runs the forward (training semantics: DINOv2 frozen and in eval mode, dropout on
+video tokens must be 0), keeps only the residual stream at block boundaries (the reference checkpoints every
+block / block pair, Pcd_motion.py:375-448) and immediately back-propagates d loss / d params, recomputing block
+internals.  No torch autograd graph is built; `Motion_Latent_Model.forward` wraps this in an autograd.Function so that
+`loss.backward()` of the reference's train.py delivers the same gradients to `.grad` (and to DDP's hooks).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import backward as bw
+from . import ops
+from .image_encoder import DINO_EPS
+from .lib import ACT_GELU, M324Error
+from .prepared import Prepared, compute_dtype, pad_k
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _point_features_train(model, P: Prepared, xyz, normal, rgb):
+    """As Motion_Latent_Model._point_features, also returning the two GEMM inputs needed by the weight gradients."""
+    C = model.embed_dim
+    enc = ops.point_encode(xyz, P.dtype)
+    feat = torch.empty((xyz.shape[0], pad_k(C + 6)), dtype=P.dtype, device=xyz.device)
+    ops.gemm(enc, P.mat(model.point_embed.mlp.weight), feat, bias=P.vec(model.point_embed.mlp.bias))
+    ops.point_concat(normal, rgb, feat, C)
+    out = torch.empty((xyz.shape[0], C), dtype=torch.float32, device=xyz.device)
+    ops.gemm(feat, P.mat(model.point_normal_rgb_proj.weight), out, bias=P.vec(model.point_normal_rgb_proj.bias))
+    return out, enc, feat
+
+
+def _point_features_bwd(model, P: Prepared, G: bw.GradStore, enc, feat, d_pf: torch.Tensor) -> None:
+    """d_pf fp32 [n, C]: gradient of the point features -> weight / bias gradients of the two projections."""
+    C = model.embed_dim
+    dfeat = bw.linear_bwd(P, G, model.point_normal_rgb_proj.weight, model.point_normal_rgb_proj.bias, feat,
+                          ops.cast(d_pf, P.dtype))
+    demb = ops.cast(dfeat[:, :C], P.dtype)                     # contiguous copy of the embedding columns
+    bw.linear_bwd(P, G, model.point_embed.mlp.weight, model.point_embed.mlp.bias, enc, demb, need_da=False)
+
+
+def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0
+                     ) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
+    """Returns (loss [0-dim fp32], pcd_moved [B,T,N,3] fp32, GradStore with d(grad_scale * loss)/d param)."""
+    if "point_clouds" not in sample:
+        raise M324Error("training step needs sample['point_clouds'] (the regression target)")
+    if model.drop_rate > 0.0:
+        raise NotImplementedError("training-mode dropout on video tokens (drop_rate > 0) is not implemented; "
+                                  "set model.video_encoder.transformer.drop_rate=0")
+    ref_pcd = sample["ref_pcd"]
+    dev = ref_pcd.device
+    if dev.type != "cuda":
+        raise M324Error("the training step runs only on a HIP device")
+    P = Prepared.for_module(model, dev, compute_dtype())
+    G = bw.GradStore()
+    B, N, _ = ref_pcd.shape
+    C, K = model.embed_dim, model.num_learnable_tokens
+    S = sample["ref_shape_pcd"].shape[1]
+    T = sample["rgb_video"].shape[1]
+    Pn = model.num_patches_h * model.num_patches_w
+    Lt = 4 + K + Pn
+    weight = float(model.loss_computer._weight)
+
+    # ================================================================ forward (block inputs kept)
+    pts, enc_s, feat_s = _point_features_train(model, P, _f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
+                                               _f32c(sample["ref_shape_normals"]), _f32c(sample["ref_shape_rgbs"]))
+    query = P.f32(model.learnable_tokens).reshape(K, C).repeat(B, 1)
+    mesh = model.encoder_cross_attn.run(P, query, pts, B, K, S)
+    mesh_in = []
+    for blk in model.points_transformer_blocks:
+        mesh_in.append(mesh.clone())
+        blk.run(P, mesh, B, K)
+
+    video = _f32c(sample["rgb_video"])
+    _, _, Hin, Win, _ = video.shape
+    dino_x = model.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))            # frozen: no gradient
+    enc_m = model.image_encoder.model
+    pos = model._video_pos(P, T)
+    sp0, spr = P.f32(model.special_token_0).reshape(4, C), P.f32(model.special_token_rest).reshape(4, C)
+    ln_in = model.transformer_input_layernorm
+    tok = ops.assemble_tokens(dino_x, P.vec(enc_m.norm.weight), P.vec(enc_m.norm.bias), DINO_EPS, pos, sp0, spr, mesh,
+                              P.vec(ln_in.weight), ln_in.eps, B, T, K, Pn)
+    trunk_in = []
+    for gblk, lblk in zip(model.global_transformer_blocks, model.local_transformer_blocks):
+        trunk_in.append(tok.clone())
+        gblk.run(P, tok, B, T * Lt)
+        trunk_in.append(tok.clone())
+        lblk.run(P, tok, B * T, Lt)
+
+    dec = model.decoder_cross_attn
+    head_ln, head_fc1, head_fc2 = model.shared_mlp_output[0], model.shared_mlp_output[1], model.shared_mlp_output[3]
+    w3, b3 = P.f32(head_fc2.weight), P.vec(head_fc2.bias)
+    out = torch.empty((B, T, N, 3), dtype=torch.float32, device=dev)
+    pcd, nrm, rgb = (_f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
+    dec_saved = []
+    for b in range(B):
+        pf, enc_p, feat_p = _point_features_train(model, P, pcd[b], nrm[b].contiguous(), rgb[b].contiguous())
+        tok_b = tok[b * T * Lt:(b + 1) * T * Lt]
+        Q = dec.project_q(P, pf, 1, N)
+        Kd, Vd = dec.project_kv(P, tok_b, T, K, row_map=(K, Lt, 4))
+        x = dec.attend(P, Q, Kd, Vd, pf, N, shared_q=True)                            # fp32 [T*N, C]
+        h = torch.empty(x.shape, dtype=P.dtype, device=dev)
+        ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
+        h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
+        ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
+        ops.linear_n3(h2, w3, b3, out[b])
+        dec_saved.append((pf, enc_p, feat_p, x))
+    target = _f32c(sample["point_clouds"])
+    mse = ops.mse(out, target, 1.0)
+    loss = mse * weight
+
+    # ================================================================ backward
+    d_out = ops.mse_bwd(out, target, weight * grad_scale)                             # [B,T,N,3]
+    d_tok = torch.zeros((B * T * Lt, C), dtype=torch.float32, device=dev)
+    for b in range(B):
+        pf, enc_p, feat_p, x = dec_saved[b]
+        tok_b = tok[b * T * Lt:(b + 1) * T * Lt]
+        # head: LN -> Linear -> GELU -> Linear(3)
+        h = torch.empty(x.shape, dtype=P.dtype, device=dev)
+        ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
+        z2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
+        ops.gemm(h, P.mat(head_fc1.weight), z2, bias=P.vec(head_fc1.bias))
+        h2 = ops.gelu(z2)
+        dh2, dW3, db3 = ops.linear_n3_bwd(h2, w3, d_out[b])
+        G.add(head_fc2.weight, dW3)
+        G.add(head_fc2.bias, db3)
+        dz2 = ops.gelu_bwd(z2, dh2)
+        dh = bw.linear_bwd(P, G, head_fc1.weight, head_fc1.bias, h, dz2)
+        dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        dw, db = ops.layernorm_bwd(x, P.vec(head_ln.weight), head_ln.eps, dh, dx, accumulate=False)
+        G.add(head_ln.weight, dw)
+        G.add(head_ln.bias, db)
+        d_pf = bw.cross_attn_block_bwd(dec, P, G, pf, tok_b, dx, T, N, K, kv_row_map=(K, Lt, 4), shared_q=True,
+                                       d_kv=d_tok[b * T * Lt:(b + 1) * T * Lt])
+        _point_features_bwd(model, P, G, enc_p, feat_p, d_pf)
+        dec_saved[b] = None
+
+    n_pairs = len(model.global_transformer_blocks)
+    for i in reversed(range(n_pairs)):
+        bw.self_attn_block_bwd(model.local_transformer_blocks[i], P, G, trunk_in[2 * i + 1], d_tok, B * T, Lt)
+        bw.self_attn_block_bwd(model.global_transformer_blocks[i], P, G, trunk_in[2 * i], d_tok, B, T * Lt)
+        trunk_in[2 * i + 1] = trunk_in[2 * i] = None
+
+    # token assembly + input LayerNorm: recompute the un-normalised concatenation, LN backward over every row (the LN
+    # weight sees the video rows too), then fold the rows that carry parameters / the mesh latents
+    pre = ops.assemble_tokens(dino_x, P.vec(enc_m.norm.weight), P.vec(enc_m.norm.bias), DINO_EPS, pos, sp0, spr, mesh,
+                              None, ln_in.eps, B, T, K, Pn)
+    d_pre = torch.empty_like(pre)
+    dw, _ = ops.layernorm_bwd(pre, P.vec(ln_in.weight), ln_in.eps, d_tok, d_pre, accumulate=False)
+    G.add(ln_in.weight, dw)
+    d4 = d_pre.reshape(B, T, Lt, C)
+    G.add(model.special_token_0, ops.colsum(d4[:, 0, :4].reshape(B, 4 * C).contiguous()).reshape(1, 4, C))
+    if T > 1:
+        G.add(model.special_token_rest,
+              ops.colsum(d4[:, 1:, :4].reshape(B * (T - 1), 4 * C).contiguous()).reshape(1, 4, C))
+    d_mesh = torch.empty((B * K, C), dtype=torch.float32, device=dev)
+    for b in range(B):
+        d_mesh[b * K:(b + 1) * K] = ops.colsum(d4[b, :, 4:4 + K].reshape(T, K * C).contiguous()).reshape(K, C)
+
+    for i in reversed(range(len(model.points_transformer_blocks))):
+        bw.self_attn_block_bwd(model.points_transformer_blocks[i], P, G, mesh_in[i], d_mesh, B, K)
+    d_pts = torch.zeros((B * S, C), dtype=torch.float32, device=dev)
+    d_query = bw.cross_attn_block_bwd(model.encoder_cross_attn, P, G, query, pts, d_mesh, B, K, S, d_kv=d_pts)
+    G.add(model.learnable_tokens, ops.colsum(d_query.reshape(B, K * C)).reshape(1, K, C))
+    _point_features_bwd(model, P, G, enc_s, feat_s, d_pts)
+    return loss, out, G
