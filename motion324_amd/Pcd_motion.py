@@ -70,6 +70,25 @@ def resize_pos_embed(posemb, src_shape, target_shape):
     return posemb.permute(0, 2, 3, 4, 1).reshape(1, target_shape[0] * target_shape[1] * target_shape[2], -1)
 
 
+class _TrainStepFunction(torch.autograd.Function):
+    """loss, pcd_moved = f(params): forward AND backward are computed in forward() by libm324 kernels; backward()
+    only scales the stored gradients by d(loss)."""
+
+    @staticmethod
+    def forward(ctx, model, sample, *params):
+        from . import training
+        loss, out, G = training.forward_backward(model, sample)
+        ctx.grads = [G.get(p) for p in params]
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, dloss, dout):
+        grads = tuple(None if g is None else g * dloss for g in ctx.grads)
+        ctx.grads = None
+        return (None, None) + grads
+
+
 class Motion_Latent_Model(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -169,7 +188,23 @@ class Motion_Latent_Model(nn.Module):
         return t.detach().to(torch.float32).contiguous()
 
     def forward(self, sample: Dict[str, torch.Tensor]):
+        if self.training and torch.is_grad_enabled() and "point_clouds" in sample \
+                and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(sample)
         return self._forward(sample, None)
+
+    def _forward_train(self, sample: Dict[str, torch.Tensor]):
+        """Training forward (the reference's train.py:150-166 calls model(batch) then loss.backward()).  The HIP
+        forward+backward runs eagerly (motion324_amd.training.forward_backward); `loss` is returned through an
+        autograd.Function whose backward hands the already-computed gradients (times the incoming scalar) to autograd,
+        so `.grad`, GradScaler, clip_grad_norm_ and DDP's reducer hooks all behave as with the reference model."""
+        from . import training
+        params = [p for p in self.parameters() if p.requires_grad]
+        loss, out = _TrainStepFunction.apply(self, sample, *params)
+        lm = edict()
+        lm.loss = loss
+        lm.xyz_loss = loss.detach() / max(float(self.loss_computer._weight), 1e-30)
+        return edict(input_data=sample, pcd_moved=out, loss_metrics=lm)
 
     def forward_frame_parallel(self, sample: Dict[str, torch.Tensor], group=None):
         """One long clip, frames sharded over the ranks of `group` with EXACT single-GPU semantics
@@ -188,12 +223,6 @@ class Motion_Latent_Model(nn.Module):
         if dev.type != "cuda":
             raise M324Error("motion324_amd.Motion_Latent_Model runs only on a HIP device (model.to('cuda'), inputs on "
                             "'cuda'); there is no CPU fallback on this path")
-        if self.training and self.drop_rate > 0.0:
-            raise NotImplementedError("training-mode dropout on video tokens (drop_rate > 0) is not implemented yet; "
-                                      "set model.video_encoder.transformer.drop_rate=0")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("backward through the HIP path is not implemented yet (inference only): "
-                                      "call under torch.no_grad() / model.eval()")
         P = Prepared.for_module(self, dev, compute_dtype())
         cap = getattr(self, "_capture", None)      # tests: dict that receives clones of stage activations
         B, N, _ = ref_pcd.shape

@@ -38,6 +38,16 @@ def compute_dtype() -> torch.dtype:
     return torch.float32
 
 
+_GENERATION = 0
+
+
+def bump_generation() -> None:
+    """Invalidates every cached kernel-ready copy.  Call after updating parameters through raw pointers (the fused
+    AdamW kernel writes parameter memory without touching torch's version counters)."""
+    global _GENERATION
+    _GENERATION += 1
+
+
 def pad_k(k: int) -> int:
     return (k + K_ALIGN - 1) // K_ALIGN * K_ALIGN
 
@@ -61,7 +71,7 @@ class Prepared:
 
     @staticmethod
     def _stamp(ps: Sequence[torch.Tensor]) -> tuple:
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        return (_GENERATION,) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def _get(self, kind: str, ps: Sequence[torch.Tensor], make):
         key = (kind,) + tuple(id(p) for p in ps)

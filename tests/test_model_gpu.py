@@ -260,3 +260,62 @@ def test_training_gradients_match_oracle_autograd(precision, tol):
     print(f"[train grads {precision}] worst: " + "  ".join(f"{k}={v:.2e}" for k, v in worst))
     assert len(errs) == sum(1 for k, v in sd.items() if v.requires_grad)
     assert worst[0][1] < tol, worst
+
+
+def test_autograd_wrapper_and_three_optimizer_steps_match_torch_on_oracle():
+    """(1) model(sample).loss_metrics.loss.backward() fills .grad exactly like forward_backward;
+    (2) three FusedAdamW steps (clip 1.0, decay on dim()>1 only) track torch.optim.AdamW driven by oracle autograd."""
+    import motion324_amd as m
+    from motion324_amd import synth
+    from motion324_amd.optim import FusedAdamW
+    from oracle import ref_forward as oracle
+    model, dm = build("tiny")
+    model.train()
+    B, T, N, S, HW = 1, 3, 30, 80, 64
+    s_np = synth.synth_inputs(B, T, N, S, HW, seed=2, with_target=True)
+    sample = {k: torch.from_numpy(v).cuda() for k, v in s_np.items()}
+    # reference: oracle + torch AdamW on CPU (fp64 params would hide fp32 rounding: keep fp32 like the reference)
+    sd = {k: torch.from_numpy(v).clone() for k, v in synth_sd(CASES["tiny"]["dims"]).items()}
+    train_keys = [k for k in sd if not k.startswith("image_encoder.")]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    decay = [sd[k] for k in train_keys if sd[k].dim() > 1]
+    no_decay = [sd[k] for k in train_keys if sd[k].dim() <= 1]
+    ropt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}],
+                             lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    m.set_precision("fp32")
+    try:
+        # (1) autograd wrapper
+        ret = model(sample)
+        assert isinstance(ret, dict) and ret.loss_metrics.loss.requires_grad
+        ret.loss_metrics.loss.backward()
+        from motion324_amd import training
+        _, _, G = training.forward_backward(model, sample)
+        for name, p in model.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None and torch.allclose(p.grad, G.get(p), rtol=1e-5, atol=1e-9), name
+        model.zero_grad(set_to_none=True)
+        # (2) optimizer trajectory
+        opt = FusedAdamW(model.named_parameters(), lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05,
+                         grad_clip_norm=1.0, allowed_gradnorm_factor=1e9)
+        losses, ref_losses = [], []
+        for step in range(3):
+            ref = oracle.forward(sd, oracle.to_torch(s_np), frames=dm.frames)
+            ropt.zero_grad()
+            ref["loss"].backward()
+            torch.nn.utils.clip_grad_norm_([sd[k] for k in train_keys], 1.0)
+            ropt.step()
+            ref_losses.append(float(ref["loss"]))
+            loss, _, G = training.forward_backward(model, sample)
+            opt.load_grads(G)
+            info = opt.step()
+            assert not info["skipped"]
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+    finally:
+        m.set_precision(None)
+    assert all(abs(a - b) <= 1e-4 * abs(b) for a, b in zip(losses, ref_losses)), (losses, ref_losses)
+    got = dict(model.named_parameters())
+    worst = max(rel_err(got[k].detach(), sd[k].detach()) for k in train_keys)
+    assert worst < 1e-4, worst
+    assert losses[2] < losses[0]
