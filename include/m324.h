@@ -208,6 +208,12 @@ int m324_attention_delta(const void* O, const void* dO, long ld, float* D, int B
 int m324_attention_bwd(const void* Qs, long q_bstride, const void* K, const void* V, const void* dO, const float* lse,
                        const float* D, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, float scale,
                        int dtype, void* stream);
+/* bf16 MFMA implementation of the same backward (two kernels: dQ per query block, dK/dV per key block, both
+ * recomputing the scores).  Besides the row-major operands it takes the transposed, permuted copies m324_qkv_split
+ * emits: Qst [Bq,H,64,Lqp], Kt [B,H,64,Lkp], dOt [B,H,64,Lqp] (qt_bstride / q_bstride = 0 for a shared query set). */
+int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_bstride, long qt_bstride, const void* K, const void* Kt,
+                            const void* V, const void* dO, const void* dOt, const float* lse, const float* D,
+                            void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, float scale, void* stream);
 /* Backward of m324_qkv_split: head-major dQ/dK/dV -> token-major gradients of the projections (RMSNorm backward for
  * q, k when q_w / k_w are given; raw projections needed).  partial [n_partial][128]: per-block sums of the q_norm | k_norm
  * weight gradients, reduce with m324_colsum. */

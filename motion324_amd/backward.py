@@ -42,6 +42,15 @@ class GradStore:
         return self.grads.get(id(param))
 
 
+def _attention_bwd(P: Prepared, spq: dict, spk: dict, do: torch.Tensor, lse, D, B: int, Lq: int, H: int, shared_q: bool):
+    """bf16: MFMA kernels on the row-major + transposed operand copies; fp32 parity mode: the fp32-arithmetic kernels."""
+    if P.dtype == torch.bfloat16:
+        spdo = ops.qkv_split(do, None, None, None, None, 0.0, B, Lq, H, P.dtype, train=True)
+        return ops.attention_bwd_mfma(spq, spk, spdo, lse, D, shared_q=shared_q)
+    dO_hm = ops.qkv_split(do, None, None, None, None, 0.0, B, Lq, H, P.dtype)[0]
+    return ops.attention_bwd(spq["Q"], spk["K"], spk["V"], dO_hm, lse, D, shared_q=shared_q)
+
+
 def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
     """[K', N_pad] transposed GEMM operand of a weight (for dgrad), cached like P.mat."""
     return P.derived("matT", (weight,), lambda: ops.transpose(P.mat(weight)))
@@ -111,8 +120,7 @@ def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: 
     dxT = ops.cast(dx, P.dtype)
     do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)
     D = ops.attention_delta(o, do, B, H, L)
-    dO_hm = ops.qkv_split(do, None, None, None, None, 0.0, B, L, H, P.dtype)[0]
-    dQ, dK, dV = ops.attention_bwd(sp["Q"], sp["K"], sp["V"], dO_hm, lse, D)
+    dQ, dK, dV = _attention_bwd(P, sp, sp, do, lse, D, B, L, H, shared_q=False)
     dqkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=dev)
     dqw, dkw = ops.qkv_split_bwd(dQ, dK, dV, qkv[:, :C], qkv[:, C:2 * C], qw, kw, RMS_EPS, B, L, H, dqkv[:, :C],
                                  dqkv[:, C:2 * C], dqkv[:, 2 * C:])
@@ -162,8 +170,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
     dxT = ops.cast(dx, P.dtype)
     do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)
     D = ops.attention_delta(o, do, B, H, Lq)
-    dO_hm = ops.qkv_split(do, None, None, None, None, 0.0, B, Lq, H, P.dtype)[0]
-    dQ, dK, dV = ops.attention_bwd(spq["Q"], spk["K"], spk["V"], dO_hm, lse, D, shared_q=shared_q)
+    dQ, dK, dV = _attention_bwd(P, spq, spk, do, lse, D, B, Lq, H, shared_q=shared_q)
     # key / value path
     dkvp = torch.empty((B * Lk, 2 * C), dtype=P.dtype, device=dev)
     _, dkw = ops.qkv_split_bwd(None, dK, dV, None, kvp[:, :C], None, kw, RMS_EPS, B, Lk, H, None, dkvp[:, :C], dkvp[:, C:])

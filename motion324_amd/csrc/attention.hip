@@ -247,6 +247,249 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     }
 }
 
+
+// =====================================================================================================
+// Backward (bf16 MFMA).  Same swapped formulation and LDS tile images as the forward:
+//   dQ kernel : a wave owns 32 queries (lane = query), walks the keys:
+//       S^T = K Qs^T, dP^T = V dO^T          (A = K / V rows from LDS, B = Qs / dO rows in registers)
+//       dS^T = exp2(S^T - lse) * (dP^T - D)   (per-lane lse, D)
+//       dQ^T += Kt dS^T                        (A = Kt rows [d][kv] in the permuted key order, B = dS^T registers)
+//   dK/dV kernel : a wave owns 32 keys (lane = key), walks the queries:
+//       S = Qs K^T, dP = dO V^T               (A = Qs / dO rows from LDS, B = K / V rows in registers)
+//       P = exp2(S - lse[q]), dS = P * (dP - D[q])      (lse, D vary along the registers)
+//       dV^T += dOt P, dK^T += Qst dS          (A = dOt / Qst rows [d][q], permuted query order)
+// Every operand is staged by LDS-DMA into XOR-swizzled [64][128 B] tiles; two stages, one barrier per tile.
+// Scale conventions as m324_attention_bwd (include/m324.h): dQ = scale * dS K, dK = ln2 * dS^T Qs.
+__device__ __forceinline__ void dma_rows(unsigned char* part, const bf16_t* src, long row_stride, int row0, int max_row, long col0,
+                                         int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 16 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const bf16_t* g = src + (long)min(row0 + r, max_row) * row_stride + col0 + c * 8;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)g, (lds_ptr_t*)(part + (wave * 16 + i * 8) * 128), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void pack_frags(const f32x16 (&x)[2], bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) pk[r >> 1] = pack_bf16x2(x[kb][r], x[kb][r + 1]);
+        uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        f[kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
+        f[kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __restrict__ Qs, long q_bstride,
+                                                               const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ dO,
+                                                               const float* __restrict__ lse, const float* __restrict__ D,
+                                                               bf16_t* __restrict__ dQ, int H, int Lq, int Lk, int Lkp, float scale) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 3 * 8192];   // [stage][K | V | Kt]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = (blockIdx.x * NW + wave) * QW + l31;
+    const long bh = (long)b * H + h;
+    const bool qok = q < Lq;
+    const bf16_t* Qh = Qs + (long)b * q_bstride + (long)h * Lq * 64;
+    const bf16_t* dOh = dO + bh * (long)Lq * 64;
+    const bf16_t* Kh = K + bh * (long)Lk * 64;
+    const bf16_t* Vh = V + bh * (long)Lk * 64;
+    const bf16_t* Kth = Kt + bh * 64 * (long)Lkp;
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 a = qok ? *reinterpret_cast<const uint4*>(Qh + (long)q * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+        uint4 c = qok ? *reinterpret_cast<const uint4*>(dOh + (long)q * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+        qf[ks] = *reinterpret_cast<bf16x8*>(&a);
+        dof[ks] = *reinterpret_cast<bf16x8*>(&c);
+    }
+    const float l2 = qok ? lse[bh * Lq + q] : 0.f, dl = qok ? D[bh * Lq + q] : 0.f;
+    auto issue = [&](int t) {
+        unsigned char* st = smem + (t & 1) * 24576;
+        dma_rows(st, Kh, 64, t * KV, Lk - 1, 0, wave, lane);
+        dma_rows(st + 8192, Vh, 64, t * KV, Lk - 1, 0, wave, lane);
+        dma_rows(st + 16384, Kth, Lkp, 0, 63, (long)t * KV, wave, lane);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int nt = (Lk + KV - 1) / KV;
+    issue(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1);
+        const unsigned char* sk = smem + (t & 1) * 24576;
+        const unsigned char* sv = sk + 8192;
+        const unsigned char* skt = sk + 16384;
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = -l2, dp[kb][r] = -dl;      // S - lse and dP - D straight from the MFMA
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + k_off(kb * 32 + l31, ks * 2 + hi));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kb], 0, 0, 0);
+            }
+        }
+        const int kv0 = t * KV;
+        const bool ragged = kv0 + KV > Lk;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[kb][r]);
+                if (ragged && kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) p = 0.f;
+                s[kb][r] = p * dp[kb][r];                                         // dS^T
+            }
+        bf16x8 dsf[4];
+        pack_frags(s, dsf);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(skt + k_off(db * 32 + l31, 2 * j + hi));
+                acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[j], acc[db], 0, 0, 0);
+            }
+    }
+    if (qok) {
+        bf16_t* orow = dQ + (bh * Lq + q) * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack_bf16x2(acc[db][g * 4 + 0] * scale, acc[db][g * 4 + 1] * scale);
+                w.y = pack_bf16x2(acc[db][g * 4 + 2] * scale, acc[db][g * 4 + 3] * scale);
+                *reinterpret_cast<uint2*>(orow + db * 32 + g * 8 + hi * 4) = w;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ Qst,
+                                                                long q_bstride, long qt_bstride, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                                const bf16_t* __restrict__ dOt, const float* __restrict__ lse,
+                                                                const float* __restrict__ D, bf16_t* __restrict__ dK,
+                                                                bf16_t* __restrict__ dV, int H, int Lq, int Lk, int Lqp) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * 8192];   // [stage][Qs | dO | Qst | dOt]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int kv = (blockIdx.x * NW + wave) * QW + l31;
+    const long bh = (long)b * H + h;
+    const bool kok = kv < Lk;
+    const bf16_t* Qh = Qs + (long)b * q_bstride + (long)h * Lq * 64;
+    const bf16_t* Qth = Qst + (long)b * qt_bstride + (long)h * 64 * Lqp;
+    const bf16_t* dOh = dO + bh * (long)Lq * 64;
+    const bf16_t* dOth = dOt + bh * 64 * (long)Lqp;
+    const bf16_t* Kh = K + bh * (long)Lk * 64;
+    const bf16_t* Vh = V + bh * (long)Lk * 64;
+    const float* lseh = lse + bh * Lq;
+    const float* Dh = D + bh * Lq;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 a = kok ? *reinterpret_cast<const uint4*>(Kh + (long)kv * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+        uint4 c = kok ? *reinterpret_cast<const uint4*>(Vh + (long)kv * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+        kf[ks] = *reinterpret_cast<bf16x8*>(&a);
+        vf[ks] = *reinterpret_cast<bf16x8*>(&c);
+    }
+    auto issue = [&](int t) {
+        unsigned char* st = smem + (t & 1) * 32768;
+        dma_rows(st, Qh, 64, t * KV, Lq - 1, 0, wave, lane);
+        dma_rows(st + 8192, dOh, 64, t * KV, Lq - 1, 0, wave, lane);
+        dma_rows(st + 16384, Qth, Lqp, 0, 63, (long)t * KV, wave, lane);
+        dma_rows(st + 24576, dOth, Lqp, 0, 63, (long)t * KV, wave, lane);
+    };
+    f32x16 ak[2], av[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ak[i][r] = 0.f, av[i][r] = 0.f;
+    const int nt = (Lq + KV - 1) / KV;
+    issue(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1);
+        const unsigned char* sq = smem + (t & 1) * 32768;
+        const unsigned char* sdo = sq + 8192;
+        const unsigned char* sqt = sq + 16384;
+        const unsigned char* sdot = sq + 24576;
+        const int q0 = t * KV;
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            // accumulator rows are queries q0 + qb*32 + (r & 3) + 8 (r >> 2) + 4 hi: start from -lse[q] / -D[q]
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qq = q0 + qb * 32 + 8 * g + 4 * hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = qq + e < Lq;
+                    s[qb][g * 4 + e] = ok ? -lseh[qq + e] : -INFINITY;          // query past the end: P = exp2(-inf) = 0
+                    dp[qb][g * 4 + e] = ok ? -Dh[qq + e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(sq + k_off(qb * 32 + l31, ks * 2 + hi));
+                const bf16x8 dfr = *reinterpret_cast<const bf16x8*>(sdo + k_off(qb * 32 + l31, ks * 2 + hi));
+                s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], s[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], dp[qb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[qb][r]);
+                s[qb][r] = p;
+                dp[qb][r] = p * dp[qb][r];
+            }
+        bf16x8 pf[4], dsf[4];
+        pack_frags(s, pf);
+        pack_frags(dp, dsf);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 dotf = *reinterpret_cast<const bf16x8*>(sdot + k_off(db * 32 + l31, 2 * j + hi));
+                const bf16x8 qtf = *reinterpret_cast<const bf16x8*>(sqt + k_off(db * 32 + l31, 2 * j + hi));
+                av[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf[j], av[db], 0, 0, 0);
+                ak[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[j], ak[db], 0, 0, 0);
+            }
+    }
+    if (kok) {
+        bf16_t* krow = dK + (bh * Lk + kv) * 64;
+        bf16_t* vrow = dV + (bh * Lk + kv) * 64;
+        const float ln2 = 0.69314718055994530942f;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w, u;
+                w.x = pack_bf16x2(ak[db][g * 4 + 0] * ln2, ak[db][g * 4 + 1] * ln2);
+                w.y = pack_bf16x2(ak[db][g * 4 + 2] * ln2, ak[db][g * 4 + 3] * ln2);
+                u.x = pack_bf16x2(av[db][g * 4 + 0], av[db][g * 4 + 1]);
+                u.y = pack_bf16x2(av[db][g * 4 + 2], av[db][g * 4 + 3]);
+                *reinterpret_cast<uint2*>(krow + db * 32 + g * 8 + hi * 4) = w;
+                *reinterpret_cast<uint2*>(vrow + db * 32 + g * 8 + hi * 4) = u;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- fp32
 constexpr int FLD = 65;   // padded row length (floats) of the fp32 tiles: conflict-free column reads
 
@@ -403,5 +646,23 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         M324_FAIL(M324_ERR_UNSUPPORTED, "m324_attention: dtype %d", dtype);
     }
     M324_CHECK_LAUNCH("m324_attention");
+    return M324_OK;
+}
+
+extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_bstride, long qt_bstride, const void* K,
+                                       const void* Kt, const void* V, const void* dO, const void* dOt, const float* lse,
+                                       const float* D, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, float scale,
+                                       void* stream) {
+    M324_REQUIRE(Qs && Qst && K && Kt && V && dO && dOt && lse && D && dQ && dK && dV, "m324_attention_bwd_mfma: null pointer");
+    M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && H <= 65535 && B <= 65535, "m324_attention_bwd_mfma: bad sizes");
+    const int Lkp = (Lk + 63) / 64 * 64, Lqp = (Lq + 63) / 64 * 64;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(ceil_div(Lq, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs, q_bstride,
+                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D, (bf16_t*)dQ, H, Lq, Lk, Lkp,
+                       scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(ceil_div(Lk, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs,
+                       (const bf16_t*)Qst, q_bstride, qt_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO,
+                       (const bf16_t*)dOt, lse, D, (bf16_t*)dK, (bf16_t*)dV, H, Lq, Lk, Lqp);
+    M324_CHECK_LAUNCH("m324_attention_bwd_mfma");
     return M324_OK;
 }

@@ -353,6 +353,24 @@ def attention_bwd(Qs, K, V, dO, lse, D, *, shared_q: bool = False, scale: float 
     return dQ, dK, dV
 
 
+def attention_bwd_mfma(spq: dict, spk: dict, spdo: dict, lse, D, *, shared_q: bool = False, scale: float = 64 ** -0.5):
+    """bf16 MFMA backward.  spq / spk / spdo: the dicts qkv_split(train=True) returns for q, for k|v and for dO
+    (passed as its q source).  Returns (dQ, dK, dV) like attention_bwd."""
+    Qs, Qst, K, Kt, V = spq["Q"], spq["Qt"], spk["K"], spk["Kt"], spk["V"]
+    dO, dOt = spdo["Q"], spdo["Qt"]
+    B, H, Lk, _ = K.shape
+    Lq = Qs.shape[2]
+    Lqp = (Lq + 63) // 64 * 64
+    if K.dtype != torch.bfloat16:
+        raise L.M324Error("attention_bwd_mfma is the bf16 kernel; use attention_bwd for fp32")
+    dQ = torch.empty((B, H, Lq, 64), dtype=K.dtype, device=K.device)
+    dK, dV = torch.empty_like(K), torch.empty_like(V)
+    L.check(L.load().m324_attention_bwd_mfma(_p(Qs), _p(Qst), 0 if shared_q else H * Lq * 64, 0 if shared_q else H * 64 * Lqp,
+                                             _p(K), _p(Kt), _p(V), _p(dO), _p(dOt), _p(lse), _p(D), _p(dQ), _p(dK), _p(dV),
+                                             B, H, Lq, Lk, scale, _stream()), "m324_attention_bwd_mfma")
+    return dQ, dK, dV
+
+
 def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: int, H: int, dq_out, dk_out, dv_out):
     """Writes token-major gradients into dq_out / dk_out / dv_out (2-D views, any may be None with its dX);
     returns (dq_norm_w [64] or None, dk_norm_w [64] or None)."""

@@ -274,3 +274,41 @@ def test_cross_attn_block_backward_vs_oracle_autograd(dtype, shared):
         g = G.get(p)
         assert g is not None, name
         assert rel_err(g, sdd["b." + name].grad) < tol, (name, rel_err(g, sdd["b." + name].grad))
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,shared", [(2, 3, 70, 70, False), (1, 2, 33, 200, False), (3, 2, 50, 64, True),
+                                               (1, 12, 324, 324, False), (1, 2, 700, 129, False)])
+def test_attention_backward_mfma_against_autograd(B, H, Lq, Lk, shared):
+    """bf16 MFMA backward kernels (through qkv_split's train outputs) vs fp64 autograd and vs the reference kernels."""
+    from motion324_amd import ops
+    dtype = torch.bfloat16
+    Bq = 1 if shared else B
+    C = H * 64
+    q_tok, k_tok, v_tok = (_q(_rand((n * L_, C), sd_, 1.2), dtype) for n, L_, sd_ in ((Bq, Lq, 41), (B, Lk, 42), (B, Lk, 43)))
+    dO_tok = _q(_rand((B * Lq, C), 44), dtype)
+    dev = lambda t: t.to(dtype).to(DEV)
+    spq = ops.qkv_split(dev(q_tok), None, None, None, None, 0.0, Bq, Lq, H, dtype, q_scale=ops.Q_PRESCALE, train=True)
+    spk = ops.qkv_split(None, dev(k_tok), dev(v_tok), None, None, 0.0, B, Lk, H, dtype, train=True)
+    out = torch.empty((B * Lq, C), dtype=dtype, device=DEV)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=DEV)
+    ops.attention(spq["Q"], spk["K"], spk["Vt"], out, shared_q=shared, prescaled=True, lse=lse)
+    D = ops.attention_delta(out, dev(dO_tok), B, H, Lq)
+    spdo = ops.qkv_split(dev(dO_tok), None, None, None, None, 0.0, B, Lq, H, dtype, train=True)
+    dQ, dK, dV = ops.attention_bwd_mfma(spq, spk, spdo, lse, D, shared_q=shared)
+    rQ, rK, rV = ops.attention_bwd(spq["Q"], spk["K"], spk["V"], spdo["Q"], lse, D, shared_q=shared)
+    for a, b_ in ((dQ, rQ), (dK, rK), (dV, rV)):
+        assert torch.isfinite(a.float()).all()
+        assert rel_err(a.float(), b_.float()) < 1.5e-2
+    # fp64 autograd on the stored operands
+    qs = spq["Q"].float().cpu().double()
+    qh = (qs / ops.Q_PRESCALE).requires_grad_(True)
+    kd = spk["K"].float().cpu().double().requires_grad_(True)
+    vd = spk["V"].float().cpu().double().requires_grad_(True)
+    sc = torch.einsum("bhqd,bhkd->bhqk", qh.expand(B, -1, -1, -1), kd) * (64 ** -0.5)
+    o = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, -1), vd).reshape(B * Lq, C)
+    o.backward(dO_tok.double())
+    got_dq = dQ.float().cpu().double()
+    if shared:
+        got_dq = got_dq.sum(0, keepdim=True)
+    assert rel_err(got_dq, qh.grad) < 2e-2
+    assert rel_err(dK.float(), kd.grad) < 2e-2 and rel_err(dV.float(), vd.grad) < 2e-2
