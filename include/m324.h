@@ -45,6 +45,8 @@ int m324_device_info(char* name, int n);
  *                             v += residual[(m % res_rows) * ldr + n] ; store as out_dtype at
  *                             C[out_row(m) * ldc + n],  out_row(m) = (m / row_gin) * row_gout + m % row_gin + row_off.
  *   constraints: K % 64 == 0 (bf16) / K % 32 == 0 (f32) -- pad K with zeros; A, W rows 16-byte aligned.
+ *   batch > 1 runs independent problems in one launch (used for split-K weight gradients: the token dimension is cut
+ *   into slices, each slice writes its own partial dW, m324_colsum adds them -- deterministic, no atomics).
  *   in_dtype selects the MFMA: bf16 -> v_mfma_f32_32x32x16_bf16, f32 -> v_mfma_f32_32x32x2_f32.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -58,6 +60,8 @@ typedef struct {
     const float* gamma;
     const float* residual; long ldr; int res_rows;   /* res_rows <= 0 -> M */
     int row_gin, row_gout, row_off;                  /* row_gin <= 0 -> identity */
+    int batch;                                       /* <= 1: single GEMM; else `batch` independent GEMMs ...   */
+    long strideA, strideW, strideC;                  /* ... whose A / W / C start strideX elements apart          */
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
 

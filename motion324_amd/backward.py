@@ -51,6 +51,15 @@ def _attention_bwd(P: Prepared, spq: dict, spk: dict, do: torch.Tensor, lse, D, 
     return ops.attention_bwd(spq["Q"], spk["K"], spk["V"], dO_hm, lse, D, shared_q=shared_q)
 
 
+def _wgrad(dYt: torch.Tensor, At: torch.Tensor) -> torch.Tensor:
+    """dW [N, Ka] fp32 = dYt [N, Mp] . At [Ka, Mp]^T.  The output is small and the contraction (tokens) long: cut it into
+    slices so that the launch has at least ~256 workgroups (split-K, partials summed deterministically)."""
+    N, Mp = dYt.shape
+    tiles = ((N + 127) // 128) * ((At.shape[0] + 127) // 128)
+    slices = max(1, min(32, (320 + tiles - 1) // tiles, Mp // 512))
+    return ops.gemm_splitk(dYt, At, slices)
+
+
 def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
     """[K', N_pad] transposed GEMM operand of a weight (for dgrad), cached like P.mat."""
     return P.derived("matT", (weight,), lambda: ops.transpose(P.mat(weight)))
@@ -63,8 +72,7 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
         G.add(bias, ops.colsum(dy))
     dYt = ops.transpose(dy)                                   # [N, Mp]
     At = ops.transpose(a)                                     # [Ka, Mp]
-    dW = torch.empty((N, a.shape[1]), dtype=torch.float32, device=dy.device)
-    ops.gemm(dYt, At, dW)
+    dW = _wgrad(dYt, At)
     k_true = weight[0].numel()
     G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
     if not need_da:
@@ -181,8 +189,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
         G.add(a.to_k.bias, bsum[:C])
         G.add(a.to_v.bias, bsum[C:])
     dYt, At = ops.transpose(dkvp), ops.transpose(kn)
-    dWkv = torch.empty((2 * C, C), dtype=torch.float32, device=dev)
-    ops.gemm(dYt, At, dWkv)
+    dWkv = _wgrad(dYt, At)
     G.add(a.to_k.weight, dWkv[:C])
     G.add(a.to_v.weight, dWkv[C:])
     if d_kv is not None:

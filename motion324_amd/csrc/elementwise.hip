@@ -407,6 +407,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
     }
 }
 
+// few rows, very many columns (sum over the frames of a shared-query gradient): thread per column, coalesced
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, long ld, float* __restrict__ out, int rows,
+                                                          long cols, int accumulate) {
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += Elem<T>::load(x + (long)r * ld + c);
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
 // GELU forward on a stored pre-activation and its backward: dz = dh * (Phi(z) + z * phi(z)).
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ z, T* __restrict__ h, long n) {
@@ -630,9 +641,16 @@ extern "C" int m324_transpose(const void* in, long ld_in, void* out, long ld_out
 extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate, void* stream) {
     M324_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "m324_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, "m324_colsum",
-                   hipLaunchKernelGGL(colsum_kernel<T>, dim3(ceil_div(cols, 64)), dim3(256), 0, s, (const T*)x, ld, out, rows, cols,
-                                      accumulate));
+    if (rows <= 64) {
+        const int nb = (int)(((long)cols + 255) / 256 < 8192 ? ((long)cols + 255) / 256 : 8192);
+        DISPATCH_DTYPE(dtype, "m324_colsum",
+                       hipLaunchKernelGGL(colsum_wide_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)x, ld, out, rows, (long)cols,
+                                          accumulate));
+    } else {
+        DISPATCH_DTYPE(dtype, "m324_colsum",
+                       hipLaunchKernelGGL(colsum_kernel<T>, dim3(ceil_div(cols, 64)), dim3(256), 0, s, (const T*)x, ld, out, rows,
+                                          cols, accumulate));
+    }
     M324_CHECK_LAUNCH("m324_colsum");
     return M324_OK;
 }

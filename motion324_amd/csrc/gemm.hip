@@ -28,6 +28,7 @@ struct Epilogue {
     int res_rows;
     int act;
     int row_gin, row_gout, row_off;
+    long strideA, strideW, strideC;
 };
 
 // GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
@@ -349,6 +350,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
         lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
     }
     const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+    A += (long)blockIdx.y * ep.strideA;      // batched launch (split-K weight gradients): blockIdx.y = problem index
+    W += (long)blockIdx.y * ep.strideW;
+    C += (long)blockIdx.y * ep.strideC;
 
     // this wave stages row groups g = wave*4 + i (8 rows each) of both operands
     const TIN* ga[4];
@@ -748,9 +752,11 @@ static void launch_stag(const m324_gemm_args* a, hipStream_t s, const Epilogue& 
 
 template <typename TIN, typename TOUT>
 int launch(const m324_gemm_args* a, hipStream_t s) {
-    Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off};
+    Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off,
+                a->strideA, a->strideW, a->strideC};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
-    const int variant = pick_variant(a);
+    const int nbatch = a->batch > 1 ? a->batch : 1;
+    const int variant = nbatch > 1 ? 2 : pick_variant(a);
     if (variant == 1) {
         hipLaunchKernelGGL((gemm_kernel<TIN, TOUT>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda, (const TIN*)a->W,
                            a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
@@ -772,7 +778,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
                                a->K, ep, (int)grid.x, xcd_remap());                                                      \
         else                                                                                                             \
-            hipLaunchKernelGGL((gemm_glds_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * grid.y), dim3(256), 0, s,          \
+            hipLaunchKernelGGL((gemm_glds_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * grid.y, nbatch), dim3(256), 0, s,  \
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
                                a->K, ep, (int)grid.x, xcd_remap());                                                      \
     } while (0)
@@ -800,6 +806,8 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
                  "m324_gemm: A/W rows must be 16-byte aligned");
     M324_REQUIRE(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, "m324_gemm: leading dimension too small");
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
+    M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
+                 "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
     hipStream_t s = (hipStream_t)stream;
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16) return launch<bf16_t, bf16_t>(a, s);
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_F32) return launch<bf16_t, float>(a, s);

@@ -33,6 +33,8 @@ class GemmArgs(C.Structure):
         ("gamma", C.c_void_p),
         ("residual", C.c_void_p), ("ldr", C.c_long), ("res_rows", C.c_int),
         ("row_gin", C.c_int), ("row_gout", C.c_int), ("row_off", C.c_int),
+        ("batch", C.c_int),
+        ("strideA", C.c_long), ("strideW", C.c_long), ("strideC", C.c_long),
     ]
 
 

@@ -57,6 +57,33 @@ def _rows(t: torch.Tensor, name: str):
     return _p(t), t.stride(0)
 
 
+def gemm_splitk(a: torch.Tensor, w: torch.Tensor, slices: int) -> torch.Tensor:
+    """out[M,N] fp32 = a[M,K] @ w[N,K]^T with the contraction cut into `slices` independent GEMMs launched together
+    (grid.y) and summed by m324_colsum: for weight gradients, where M x N is small and K (tokens) is huge."""
+    M, K = a.shape
+    N = w.shape[0]
+    esz = a.element_size()
+    tile = 64 if esz == 2 else 32
+    ks = (K // tile // slices) * tile
+    if slices <= 1 or ks == 0:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        return gemm(a, w, out)
+    main = ks * slices
+    part = torch.empty((slices + (1 if main < K else 0), M, N), dtype=torch.float32, device=a.device)
+    args = L.GemmArgs()
+    args.A, args.lda = _rows(a, "a")
+    args.W, args.ldw = _rows(w, "w")
+    args.C, args.ldc = _p(part), N
+    args.M, args.N, args.K = M, N, ks
+    args.in_dtype, args.out_dtype = code_of(a.dtype), F32
+    args.batch, args.strideA, args.strideW, args.strideC = slices, ks, ks, M * N
+    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * main, esz * (M + N) * main + 4.0 * slices * M * N):
+        L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
+    if main < K:                                        # remainder of the contraction
+        gemm(a[:, main:], w[:, main:], part[slices])
+    return colsum(part.reshape(part.shape[0], M * N)).reshape(M, N)
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = L.ACT_NONE, gamma=None,
          residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0)) -> torch.Tensor:
     """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm."""

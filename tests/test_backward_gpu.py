@@ -312,3 +312,20 @@ def test_attention_backward_mfma_against_autograd(B, H, Lq, Lk, shared):
         got_dq = got_dq.sum(0, keepdim=True)
     assert rel_err(got_dq, qh.grad) < 2e-2
     assert rel_err(dK.float(), kd.grad) < 2e-2 and rel_err(dV.float(), vd.grad) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K,slices", [(192, 768, 4096, 8), (768, 64, 1000 // 64 * 64 + 64, 3), (100, 52, 640, 4)])
+def test_gemm_splitk_matches_plain(dtype, M, N, K, slices):
+    from motion324_amd import ops
+    a, w = _q(_rand((M, K), 51, 0.3), dtype), _q(_rand((N, K), 52, 0.3), dtype)
+    out = ops.gemm_splitk(a.to(dtype).to(DEV), w.to(dtype).to(DEV), slices)
+    assert rel_err(out, a.double() @ w.double().T) < 2e-5
+
+
+def test_colsum_wide_few_rows():
+    from motion324_amd import ops
+    x = _rand((12, 100003), 53)
+    assert rel_err(ops.colsum(x.to(DEV)), x.double().sum(0)) < 1e-6
+    xb = x.to(torch.bfloat16)
+    assert rel_err(ops.colsum(xb.to(DEV)), xb.double().sum(0)) < 1e-6

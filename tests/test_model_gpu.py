@@ -319,3 +319,61 @@ def test_autograd_wrapper_and_three_optimizer_steps_match_torch_on_oracle():
     worst = max(rel_err(got[k].detach(), sd[k].detach()) for k in train_keys)
     assert worst < 1e-4, worst
     assert losses[2] < losses[0]
+
+
+def _ddp_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import motion324_amd as m
+        from motion324_amd import synth, training
+        from motion324_amd.optim import FusedAdamW
+        model, dm = build("tiny")
+        model.train()
+        s_np = synth.synth_inputs(2, 3, 30, 80, 64, seed=4, with_target=True)
+        mine = {k: torch.from_numpy(v[rank:rank + 1]).cuda() for k, v in s_np.items()}      # this rank's sample
+        m.set_precision("fp32")
+        opt = FusedAdamW(model.named_parameters(), lr=1e-3, allowed_gradnorm_factor=1e9)
+        loss, _, G = training.forward_backward(model, mine)
+        opt.load_grads(G)
+        opt.all_reduce_mean()                                   # one flat all-reduce (gloo here, RCCL on a node)
+        info = opt.step()
+        torch.cuda.synchronize()
+        ret[rank] = (opt.flat_grad.cpu(), torch.cat([p.detach().reshape(-1).cpu() for p in opt.params]), info["grad_norm"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_single_process_on_the_concatenated_batch():
+    """DDP semantics (train.py:88-89): 2 ranks x batch 1 with the flat gradient all-reduce(mean) == 1 process x batch 2."""
+    import os
+    import torch.multiprocessing as mp
+    import motion324_amd as m
+    from motion324_amd import synth, training
+    from motion324_amd.optim import FusedAdamW
+    model, dm = build("tiny")
+    model.train()
+    s_np = synth.synth_inputs(2, 3, 30, 80, 64, seed=4, with_target=True)
+    m.set_precision("fp32")
+    try:
+        opt = FusedAdamW(model.named_parameters(), lr=1e-3, allowed_gradnorm_factor=1e9)
+        loss, _, G = training.forward_backward(model, {k: torch.from_numpy(v).cuda() for k, v in s_np.items()})
+        opt.load_grads(G)
+        info = opt.step()
+        torch.cuda.synchronize()
+    finally:
+        m.set_precision(None)
+    ref_grad = opt.flat_grad.cpu()
+    ref_params = torch.cat([p.detach().reshape(-1).cpu() for p in opt.params])
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 27000 + (os.getpid() * 3) % 4000
+    mp.spawn(_ddp_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in range(2):
+        g, p, norm = ret[r]
+        assert rel_err(g, ref_grad) < 1e-5
+        assert rel_err(p, ref_params) < 1e-6
+        assert abs(norm - info["grad_norm"]) < 1e-5 * info["grad_norm"]
+    assert torch.equal(ret[0][1], ret[1][1])                    # replicas stay bit-identical
