@@ -189,7 +189,9 @@ int m324_smooth_trajectories(const float* trajs, float* tmp, float* out, int B, 
 int m324_transpose(const void* in, long ld_in, void* out, long ld_out, int rows, int cols, int rows_pad,
                    int dtype, void* stream);
 /* out[c] (+)= sum over rows of x[r][c] (fp32 accumulation): bias gradients. */
-int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate, void* stream);
+int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate,
+                float* scratch, int scratch_rows, void* stream);
+/*   scratch (optional, scratch_rows x cols floats): lets tall inputs be reduced by row chunks in parallel. */
 /* h = gelu_erf(z);  dz = dh * gelu'(z)  (nn.GELU, transformer.py:58), elementwise over n values. */
 int m324_gelu(const void* z, void* h, long n, int dtype, void* stream);
 int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, void* stream);

@@ -435,11 +435,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int qq = q0 + qb * 32 + 8 * g + 4 * hi;
+                if (qq + 3 < Lq && (Lq & 3) == 0) {                             // aligned run of 4 queries: one 16-byte load each
+                    const float4 l4 = *reinterpret_cast<const float4*>(lseh + qq);
+                    const float4 d4 = *reinterpret_cast<const float4*>(Dh + qq);
+                    s[qb][g * 4 + 0] = -l4.x; s[qb][g * 4 + 1] = -l4.y; s[qb][g * 4 + 2] = -l4.z; s[qb][g * 4 + 3] = -l4.w;
+                    dp[qb][g * 4 + 0] = -d4.x; dp[qb][g * 4 + 1] = -d4.y; dp[qb][g * 4 + 2] = -d4.z; dp[qb][g * 4 + 3] = -d4.w;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = qq + e < Lq;
-                    s[qb][g * 4 + e] = ok ? -lseh[qq + e] : -INFINITY;          // query past the end: P = exp2(-inf) = 0
-                    dp[qb][g * 4 + e] = ok ? -Dh[qq + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = qq + e < Lq;
+                        s[qb][g * 4 + e] = ok ? -lseh[qq + e] : -INFINITY;      // query past the end: P = exp2(-inf) = 0
+                        dp[qb][g * 4 + e] = ok ? -Dh[qq + e] : 0.f;
+                    }
                 }
             }
 #pragma unroll

@@ -407,6 +407,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
     }
 }
 
+// many rows: blockIdx.y = row chunk, partial sums into scratch[chunk][cols] (then reduced by the wide kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__ x, long ld, float* __restrict__ scratch, int rows,
+                                                           int cols) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = blockIdx.y * 4 + w; r < rows; r += gridDim.y * 4) s += Elem<T>::load(x + (long)r * ld + c);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < cols)
+        scratch[(long)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // few rows, very many columns (sum over the frames of a shared-query gradient): thread per column, coalesced
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, long ld, float* __restrict__ out, int rows,
@@ -638,9 +653,21 @@ extern "C" int m324_transpose(const void* in, long ld_in, void* out, long ld_out
     return M324_OK;
 }
 
-extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate, void* stream) {
+extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate, float* scratch,
+                           int scratch_rows, void* stream) {
     M324_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "m324_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (scratch && scratch_rows > 1 && rows >= 2048) {   // two-stage: row chunks in parallel, then a short deterministic sum
+        const int R = scratch_rows < 64 ? scratch_rows : 64;
+        DISPATCH_DTYPE(dtype, "m324_colsum",
+                       hipLaunchKernelGGL(colsum_chunk_kernel<T>, dim3(ceil_div(cols, 64), R), dim3(256), 0, s, (const T*)x, ld,
+                                          scratch, rows, cols));
+        const int nb = (cols + 255) / 256 < 8192 ? (cols + 255) / 256 : 8192;
+        hipLaunchKernelGGL(colsum_wide_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)scratch, (long)cols, out, R,
+                           (long)cols, accumulate);
+        M324_CHECK_LAUNCH("m324_colsum");
+        return M324_OK;
+    }
     if (rows <= 64) {
         const int nb = (int)(((long)cols + 255) / 256 < 8192 ? ((long)cols + 255) / 256 : 8192);
         DISPATCH_DTYPE(dtype, "m324_colsum",

@@ -58,7 +58,7 @@ SIGNATURES = {
     "m324_mse": [_P, _P, _L, _F, _P, _P, _P],
     "m324_smooth_trajectories": [_P, _P, _P, _I, _I, _I, _F, _F, _P],
     "m324_transpose": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
-    "m324_colsum": [_P, _L, _P, _I, _I, _I, _I, _P],
+    "m324_colsum": [_P, _L, _P, _I, _I, _I, _I, _P, _I, _P],
     "m324_gelu": [_P, _P, _L, _I, _P],
     "m324_gelu_bwd": [_P, _P, _P, _L, _I, _P],
     "m324_cast": [_P, _L, _I, _P, _L, _I, _I, _I, _P],

@@ -308,8 +308,12 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     if out is None:
         out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
         accumulate = False
-    L.check(L.load().m324_colsum(px, ld, _vec(out, Cc, "out"), R, Cc, code_of(x.dtype), int(accumulate), _stream()),
-            "m324_colsum")
+    scratch, srows = None, 0
+    if R >= 2048:
+        srows = 64
+        scratch = torch.empty((srows, Cc), dtype=torch.float32, device=x.device)
+    L.check(L.load().m324_colsum(px, ld, _vec(out, Cc, "out"), R, Cc, code_of(x.dtype), int(accumulate), _p(scratch), srows,
+                                 _stream()), "m324_colsum")
     return out
 
 
