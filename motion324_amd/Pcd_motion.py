@@ -25,7 +25,7 @@ from .easydict import EasyDict as edict
 from .image_encoder import DINO_EPS, DinoEncoder
 from .lib import ACT_GELU, M324Error
 from .loss import MSELossComputer
-from .prepared import Prepared, compute_dtype, pad_k
+from .prepared import Prepared, bump_generation, compute_dtype, pad_k
 from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
 DECODE_ROWS = 1 << 17     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
@@ -159,6 +159,7 @@ class Motion_Latent_Model(nn.Module):
         # the reference's override returns None (Pcd_motion.py:372-373); returning self keeps
         # `model.eval()` as a statement working and also the usual chaining
         super().train(mode)
+        bump_generation()            # eval after training steps of an external optimizer: re-derive weight copies
         return self
 
     # ------------------------------------------------------------------------------------ stages
@@ -198,7 +199,9 @@ class Motion_Latent_Model(nn.Module):
         forward+backward runs eagerly (motion324_amd.training.forward_backward); `loss` is returned through an
         autograd.Function whose backward hands the already-computed gradients (times the incoming scalar) to autograd,
         so `.grad`, GradScaler, clip_grad_norm_ and DDP's reducer hooks all behave as with the reference model."""
-        from . import training
+        # the caller's optimizer owns the parameters here, and torch.optim.AdamW(fused=True) (training_utils.py:52)
+        # updates them without bumping tensor._version: kernel-ready copies cannot be trusted across steps
+        bump_generation()
         params = [p for p in self.parameters() if p.requires_grad]
         loss, out = _TrainStepFunction.apply(self, sample, *params)
         lm = edict()

@@ -9,8 +9,10 @@ hipStreamBeginCapture on the stream libm324 launches on) and replayed: one host 
     out = fast(sample)                    # first call per (shapes, precision): warm-up + capture
     out.pcd_moved                         # static output buffer, overwritten by the next replay
 
-Weights are read through the Prepared cache at capture time; after an in-place weight update call
-``fast.reset()`` (inference-only helper: the reference's callers never update weights between forwards).
+Weights are read through the Prepared cache at capture time: a graph is keyed by the cache generation, so
+``model.train()/eval()`` toggles, the native optimizer step and ``prepared.bump_generation()`` force a re-capture;
+after any other in-place weight update call ``fast.reset()`` (inference-only helper: the reference's callers
+never update weights between forwards).
 """
 from __future__ import annotations
 
@@ -19,6 +21,7 @@ from typing import Dict, Tuple
 import torch
 
 from .easydict import EasyDict as edict
+from . import prepared
 from .prepared import compute_dtype
 
 _KEYS = ("ref_shape_pcd", "ref_shape_normals", "ref_shape_rgbs", "ref_pcd", "ref_normal", "ref_rgb", "rgb_video",
@@ -35,7 +38,7 @@ class GraphedForward:
         self._graphs.clear()
 
     def _key(self, sample) -> Tuple:
-        return (compute_dtype(),) + tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
+        return (prepared.generation(), compute_dtype()) + tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
 
     def __call__(self, sample: Dict[str, torch.Tensor]):
         if self.model.training:
@@ -43,6 +46,8 @@ class GraphedForward:
         key = self._key(sample)
         entry = self._graphs.get(key)
         if entry is None:
+            for stale in [k for k in self._graphs if k[0] != key[0]]:     # graphs that point at dropped weight copies
+                del self._graphs[stale]
             static_in = {k: sample[k].detach().to(torch.float32).contiguous().clone() for k in _KEYS if k in sample}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

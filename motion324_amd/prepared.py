@@ -43,9 +43,14 @@ _GENERATION = 0
 
 def bump_generation() -> None:
     """Invalidates every cached kernel-ready copy.  Call after updating parameters through raw pointers (the fused
-    AdamW kernel writes parameter memory without touching torch's version counters)."""
+    AdamW kernel writes parameter memory without touching torch's version counters; so does
+    torch.optim.AdamW(fused=True), which is why Motion_Latent_Model bumps it on every training-mode forward)."""
     global _GENERATION
     _GENERATION += 1
+
+
+def generation() -> int:
+    return _GENERATION
 
 
 def pad_k(k: int) -> int:

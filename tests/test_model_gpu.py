@@ -3,6 +3,8 @@
  (b) the CPU oracle on the same seeded inputs.
 Tolerances: fp32 parity mode <= 1e-3 relative (north_star); bf16 speed mode is reported against the same
 goldens with its own band (the reference's own bf16-vs-fp32 gap is 0.9-11 %)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -377,3 +379,65 @@ def test_data_parallel_step_equals_single_process_on_the_concatenated_batch():
         assert rel_err(p, ref_params) < 1e-6
         assert abs(norm - info["grad_norm"]) < 1e-5 * info["grad_norm"]
     assert torch.equal(ret[0][1], ret[1][1])                    # replicas stay bit-identical
+
+
+def test_reference_train_loop_sequence_runs_unchanged_and_matches_native_path():
+    """The statement sequence of the reference's train.py:150-213 (autocast bf16 -> model(batch) -> scaler.scale(loss)
+    .backward() -> nan_to_num_ -> clip_grad_norm_ -> fused torch AdamW) on the drop-in model, vs the native
+    forward_backward + FusedAdamW path: same losses, same weights."""
+    import motion324_amd as m
+    from motion324_amd import synth, training
+    from motion324_amd.optim import FusedAdamW
+    s_np = synth.synth_inputs(2, 3, 30, 80, 64, seed=6, with_target=True)
+
+    def make():
+        model, _ = build("tiny")
+        model.train()
+        return model
+    # ---- the reference's loop body
+    model = make()
+    decay = [p for n, p in model.named_parameters() if p.requires_grad and p.dim() > 1]
+    no_decay = [p for n, p in model.named_parameters() if p.requires_grad and p.dim() <= 1]
+    optimizer = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}],
+                                  lr=1e-3, betas=(0.9, 0.95), fused=True)
+    scaler = torch.amp.GradScaler("cuda", enabled=False)
+    ref_losses = []
+    for step in range(2):
+        batch = {k: torch.from_numpy(v).cuda() for k, v in s_np.items()}
+        batch["cur_train_step"] = step                                       # train.py:148 adds a non-tensor entry
+        with torch.autocast(enabled=True, device_type="cuda", dtype=torch.bfloat16):
+            ret_dict = model(batch)
+        scaler.scale(ret_dict.loss_metrics.loss / 1).backward()
+        assert not (torch.isnan(ret_dict.loss_metrics.loss) or torch.isinf(ret_dict.loss_metrics.loss))
+        scaler.unscale_(optimizer)
+        with torch.no_grad():
+            for p in decay + no_decay:
+                p.grad.nan_to_num_(nan=0.0, posinf=1e-6, neginf=-1e-6)
+        total = torch.nn.utils.clip_grad_norm_(decay + no_decay, max_norm=1.0).item()
+        assert math.isfinite(total)
+        scaler.step(optimizer)
+        scaler.update()
+        optimizer.zero_grad(set_to_none=True)
+        ref_losses.append({k: v.item() for k, v in ret_dict.loss_metrics.items()}["loss"])
+    # ---- native path
+    native = make()
+    opt = FusedAdamW(native.named_parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05, grad_clip_norm=1.0,
+                     allowed_gradnorm_factor=1e9)
+    m.set_precision("bf16")
+    try:
+        nat_losses = []
+        for step in range(2):
+            loss, _, G = training.forward_backward(native, {k: torch.from_numpy(v).cuda() for k, v in s_np.items()})
+            opt.load_grads(G)
+            opt.step()
+            nat_losses.append(float(loss))
+    finally:
+        m.set_precision(None)
+    # step 0 is the same code on the same weights; afterwards torch's fused AdamW and m324_adamw round differently
+    # (1 ulp of an fp32 weight can flip its bf16 copy), so later losses agree to bf16 resolution only
+    assert ref_losses[0] == pytest.approx(nat_losses[0], rel=1e-6)
+    assert ref_losses == pytest.approx(nat_losses, rel=1e-3)
+    assert ref_losses[1] < 0.6 * ref_losses[0]          # the caller's optimizer really moved the weights the kernels read
+    a, b = dict(model.named_parameters()), dict(native.named_parameters())
+    worst = max(rel_err(a[k].detach(), b[k].detach()) for k in a if a[k].requires_grad)
+    assert worst < 2e-3, worst          # Adam normalises: bf16-level gradient differences of step 1 move small entries
