@@ -149,11 +149,15 @@ int m324_dino_cls_rows(const float* cls, const float* pos0, float* x, int F, int
  *   dino_x [B*T, 1+P, C] fp32 (pre final-norm); dino_w/dino_b final-norm affine, eps_dino (1e-6);
  *   pos [T*P, C]; sp0/spr [4,C]; mesh [B,K,C]; ln_w [C], eps_in (1e-5).  ln_w == NULL: the un-normalised
  *   concatenation is written instead (needed by the backward of transformer_input_layernorm).
+ *   drop_p > 0 (training): pos_drop (model/Pcd_motion.py:369-370,490) on the video rows before stacking --
+ *   element i = ((b*T+t)*P+p)*C+c of the reference's x is kept iff
+ *   (splitmix64(i * 0xD1342543DE82EF95 + drop_seed) >> 40) >= (uint32)(drop_p * 2^24) and scaled by 1/(1-drop_p);
+ *   the same (drop_p, drop_seed) must be passed when the rows are recomputed for the backward.
  * ------------------------------------------------------------------------------------------ */
 int m324_assemble_tokens(const float* dino_x, const float* dino_w, const float* dino_b, float eps_dino,
                          const float* pos, const float* sp0, const float* spr, const float* mesh,
                          const float* ln_w, float eps_in, float* out,
-                         int B, int T, int K, int P, int C, void* stream);
+                         int B, int T, int K, int P, int C, float drop_p, unsigned long long drop_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * m324_linear_n3: out[M,3] fp32 = A[M,K] . W[3,K]^T + bias -- the xyz regression head's last layer

@@ -263,12 +263,15 @@ class Motion_Latent_Model(nn.Module):
 
         # C. DINO final norm + pos-embed + token assembly + input LN in one pass (reference :477-510)
         enc = self.image_encoder.model
+        # pos_drop acts whenever the module is in training mode (reference :490), also under no_grad
+        drop_p = self.drop_rate if self.training else 0.0
+        drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0.0 else 0
         pos = self._video_pos(P, T_full)[t0 * Pn:(t0 + T) * Pn]
         sp_rest = P.f32(self.special_token_rest).reshape(4, C)
         sp_first = P.f32(self.special_token_0).reshape(4, C) if t0 == 0 else sp_rest     # only clip frame 0 is special
         tok = ops.assemble_tokens(dino_x, P.vec(enc.norm.weight), P.vec(enc.norm.bias), DINO_EPS, pos, sp_first, sp_rest,
                                   mesh, P.vec(self.transformer_input_layernorm.weight),
-                                  self.transformer_input_layernorm.eps, B, T, K, Pn)
+                                  self.transformer_input_layernorm.eps, B, T, K, Pn, drop_p, drop_seed)
         Lt = 4 + K + Pn
         if cap is not None:
             dn = torch.empty((B * T * Pn, C), dtype=torch.float32, device=dev)

@@ -227,11 +227,19 @@ __global__ void dino_cls_kernel(const float* __restrict__ cls, const float* __re
 }
 
 // ----------------------------------------------------------------------------------- token assembly
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ dino_x, const float* __restrict__ dw,
                                                        const float* __restrict__ db, float eps_d, const float* __restrict__ pos,
                                                        const float* __restrict__ sp0, const float* __restrict__ spr,
                                                        const float* __restrict__ mesh, const float* __restrict__ lw, float eps_in,
-                                                       float* __restrict__ out, int B, int T, int K, int P, int C) {
+                                                       float* __restrict__ out, int B, int T, int K, int P, int C,
+                                                       unsigned drop_thr, float drop_scale, unsigned long long drop_seed) {
     const int lane = threadIdx.x & 63;
     const int Lt = 4 + K + P;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -256,6 +264,16 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
             v[i].y = (v[i].y - mean) * rstd * ww.y + bb.y + pp.y;
             v[i].z = (v[i].z - mean) * rstd * ww.z + bb.z + pp.z;
             v[i].w = (v[i].w - mean) * rstd * ww.w + bb.w + pp.w;
+        }
+        if (drop_thr) {   // pos_drop: counter-based mask, one SplitMix64 draw per element of x[B, T*P, C]
+            const unsigned long long base = ((((unsigned long long)b * T + t) * P) + p) * (unsigned long long)C;
+            LN_FOR(i, c) {
+                float* e = reinterpret_cast<float*>(&v[i]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    e[q] = (unsigned)(splitmix64((base + c + q) * 0xD1342543DE82EF95ull + drop_seed) >> 40) >= drop_thr
+                               ? e[q] * drop_scale : 0.f;
+            }
         }
     }
     float* o = out + row * C;
@@ -589,12 +607,15 @@ extern "C" int m324_dino_cls_rows(const float* cls, const float* pos0, float* x,
 extern "C" int m324_assemble_tokens(const float* dino_x, const float* dino_w, const float* dino_b, float eps_dino,
                                     const float* pos, const float* sp0, const float* spr, const float* mesh,
                                     const float* ln_w, float eps_in, float* out, int B, int T, int K, int P, int C,
-                                    void* stream) {
+                                    float drop_p, unsigned long long drop_seed, void* stream) {
     M324_REQUIRE(dino_x && dino_w && dino_b && pos && sp0 && spr && mesh && out, "m324_assemble_tokens: null pointer");
+    M324_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "m324_assemble_tokens: drop_p=%g outside [0,1)", (double)drop_p);
+    const unsigned drop_thr = (unsigned)(drop_p * 16777216.0f);
+    const float drop_scale = 1.0f / (1.0f - drop_p);
     M324_REQUIRE(C % 4 == 0 && C <= 256 * LN_MAXV, "m324_assemble_tokens: C=%d unsupported", C);
     const long rows = (long)B * T * (4 + K + P);
     hipLaunchKernelGGL(assemble_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, dino_x, dino_w, dino_b,
-                       eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, out, B, T, K, P, C);
+                       eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, out, B, T, K, P, C, drop_thr, drop_scale, drop_seed);
     M324_CHECK_LAUNCH("m324_assemble_tokens");
     return M324_OK;
 }

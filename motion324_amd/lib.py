@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libm324.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class M324Error(RuntimeError):
@@ -53,7 +53,7 @@ SIGNATURES = {
     "m324_point_encode": [_P, _I, _P, _L, _I, _P],
     "m324_point_concat": [_P, _P, _I, _P, _I, _I, _I, _P],
     "m324_dino_cls_rows": [_P, _P, _P, _I, _I, _I, _P],
-    "m324_assemble_tokens": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
+    "m324_assemble_tokens": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _F, C.c_ulonglong, _P],
     "m324_linear_n3": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
     "m324_mse": [_P, _P, _L, _F, _P, _P, _P],
     "m324_smooth_trajectories": [_P, _P, _P, _I, _I, _I, _F, _F, _P],

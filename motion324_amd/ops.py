@@ -243,7 +243,8 @@ def dino_cls_rows(cls: torch.Tensor, pos0: torch.Tensor, x: torch.Tensor, Fr: in
                                         _stream()), "m324_dino_cls_rows")
 
 
-def assemble_tokens(dino_x, dino_w, dino_b, eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, B, T, K, P) -> torch.Tensor:
+def assemble_tokens(dino_x, dino_w, dino_b, eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, B, T, K, P,
+                    drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     Cdim = dino_x.shape[1]
     for name, t, n in (("dino_x", dino_x, B * T * (P + 1) * Cdim), ("pos", pos, T * P * Cdim), ("sp0", sp0, 4 * Cdim),
                        ("spr", spr, 4 * Cdim), ("mesh", mesh, B * K * Cdim)):
@@ -252,7 +253,8 @@ def assemble_tokens(dino_x, dino_w, dino_b, eps_dino, pos, sp0, spr, mesh, ln_w,
     out = torch.empty((B * T * (4 + K + P), Cdim), dtype=torch.float32, device=dino_x.device)
     L.check(L.load().m324_assemble_tokens(_p(dino_x), _vec(dino_w, Cdim, "dino_w"), _vec(dino_b, Cdim, "dino_b"), eps_dino,
                                           _p(pos), _p(sp0), _p(spr), _p(mesh), _vec(ln_w, Cdim, "ln_w") if ln_w is not None else None, eps_in, _p(out),
-                                          B, T, K, P, Cdim, _stream()), "m324_assemble_tokens")
+                                          B, T, K, P, Cdim, float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _stream()),
+            "m324_assemble_tokens")
     return out
 
 

@@ -60,6 +60,22 @@ def uniform(seed: int, key: str, shape, lo: float = 0.0, hi: float = 1.0) -> np.
     return out.reshape(shape)
 
 
+def dropout_keep(drop_seed: int, n: int, p: float) -> np.ndarray:
+    """bool[n]: the keep-mask m324_assemble_tokens applies for (drop_p=p, drop_seed) -- element i of the
+    reference's x[B, T*P, C] (flattened) survives pos_drop iff its top 24 SplitMix64 bits >= p * 2^24
+    (include/m324.h).  Host restatement for parity tests; the product path generates the mask on the GPU."""
+    thr = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    out = np.empty(n, dtype=bool)
+    s = np.uint64(drop_seed & 0xFFFFFFFFFFFFFFFF)
+    step = 1 << 22
+    for a in range(0, n, step):
+        idx = np.arange(a, min(n, a + step), dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            bits = _splitmix64(idx * np.uint64(0xD1342543DE82EF95) + s)
+        out[a:a + step] = (bits >> np.uint64(40)) >= thr
+    return out
+
+
 def normal(seed: int, key: str, shape, mean: float = 0.0, std: float = 1.0) -> np.ndarray:
     """N(mean, std^2) float32 tensor via Box-Muller on two SplitMix64 streams."""
     n = int(np.prod(shape))

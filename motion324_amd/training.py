@@ -45,14 +45,18 @@ def _point_features_bwd(model, P: Prepared, G: bw.GradStore, enc, feat, d_pf: to
     bw.linear_bwd(P, G, model.point_embed.mlp.weight, model.point_embed.mlp.bias, enc, demb, need_da=False)
 
 
-def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0
+def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None
                      ) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
-    """Returns (loss [0-dim fp32], pcd_moved [B,T,N,3] fp32, GradStore with d(grad_scale * loss)/d param)."""
+    """Returns (loss [0-dim fp32], pcd_moved [B,T,N,3] fp32, GradStore with d(grad_scale * loss)/d param).
+    pos_drop (reference :369-370,490; p = transformer.drop_rate, default 0.1) is applied to the video tokens when
+    model.training; its mask is a function of ``drop_seed`` (default: drawn from torch's CPU generator, so
+    torch.manual_seed(seed + rank) of train.py:61-64 makes runs repeatable and ranks independent)."""
     if "point_clouds" not in sample:
         raise M324Error("training step needs sample['point_clouds'] (the regression target)")
-    if model.drop_rate > 0.0:
-        raise NotImplementedError("training-mode dropout on video tokens (drop_rate > 0) is not implemented; "
-                                  "set model.video_encoder.transformer.drop_rate=0")
+    drop_p = float(model.drop_rate) if model.training else 0.0
+    if drop_p > 0.0 and drop_seed is None:
+        drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    drop_seed = 0 if drop_seed is None else drop_seed
     ref_pcd = sample["ref_pcd"]
     dev = ref_pcd.device
     if dev.type != "cuda":
@@ -85,7 +89,7 @@ def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float =
     sp0, spr = P.f32(model.special_token_0).reshape(4, C), P.f32(model.special_token_rest).reshape(4, C)
     ln_in = model.transformer_input_layernorm
     tok = ops.assemble_tokens(dino_x, P.vec(enc_m.norm.weight), P.vec(enc_m.norm.bias), DINO_EPS, pos, sp0, spr, mesh,
-                              P.vec(ln_in.weight), ln_in.eps, B, T, K, Pn)
+                              P.vec(ln_in.weight), ln_in.eps, B, T, K, Pn, drop_p, drop_seed)
     trunk_in = []
     for gblk, lblk in zip(model.global_transformer_blocks, model.local_transformer_blocks):
         trunk_in.append(tok.clone())
@@ -150,7 +154,7 @@ def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float =
     # token assembly + input LayerNorm: recompute the un-normalised concatenation, LN backward over every row (the LN
     # weight sees the video rows too), then fold the rows that carry parameters / the mesh latents
     pre = ops.assemble_tokens(dino_x, P.vec(enc_m.norm.weight), P.vec(enc_m.norm.bias), DINO_EPS, pos, sp0, spr, mesh,
-                              None, ln_in.eps, B, T, K, Pn)
+                              None, ln_in.eps, B, T, K, Pn, drop_p, drop_seed)
     d_pre = torch.empty_like(pre)
     dw, _ = ops.layernorm_bwd(pre, P.vec(ln_in.weight), ln_in.eps, d_tok, d_pre, accumulate=False)
     G.add(ln_in.weight, dw)

@@ -207,8 +207,9 @@ def dino_forward(sd: SD, images, patch: int, dh: int = 64, pre: str = "image_enc
 # ------------------------------------------------------------------ full forward
 def forward(sd: SD, sample: Dict[str, torch.Tensor], *, frames: int, d_head: int = 64,
             image_size: int = 224, patch_size: int = 14, loss_weight: float = 1.0,
-            stages: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+            stages: Optional[dict] = None, drop: Optional[tuple] = None) -> Dict[str, torch.Tensor]:
     """Motion_Latent_Model.forward in eval mode (Pcd_motion.py:450-598), stages A-G of SURVEY.md 3.2.
+    ``drop`` = (keep bool[B*T*g*g*C], p) reproduces the training-mode pos_drop with a given mask.
 
     ``frames`` = config.training.frames (the length pos_embed was built for, Pcd_motion.py:352,364).
     If ``stages`` is a dict it receives intermediate activations for stage-wise parity tests."""
@@ -243,7 +244,11 @@ def forward(sd: SD, sample: Dict[str, torch.Tensor], *, frames: int, d_head: int
     pe = generate_pos_embed(frames, g, g, C)
     if T != frames:
         pe = resize_pos_embed(pe, (frames, g, g), (T, g, g))
-    x = (x + pe).reshape(B, T, g * g, C)
+    x = x + pe
+    if drop is not None:        # training mode: x = self.pos_drop(x) (:369-370,490) with an explicit keep-mask
+        keep, p = drop
+        x = x * keep.reshape(x.shape).to(x.dtype) * (1.0 / (1.0 - p))
+    x = x.reshape(B, T, g * g, C)
 
     # C. token assembly + input LN (:495-510)
     sp0 = sd["special_token_0"].expand(B, 4, C)

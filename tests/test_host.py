@@ -1,4 +1,5 @@
 """Host-side contract of the drop-in (no GPU): state-dict manifest, module semantics, return type, weight cache."""
+import numpy as np
 import pytest
 import torch
 
@@ -133,8 +134,22 @@ def test_unsupported_configurations_are_rejected_not_approximated():
     model = small_model(drop_rate=0.1)
     model.train()
     s = {k: torch.from_numpy(v) for k, v in synth.synth_inputs(1, 3, 8, 16, 32).items()}
-    with pytest.raises(Exception):
+    with pytest.raises(Exception):                      # CPU tensors: no silent CPU fallback
         model(s)
+
+
+def test_dropout_keep_mask_restatement():
+    """Host restatement of the pos_drop mask m324_assemble_tokens generates (include/m324.h): deterministic in the seed,
+    keeps ~(1-p), independent across seeds, p=0 keeps everything."""
+    n = 1 << 20
+    k1 = synth.dropout_keep(1234, n, 0.1)
+    assert np.array_equal(k1, synth.dropout_keep(1234, n, 0.1))
+    assert abs(k1.mean() - 0.9) < 2e-3
+    k2 = synth.dropout_keep(1235, n, 0.1)
+    assert abs((k1 & k2).mean() - 0.81) < 3e-3
+    assert synth.dropout_keep(7, 1000, 0.0).all()
+    # nested in p: an element dropped at p is dropped at every p' > p (same draw, higher threshold)
+    assert not (synth.dropout_keep(1234, n, 0.5) & ~k1).any()
 
 
 def test_checkpoint_roundtrip_reference_format(tmp_path):

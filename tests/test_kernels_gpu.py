@@ -307,6 +307,22 @@ def test_assemble_tokens():
     tok = torch.cat([special, mesh.double().reshape(B, 1, K, C).expand(-1, T, -1, -1), vid], dim=2)
     ref = LN(tok, (C,), lw.double(), None, 1e-5).reshape(-1, C)
     assert rel_err(out, ref) < 1e-6
+    # training mode: pos_drop on the video rows with the documented counter-based mask; pre-LN rows and LN'ed rows
+    from motion324_amd import synth
+    p_drop, seed = 0.3, 0xDEADBEEFCAFE1234
+    keep = torch.from_numpy(synth.dropout_keep(seed, B * T * Pn * C, p_drop)).reshape(B, T, Pn, C)
+    assert 0.6 < keep.double().mean() < 0.8
+    vid_d = vid * keep.double() / (1.0 - p_drop)
+    tok_d = torch.cat([special, mesh.double().reshape(B, 1, K, C).expand(-1, T, -1, -1), vid_d], dim=2)
+    args = (dino_x.to(DEV), dw.to(DEV), db.to(DEV), 1e-6, pos.to(DEV), sp0.to(DEV), spr.to(DEV), mesh.to(DEV))
+    pre = ops.assemble_tokens(*args, None, 1e-5, B, T, K, Pn, p_drop, seed)
+    assert rel_err(pre, tok_d.reshape(-1, C)) < 1e-6
+    dropped = (pre.reshape(B, T, 4 + K + Pn, C)[:, :, 4 + K:] == 0).cpu()
+    assert torch.equal(dropped, ~keep)                                      # the mask itself is bit-exact
+    out_d = ops.assemble_tokens(*args, lw.to(DEV), 1e-5, B, T, K, Pn, p_drop, seed)
+    assert rel_err(out_d, LN(tok_d, (C,), lw.double(), None, 1e-5).reshape(-1, C)) < 1e-6
+    with pytest.raises(Exception):
+        ops.assemble_tokens(*args, None, 1e-5, B, T, K, Pn, 1.0, seed)
 
 
 def test_dino_cls_rows():

@@ -227,10 +227,11 @@ def test_frame_parallel_equals_single_gpu(world):
         assert abs(loss - float(ref.loss_metrics.loss)) < 1e-6
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("bf16", 6e-2)])
-def test_training_gradients_match_oracle_autograd(precision, tol):
+@pytest.mark.parametrize("precision,tol,drop", [("fp32", 2e-3, 0.0), ("bf16", 6e-2, 0.0), ("fp32", 2e-3, 0.25)])
+def test_training_gradients_match_oracle_autograd(precision, tol, drop):
     """forward_backward (hand-written HIP backward) vs torch autograd through the CPU oracle: loss, pcd_moved and the
-    gradient of all 196-equivalent trainable tensors of the tiny config."""
+    gradient of all 196-equivalent trainable tensors of the tiny config.  drop > 0: training-mode pos_drop on the
+    video tokens (reference Pcd_motion.py:490), the oracle being handed the same keep-mask."""
     import motion324_amd as m
     from motion324_amd import synth, training
     from oracle import ref_forward as oracle
@@ -242,11 +243,15 @@ def test_training_gradients_match_oracle_autograd(precision, tol):
     for k, v in sd.items():
         if not k.startswith("image_encoder."):
             v.requires_grad_(True)
-    ref = oracle.forward(sd, oracle.to_torch(s_np), frames=dm.frames)
+    model.drop_rate = drop
+    g = model.num_patches_h
+    keep = torch.from_numpy(synth.dropout_keep(99, B * T * g * g * dm.d, drop)) if drop else None
+    ref = oracle.forward(sd, oracle.to_torch(s_np), frames=dm.frames, drop=(keep, drop) if drop else None)
     ref["loss"].backward()
     m.set_precision(precision)
     try:
-        loss, out, G = training.forward_backward(model, {k: torch.from_numpy(v).cuda() for k, v in s_np.items()})
+        loss, out, G = training.forward_backward(model, {k: torch.from_numpy(v).cuda() for k, v in s_np.items()},
+                                                 drop_seed=99)
         torch.cuda.synchronize()
     finally:
         m.set_precision(None)
@@ -262,6 +267,30 @@ def test_training_gradients_match_oracle_autograd(precision, tol):
     print(f"[train grads {precision}] worst: " + "  ".join(f"{k}={v:.2e}" for k, v in worst))
     assert len(errs) == sum(1 for k, v in sd.items() if v.requires_grad)
     assert worst[0][1] < tol, worst
+
+
+def test_training_mode_dropout_is_seeded_by_torch_and_off_in_eval():
+    """pos_drop: p = transformer.drop_rate in train(), identity in eval(); the mask follows torch.manual_seed."""
+    from motion324_amd import synth
+    model, dm = build("tiny")
+    model.drop_rate = 0.1
+    s = {k: torch.from_numpy(v).cuda() for k, v in synth.synth_inputs(1, 3, 20, 50, 64, seed=4, with_target=True).items()}
+    with torch.no_grad():
+        model.eval()
+        e1, e2 = model(s).pcd_moved.clone(), model(s).pcd_moved.clone()
+        model.train()
+        torch.manual_seed(5); t1 = model(s).pcd_moved.clone()
+        torch.manual_seed(5); t2 = model(s).pcd_moved.clone()
+        torch.manual_seed(6); t3 = model(s).pcd_moved.clone()
+    assert torch.equal(e1, e2) and torch.equal(t1, t2)
+    assert not torch.equal(t1, t3) and not torch.equal(t1, e1)
+    assert rel_err(t1, e1) < 0.5             # a perturbation, not garbage
+    torch.manual_seed(5)
+    l1 = float(model(s).loss_metrics.loss)   # grad-enabled training path draws the same seed -> same forward
+    with torch.no_grad():
+        torch.manual_seed(5)
+        l2 = float(model(s).loss_metrics.loss)
+    assert l1 == pytest.approx(l2, rel=1e-6)
 
 
 def test_autograd_wrapper_and_three_optimizer_steps_match_torch_on_oracle():
