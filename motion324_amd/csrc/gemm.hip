@@ -13,6 +13,7 @@
 // Pipeline: global -> registers (issued before the MFMAs of the current tile) -> LDS (after them),
 // double-buffered LDS, one barrier per K-tile.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -152,10 +153,8 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], TOUT* 
 }
 
 
-// Epilogue for SWAPPED accumulators: lane = output row m (32 rows per block), registers = columns
-// n = 8*g + 4*hi + e (g = r >> 2, e = r & 3): every lane owns runs of 4 consecutive columns, so residual
-// reads are float4 loads and stores are 16-byte (fp32) / 8-byte (bf16) -- 4x fewer memory instructions
-// than the column-per-lane layout, all residual loads of a block in flight together.  Needs N % 4 == 0.
+// SWAPPED accumulators (all LDS-DMA kernels): lane = output row m (32 rows per block), registers = columns
+// n = 8*g + 4*hi + e (g = r >> 2, e = r & 3): every lane owns runs of 4 consecutive columns.  Needs N % 4 == 0.
 template <typename TOUT>
 __device__ __forceinline__ void store4_out(TOUT* p, float a, float b, float c, float d);
 template <>
@@ -167,74 +166,77 @@ __device__ __forceinline__ void store4_out<bf16_t>(bf16_t* p, float a, float b, 
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
 }
 
+// LDS-transposed epilogue.  The swapped accumulator layout gives a lane 4-column runs of ONE row, so a direct store
+// instruction touches 32 different rows with 16-32 bytes each: the texture path handles one cache line per cycle and
+// the epilogue of a K = 768 GEMM cost as much as half its main loop.  Here every wave bounces each 32 x 64 block
+// through a wave-private LDS scratch (32 rows x 68 floats: the 4-float pad makes both the b128 writes -- 8 lanes = 8
+// rows -- and the row-contiguous b128 reads conflict-free) and then works on rows: 16 lanes cover the 64 columns of a
+// row, so bias / gamma are per-lane constants, residual reads and output stores are whole 128/256-byte lines.
+// DS operations of one wave execute in order, so no barrier or wait is needed between the write and read passes.
+constexpr int EP_LD = 68;
+constexpr int EP_WAVE_FLOATS = 32 * EP_LD;     // 8704 bytes per wave
+
 template <typename TOUT, int ACT, int RES, int MI>
-__device__ __forceinline__ void store_tile_out_t(const f32x16 (&acc)[MI][2], TOUT* C, long ldc, int M, int N, int mw, int nw,
-                                                 int l31, int hi, const Epilogue& ep) {
+__device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float* scr, TOUT* C, long ldc, int M, int N, int mw,
+                                               int nw, int lane, const Epilogue& ep) {
     const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
     const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
     const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
-    const bool gelu = ACT == 1;
-    const bool has_gamma = ep.gamma != nullptr;
-    // column of run (j, g): n = nw + 32 j + 8 g + 4 hi; clamped copy for the (unconditional) loads
-    int ncl[2][4];
-    float4 bi[2][4];
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int rr = lane >> 4, cc = (lane & 15) * 4;
+    const int n = nw + cc;
+    const bool nok = n < N;                    // N % 4 == 0: a lane's 4 columns are all in or all out
+    const int ncl = min(n, N - 4);
+    const float4 bi = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + ncl) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ga = ep.gamma ? *reinterpret_cast<const float4*>(ep.gamma + ncl) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float* wr = scr + l31 * EP_LD + 4 * hi;
+    const float* rd = scr + rr * EP_LD + cc;
+    // interior tiles (all but the last row / column of tiles) take a copy without per-store predicates, so the 8 LDS
+    // reads and the 8 stores of a block are scheduled as batches instead of read-wait-store chains
+    auto body = [&](auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < MI; ++i) {
+            const int mb = mw + i * 32 + rr;       // row of pass p: mb + 4 p
+            float4 res[8];
+            if (has_res) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) ncl[j][g] = min(nw + j * 32 + 8 * g + 4 * hi, N - 4);
-    if (ep.bias) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bi[j][g] = *reinterpret_cast<const float4*>(ep.bias + ncl[j][g]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bi[j][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = mw + i * 32 + l31;
-        const bool mok = m < M;
-        long orow = m;
-        if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
-        TOUT* crow = C + orow * ldc;
-        // every residual read of this row block is issued before anything is consumed
-        float4 res[2][4];
-        if (has_res) {
-            int mr = mok ? m : M - 1;
-            if (res_mod) mr %= ep.res_rows;
-            const float* rrow = ep.residual + (long)mr * ep.ldr;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) res[j][g] = *reinterpret_cast<const float4*>(rrow + ncl[j][g]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) res[j][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nw + j * 32 + 8 * g + 4 * hi;
-                float v0 = acc[i][j][g * 4 + 0] + bi[j][g].x, v1 = acc[i][j][g * 4 + 1] + bi[j][g].y;
-                float v2 = acc[i][j][g * 4 + 2] + bi[j][g].z, v3 = acc[i][j][g * 4 + 3] + bi[j][g].w;
-                if (gelu) {
-                    v0 = apply_gelu<TOUT>(v0); v1 = apply_gelu<TOUT>(v1);
-                    v2 = apply_gelu<TOUT>(v2); v3 = apply_gelu<TOUT>(v3);
+                for (int p = 0; p < 8; ++p) {
+                    int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
+                    if (res_mod) mr %= ep.res_rows;
+                    res[p] = *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
                 }
-                if (has_gamma) {   // LayerScale (DINO only): L1-resident after the first row block
-                    const float4 ga = *reinterpret_cast<const float4*>(ep.gamma + ncl[j][g]);
-                    v0 *= ga.x; v1 *= ga.y; v2 *= ga.z; v3 *= ga.w;
-                }
-                v0 += res[j][g].x; v1 += res[j][g].y; v2 += res[j][g].z; v3 += res[j][g].w;
-                if (mok && n < N) store4_out<TOUT>(crow + n, v0, v1, v2, v3);
             }
-    }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            float4 v[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const float4*>(rd + p * 4 * EP_LD);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float4 x = v[p];
+                x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
+                if (ACT == 1) {
+                    x.x = apply_gelu<TOUT>(x.x); x.y = apply_gelu<TOUT>(x.y);
+                    x.z = apply_gelu<TOUT>(x.z); x.w = apply_gelu<TOUT>(x.w);
+                }
+                if (ep.gamma) { x.x *= ga.x; x.y *= ga.y; x.z *= ga.z; x.w *= ga.w; }
+                if (has_res) { x.x += res[p].x; x.y += res[p].y; x.z += res[p].z; x.w += res[p].w; }
+                const int m = mb + 4 * p;
+                if (!CHECK || (m < M && nok)) {
+                    long orow = m;
+                    if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
+                    store4_out<TOUT>(C + orow * ldc + n, x.x, x.y, x.z, x.w);
+                }
+            }
+        }
+    };
+    if (mw + MI * 32 <= M && nw + 64 <= N) body(std::false_type{});
+    else body(std::true_type{});
 }
 
 template <typename TIN, typename TOUT>
@@ -391,7 +393,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
         const unsigned char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
         mma_tile<TIN, true>(sa, sa + TILE_BYTES, arow0, brow0, hi, acc);
     }
-    store_tile_out_t<TOUT, ACT, RES, 2>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+    __syncthreads();                            // all waves are done reading the stages: reuse them as epilogue scratch
+    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 64,
+                                      n0 + wn * 64, lane, ep);
 }
 
 
@@ -475,7 +479,9 @@ __global__ __launch_bounds__(512, 2) void gemm_glds3_kernel(const TIN* __restric
         mma_tile<TIN, true>(sa, sa + BM3 * ROWB, arow0, brow0, hi, acc);
         stage = stage == 2 ? 0 : stage + 1;
     }
-    store_tile_out_t<TOUT, ACT, RES, 2>(acc, C, ldc, M, N, m0 + wm * 64, n0 + wn * 64, l31, hi, ep);
+    __syncthreads();
+    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 64,
+                                      n0 + wn * 64, lane, ep);
 }
 
 
@@ -575,7 +581,9 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
             }
         }
     }
-    store_tile_out_t<TOUT, ACT, RES, 4>(acc, C, ldc, M, N, m0 + wm * 128, n0 + wn * 64, l31, hi, ep);
+    __syncthreads();
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep);
 }
 
 
@@ -704,7 +712,182 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16_t* __restr
         M324_BARRIER();
     }
     if (wm == 0) M324_BARRIER();    // group A's matching extra barrier
-    store_tile_out_t<TOUT, ACT, RES, 4>(acc, C, ldc, M, N, m0 + wm * 128, n0 + wn * 64, l31, hi, ep);
+    __syncthreads();
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v7 / v8: software-pipelined LDS-DMA kernel (bf16).  Same 64-byte-row half-tile ring as v6, but ONE barrier per
+// half-tile and the overlap is done inside each wave: the fragments of k-step s+1 are fetched into a second register
+// set while the 8 MFMAs of k-step s run, and the LDS-DMA pieces of a later half-tile are issued between MFMAs, so a
+// wave keeps the matrix pipe fed by itself instead of relying on its SIMD partner's phase.
+//   WN = 4 (v7): 256 x 256 tile, 8 waves, 4-slot ring (128 KiB, one workgroup per CU); fragments of (h+1, step 0) are
+//               fetched before barrier h+1 (XPF), so MFMAs restart right after every barrier.
+//               barrier h guarantees half-tile h+1 landed; DMA of h+3 goes to the slot of h-1.
+//   WN = 2 (v8): 256 x 128 tile, 4 waves, 3-slot ring (72 KiB): TWO workgroups per CU, so one tile's prologue and
+//               epilogue (HBM-bound for fp32 residual outputs, VALU-bound for GELU) overlap the other's main loop.
+//               barrier h guarantees half-tile h landed; DMA of h+2 goes to the slot of h-1.
+//   WAR in both: the last fragment reads of half-tile h-1 are consumed by MFMAs issued before barrier h.
+template <typename TOUT, int ACT, int RES, int WN, int RING, bool XPF, int DBG = 0>
+__global__ __launch_bounds__(WN * 128, 2) void gemm_pipe_kernel(const bf16_t* __restrict__ A, long lda,
+                                                                const bf16_t* __restrict__ W, long ldw, TOUT* C, long ldc,
+                                                                int M, int N, int K, Epilogue ep, int ntn, int xcd_remap) {
+    constexpr int NW = 2 * WN, BNt = WN * 64;
+    constexpr int PARTA = 256 * ROWB6, PARTB = BNt * ROWB6, SLOT = PARTA + PARTB;
+    constexpr int PA = 16 / NW, PB = (BNt / 16) / NW, PPW = PA + PB;      // DMA pieces per wave per half-tile
+    static_assert(!XPF || RING == 4, "cross-barrier fragment prefetch needs the 4-slot ring");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lid = blockIdx.x;
+    if (xcd_remap & 1) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * 256, n0 = (lid % ntn) * BNt;
+    if constexpr ((DBG & 24) != 0) {   // lab: de-phase the CUs so that epilogue store bursts do not coincide
+        if (blockIdx.x < 256) {
+            const int ph = (DBG & 16) ? ((blockIdx.x >> 3) & 3) : 2 * ((blockIdx.x >> 3) & 1);
+            for (int i = 0; i < ph; ++i) { __builtin_amdgcn_s_sleep(127); }
+        }
+    }
+
+    const bf16_t* ga[PA];
+    const bf16_t* gb[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int r = (wave * PA + i) * 16 + (lane >> 2);
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int r = (wave * PB + i) * 16 + (lane >> 2);
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+    }
+    auto issue_a = [&](int h, int slot) {
+        unsigned char* sa = smem + slot * SLOT + wave * (PA * 1024);
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)h * 32), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int h, int slot) {
+        unsigned char* sb = smem + slot * SLOT + PARTA + wave * (PB * 1024);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)h * 32), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
+    };
+    auto issue_half = [&](int h, int slot) { issue_a(h, slot); issue_b(h, slot); };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int NH = K / 32;
+    const int aoff = lds_off6(wm * 128 + l31, hi), boff = PARTA + lds_off6(wn * 64 + l31, hi);   // k-step 1: ^ 32
+    bf16x8 fa[2][4], fb[2][2];
+    auto load_frags = [&](int set, int slot, int ks) {
+        const unsigned char* base = smem + slot * SLOT;
+        const int x = ks << 5;          // chunk + 2  ==  byte offset ^ 32 (the swizzle only touches bits 4-5)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(base + ((boff + j * 2048) ^ x));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(base + ((aoff + i * 2048) ^ x));
+    };
+    auto mma8 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+    };
+    // one MFMA, then one LDS read (6 per k-step), the remaining MFMAs back to back
+    // k-step schedules (sched_group_barrier: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read).  The 6 fragment reads of the
+    // next k-step ride on the first MFMAs (so they have landed when that k-step starts), the LDS-DMA pieces on the
+    // last ones.  LDS-DMA instructions also match the DS mask: they are emitted after the reads in program order.
+#define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    auto sched_reads_then_dma = [&](auto ndma) {
+        constexpr int D = decltype(ndma)::value;
+        static_assert(D >= 0 && D <= 4, "at most 4 DMA pieces per k-step");
+        if constexpr (D <= 2) {
+            M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+            M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+            M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+            if constexpr (D >= 1) { M324_SG(0x008, 1); M324_SG(0x020, 1); } else { M324_SG(0x008, 1); }
+            if constexpr (D >= 2) { M324_SG(0x008, 1); M324_SG(0x020, 1); } else { M324_SG(0x008, 1); }
+        } else {
+            M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x100, 2);
+            M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 1);
+            M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
+            if constexpr (D >= 4) { M324_SG(0x008, 1); M324_SG(0x020, 1); } else { M324_SG(0x008, 1); }
+            M324_SG(0x008, 1);
+        }
+    };
+    using std::integral_constant;
+#define M324_WAIT_PIECES(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+    // The steady state is branch-free: every iteration issues PPW pieces (past the end of K the last half-tile is
+    // fetched again into a free slot -- an L2 hit nobody reads), so the counted wait is always vmcnt(PPW).
+    constexpr int AHEAD = RING - 1;            // half-tiles issued ahead of the one being computed
+    for (int h = 0; h < AHEAD; ++h) issue_half(h < NH ? h : NH - 1, h);
+    if constexpr (XPF) {
+        M324_WAIT_PIECES(2 * PPW);             // half-tile 0 landed
+        M324_BARRIER();
+        load_frags(0, 0, 0);
+    }
+    int slot = 0;                               // h % RING
+    for (int h = 0; h < ((DBG & 64) ? 0 : NH); ++h) {
+        const int nslot = slot + 1 == RING ? 0 : slot + 1;
+        if constexpr (!(DBG & 4)) {
+            M324_WAIT_PIECES(PPW);              // XPF: half-tile h+1 landed; else: half-tile h landed (own pieces)
+            M324_BARRIER();
+        }
+        const int hn = h + AHEAD < NH ? h + AHEAD : NH - 1, fslot = slot == 0 ? RING - 1 : slot - 1;
+        if constexpr (XPF) {
+            if constexpr (!(DBG & 2)) load_frags(1, slot, 1);
+            if constexpr (!(DBG & 1)) issue_a(hn, fslot);
+            mma8(0);
+            sched_reads_then_dma(integral_constant<int, PA>{});
+            if constexpr (!(DBG & 2)) load_frags(0, nslot, 0);            // past the end: stale but valid LDS, never used
+            if constexpr (!(DBG & 1)) issue_b(hn, fslot);
+            mma8(1);
+            sched_reads_then_dma(integral_constant<int, PB>{});
+        } else {
+            load_frags(0, slot, 0);
+            M324_SG(0x100, 6);
+            load_frags(1, slot, 1);
+            issue_a(hn, fslot);
+            mma8(0);
+            sched_reads_then_dma(integral_constant<int, PA>{});
+            issue_b(hn, fslot);
+            mma8(1);
+            M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 6);
+        }
+        slot = nslot;
+    }
+    M324_WAIT_PIECES(0);                        // no LDS-DMA may outlive the workgroup
+    if constexpr ((DBG & 32) != 0) {            // lab: no epilogue (keep the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) C[0] = (TOUT)1;
+        return;
+    }
+#undef M324_WAIT_PIECES
+#undef M324_SG
+    M324_BARRIER();                             // every wave is done with the ring: reuse it as epilogue scratch
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep);
 }
 
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
@@ -722,8 +905,7 @@ static int xcd_remap() {
     return v;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v3 forces a variant (A/B measurements); otherwise the 8-wave 3-stage kernel
-// is used when its 256 x 128 tiles fill the 256 CUs about as well as the 128 x 128 tiles of v2 would.
+// Kernel choice.  M324_GEMM=v1|v2|v3|v5|v6|v7|v8 forces a variant (A/B measurements, tests).
 static int forced_variant() {      // read per call: lets one process A/B-toggle the variant
     const char* e = getenv("M324_GEMM");
     return (e && e[0] == 'v') ? atoi(e + 1) : 0;
@@ -732,15 +914,17 @@ static int forced_variant() {      // read per call: lets one process A/B-toggle
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
     const int f = forced_variant();
-    if (f >= 1 && f <= 6 && f != 4) return (f == 6 && a->in_dtype != M324_BF16) ? 5 : f;
-    // 256 x 256 tiles (v5) halve the LDS traffic per FLOP and double the work per barrier: fastest whenever the
-    // column count quantises (N % 256 == 0) and the tiles still fill most of the 256 CUs in whole rounds
+#ifdef M324_LAB
+    if (f >= 71 && f <= 199) return f;
+#endif
+    if (f >= 1 && f <= 8 && f != 4) return (f >= 6 && a->in_dtype != M324_BF16) ? 5 : f;
+    // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
+    // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
+    // CU) balance better.  Measured on the c2 shapes (tools/gemm_lab): v7 wins at >= 0.70 fill, v2 below.
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
-    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) return (a->in_dtype == M324_BF16 && a->K >= 96) ? 6 : 5;
-    const long t2 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM), t3 = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM3);
-    const double e2 = (double)t2 / (double)(((t2 + 511) / 512) * 512), e3 = (double)t3 / (double)(((t3 + 255) / 256) * 256);
-    return (t3 >= 128 && e3 >= e2 - 0.05) ? 3 : 2;
+    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.70) return (a->in_dtype == M324_BF16 && a->K >= 96) ? 7 : 5;
+    return 2;
 }
 
 template <typename TOUT, int ACT, int RES>
@@ -748,6 +932,30 @@ static void launch_stag(const m324_gemm_args* a, hipStream_t s, const Epilogue& 
     hipLaunchKernelGGL((gemm_stag_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
                        (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
                        ceil_div(a->N, BN5), xcd_remap());
+}
+
+template <typename TOUT, int ACT, int RES>
+static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
+#ifdef M324_LAB
+#define M324_DBG_LAUNCH(D)                                                                                                  \
+    if (variant == 70 + D) {                                                                                                \
+        hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, 0, 0, 4, 4, true, D>), dim3(ceil_div(a->N, 256) * ceil_div(a->M, 256)),    \
+                           dim3(512), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc,  \
+                           a->M, a->N, a->K, ep, ceil_div(a->N, 256), xcd_remap());                                         \
+        return;                                                                                                             \
+    }
+    M324_DBG_LAUNCH(1) M324_DBG_LAUNCH(2) M324_DBG_LAUNCH(3) M324_DBG_LAUNCH(4) M324_DBG_LAUNCH(5) M324_DBG_LAUNCH(6) M324_DBG_LAUNCH(7)
+    M324_DBG_LAUNCH(8) M324_DBG_LAUNCH(16) M324_DBG_LAUNCH(32) M324_DBG_LAUNCH(64) M324_DBG_LAUNCH(96)
+#undef M324_DBG_LAUNCH
+#endif
+    if (variant == 7)
+        hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES, 4, 4, true>), dim3(ceil_div(a->N, 256) * ceil_div(a->M, 256)),
+                           dim3(512), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc,
+                           a->M, a->N, a->K, ep, ceil_div(a->N, 256), xcd_remap());
+    else
+        hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES, 2, 3, false>), dim3(ceil_div(a->N, 128) * ceil_div(a->M, 256)),
+                           dim3(256), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc,
+                           a->M, a->N, a->K, ep, ceil_div(a->N, 128), xcd_remap());
 }
 
 template <typename TIN, typename TOUT>
@@ -766,7 +974,9 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
         const int ntm3 = ceil_div(a->M, BM3);
 #define M324_GLDS(ACT, RES)                                                                                              \
     do {                                                                                                                 \
-        if (variant == 6)                                                                                                \
+        if (variant >= 7)                                                                                                \
+            launch_pipe<TOUT, ACT, RES>(a, s, ep, variant);                                                             \
+        else if (variant == 6)                                                                                           \
             launch_stag<TOUT, ACT, RES>(a, s, ep);                                                                      \
         else if (variant == 5)                                                                                           \
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \

@@ -97,6 +97,43 @@ def test_gemm_inplace_residual(dtype):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
+@pytest.mark.parametrize("variant", ["v1", "v2", "v3", "v5", "v6", "v7", "v8"])
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("K", [64, 192, 832])
+def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
+    """M324_GEMM=vN (read per call) forces one kernel schedule; each must handle ragged M / N tiles, a K shorter than
+    its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v6-v8 to v5.)"""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    monkeypatch.setenv("M324_GEMM", variant)
+    M, N = 3 * 230, 328
+    a, w = _q(_rand((M, K), 11), dtype), _q(_rand((N, K), 12, 0.1), dtype)
+    bias, gamma, res = _rand((N,), 13), 1 + 0.1 * _rand((N,), 14), _rand((230, N), 15)
+    v = a.double() @ w.double().T + bias.double()
+    g = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+    # (1) plain bias + GELU, output in the operand dtype
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), out, bias=bias.to(DEV), act=ACT_GELU)
+    assert rel_err(out.float(), g) < TOL[dtype]
+    # (2) gamma + broadcast residual + row remap, fp32 out
+    gin, gout, off = 230, 233, 1
+    out2 = torch.zeros((3 * 233, N), dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), out2, bias=bias.to(DEV), gamma=gamma.to(DEV), residual=res.to(DEV),
+             res_rows=230, row_map=(gin, gout, off))
+    ref = torch.zeros(3 * 233, N, dtype=torch.float64)
+    rows = torch.arange(M)
+    ref[(rows // gin) * gout + rows % gin + off] = v * gamma.double() + res.double().repeat(3, 1)
+    assert rel_err(out2, ref) < 2e-5
+    mask = torch.ones(3 * 233, dtype=torch.bool)
+    mask[(rows // gin) * gout + rows % gin + off] = False
+    assert float(out2.cpu()[mask].abs().max()) == 0.0
+    # (3) in-place residual stream
+    x0 = _rand((M, N), 16)
+    x = x0.clone().to(DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), x, residual=x)
+    assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
+
+
 def test_gemm_rejects_bad_k():
     ops = _ops()
     from motion324_amd.lib import M324Error

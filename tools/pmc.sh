@@ -5,4 +5,4 @@ ctrs=()
 while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
 shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --pmc "${ctrs[@]}" -d "$out" -o pmc --output-format csv -- python3 "$@"
+timeout 900 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" -d "$out" -o pmc --output-format csv -- python3 "$@"
