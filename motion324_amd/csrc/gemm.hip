@@ -48,6 +48,41 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * phi;
 }
 
+// Two GELUs per instruction stream for the bf16 epilogue: erf(z) = z P(z^2) on |z| <= 3 (odd minimax polynomial, 9
+// coefficients, |erf error| <= 1.7e-5; beyond the clamp erf(3) = 0.99998 stands in for 1), evaluated with packed fp32
+// FMAs (v_pk_fma_f32) and no transcendental.  |GELU error| <= 7e-5 absolute -- below the bf16 rounding step of every
+// output larger than 0.02 -- at about a third of the issue slots of the rcp/exp form above.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v gelu_poly2(f32x2v x) {
+    f32x2v z = x * 0.70710678118654752440f;
+    z.x = __builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f);
+    z.y = __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f);
+    const f32x2v t = z * z;
+    f32x2v p = (f32x2v)(4.074096087e-08f);
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-1.944782217e-06f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.105993727e-05f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-5.110323815e-04f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.235408041e-03f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-2.510281415e-02f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.110792751e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-3.753148415e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.128268421e+00f));
+    const f32x2v hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, z * p, hx);
+}
+
+template <typename TOUT>
+__device__ __forceinline__ void apply_gelu4(float4& v) {
+    if constexpr (sizeof(TOUT) == 2) {
+        f32x2v a = {v.x, v.y}, b = {v.z, v.w};
+        a = gelu_poly2(a);
+        b = gelu_poly2(b);
+        v = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+        v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+    }
+}
+
 template <typename TOUT>
 __device__ __forceinline__ float apply_gelu(float v) {
     if constexpr (sizeof(TOUT) == 2) return gelu_fast(v);
@@ -220,10 +255,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             for (int p = 0; p < 8; ++p) {
                 float4 x = v[p];
                 x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
-                if (ACT == 1) {
-                    x.x = apply_gelu<TOUT>(x.x); x.y = apply_gelu<TOUT>(x.y);
-                    x.z = apply_gelu<TOUT>(x.z); x.w = apply_gelu<TOUT>(x.w);
-                }
+                if (ACT == 1) apply_gelu4<TOUT>(x);
                 if (ep.gamma) { x.x *= ga.x; x.y *= ga.y; x.z *= ga.z; x.w *= ga.w; }
                 if (has_res) { x.x += res[p].x; x.y += res[p].y; x.z += res[p].z; x.w += res[p].w; }
                 const int m = mb + 4 * p;
@@ -890,6 +922,108 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_pipe_kernel(const bf16_t* __
                                       n0 + wn * 64, lane, ep);
 }
 
+// ------------------------------------------------------------------------------------------------
+// v9: skinny GEMM for M <= 64 (the 64 latent tokens of the shape encoder: every projection of the 4 point-transformer
+// blocks and of the encoder cross-attention at B = 1).  A 128 x 128 tile kernel runs these on N / 128 = 6..24 CUs with the
+// whole K loop serial (17-48 us for 0.1-0.3 GFLOP).  Here a workgroup owns 32 output columns, its 8 waves split K in
+// interleaved 64-element chunks, operands go global -> registers directly in MFMA fragment order (no LDS: every
+// element is used once per workgroup), and the eight partial 64 x 32 blocks are summed through LDS in a fixed order.
+// k-assignment inside a chunk: lane half `hi` owns k = 32 hi .. 32 hi + 31 (four 16-byte fragments = four MFMA steps);
+// A and W use the same assignment, so every k is contracted exactly once (only the summation order differs from the
+// tile kernels).
+constexpr int SK_LD = 36;      // floats per partial row: 32 + 4 pad (conflict-free b128 writes: 8 lanes = 8 rows)
+constexpr int SK_WAVES = 8;
+
+template <typename TOUT, int ACT>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                          long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep) {
+    __shared__ __attribute__((aligned(16))) float part[SK_WAVES * 64 * SK_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const bf16_t* a0 = A + (long)min(l31, M - 1) * lda + hi * 32;
+    const bf16_t* a1 = A + (long)min(32 + l31, M - 1) * lda + hi * 32;
+    const bf16_t* w0 = W + (long)min(n0 + l31, N - 1) * ldw + hi * 32;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int nchunk = K / 64;
+    bf16x8 fa[3][2][4], fw[3][4];
+    auto load = [&](int set, int c) {
+        const long k = (long)c * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            fw[set][s] = *reinterpret_cast<const bf16x8*>(w0 + k + s * 8);
+            fa[set][0][s] = *reinterpret_cast<const bf16x8*>(a0 + k + s * 8);
+            fa[set][1][s] = *reinterpret_cast<const bf16x8*>(a1 + k + s * 8);
+        }
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][s], fa[set][i][s], acc[i], 0, 0, 0);
+    };
+    // three chunks of this wave in flight (the kernel is latency-bound: 24-96 workgroups stream all of W);
+    // the trip is unrolled by 3 so that the register sets rotate without dynamic indexing
+    constexpr int ST = SK_WAVES;
+    int c = wave;
+    if (c < nchunk) load(0, c);
+    if (c + ST < nchunk) load(1, c + ST);
+    for (; c < nchunk; c += 3 * ST) {
+        if (c + 2 * ST < nchunk) load(2, c + 2 * ST);
+        mma(0);
+        if (c + ST < nchunk) {
+            if (c + 3 * ST < nchunk) load(0, c + 3 * ST);
+            mma(1);
+        }
+        if (c + 2 * ST < nchunk) {
+            if (c + 4 * ST < nchunk) load(1, c + 4 * ST);
+            mma(2);
+        }
+    }
+    // partial blocks -> LDS ([wave][row][col], swapped accumulator layout: lane = row, registers = 4-column runs)
+    float* mine = part + wave * 64 * SK_LD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(mine + (i * 32 + l31) * SK_LD + 8 * g + 4 * hi) =
+                make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+    __syncthreads();
+    // thread t: row t / 8, columns (t % 8) * 4 .. + 3; fixed summation order wave 0..7
+    const int row = tid >> 3, cc = (tid & 7) * 4;
+    float4 x = *reinterpret_cast<const float4*>(part + row * SK_LD + cc);
+#pragma unroll
+    for (int w = 1; w < SK_WAVES; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(part + (w * 64 + row) * SK_LD + cc);
+        x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+    }
+    const int n = n0 + cc;
+    if (row >= M || n >= N) return;            // N % 4 == 0
+    long orow = row;
+    if (ep.row_gin > 0) orow = (long)(row / ep.row_gin) * ep.row_gout + (row % ep.row_gin) + ep.row_off;
+    const int rrow = (ep.res_rows > 0 && ep.res_rows < M) ? row % ep.res_rows : row;
+    if (ep.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
+        x.x += b.x; x.y += b.y; x.z += b.z; x.w += b.w;
+    }
+    if (ACT == 1) apply_gelu4<TOUT>(x);
+    if (ep.gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(ep.gamma + n);
+        x.x *= g.x; x.y *= g.y; x.z *= g.z; x.w *= g.w;
+    }
+    if (ep.residual) {
+        const float4 r = *reinterpret_cast<const float4*>(ep.residual + (long)rrow * ep.ldr + n);
+        x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+    }
+    store4_out<TOUT>(C + orow * ldc + n, x.x, x.y, x.z, x.w);
+}
+
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
 static bool vec_ok(const m324_gemm_args* a) {
     const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
@@ -918,6 +1052,7 @@ static int pick_variant(const m324_gemm_args* a) {
     if (f >= 71 && f <= 199) return f;
 #endif
     if (f >= 1 && f <= 8 && f != 4) return (f >= 6 && a->in_dtype != M324_BF16) ? 5 : f;
+    if (a->M <= 64 && a->in_dtype == M324_BF16 && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
     // CU) balance better.  Measured on the c2 shapes (tools/gemm_lab): v7 wins at >= 0.70 fill, v2 below.
@@ -968,6 +1103,13 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
     if (variant == 1) {
         hipLaunchKernelGGL((gemm_kernel<TIN, TOUT>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda, (const TIN*)a->W,
                            a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
+    } else if (variant == 9) {
+        if (a->act == M324_ACT_GELU)
+            hipLaunchKernelGGL((gemm_skinny_kernel<TOUT, 1>), dim3(ceil_div(a->N, 32)), dim3(512), 0, s, (const bf16_t*)a->A,
+                               a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
+        else
+            hipLaunchKernelGGL((gemm_skinny_kernel<TOUT, 0>), dim3(ceil_div(a->N, 32)), dim3(512), 0, s, (const bf16_t*)a->A,
+                               a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
     } else {
         const int res = !a->residual && a->row_gin <= 0 ? 0
                         : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;

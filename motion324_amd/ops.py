@@ -111,7 +111,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
         raise L.M324Error(f"gemm: out{tuple(out.shape)} too small for {need} x {N}")
     args.row_gin, args.row_gout, args.row_off = gin, gout, off
     esz = a.element_size()
-    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, esz * (M * K + N * K) + out.element_size() * M * N):
+    tag = f"M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}{' gamma' if gamma is not None else ''}" \
+          f"{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}"
+    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, esz * (M * K + N * K) + out.element_size() * M * N, tag):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     return out
 
@@ -197,7 +199,7 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     scale = 64 ** -0.5 if scale is None else scale
     esz = Q.element_size()
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
-              esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq)):
+              esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq), f"B={B} H={H} Lq={Lq} Lk={Lk}"):
         L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, int(prescaled), _p(lse),
                                         code_of(Q.dtype), _stream()), "m324_attention")
     return out

@@ -16,7 +16,7 @@ _active: Optional["Recorder"] = None
 
 class Recorder:
     def __init__(self):
-        self.items: List[Tuple[str, float, float, torch.cuda.Event, torch.cuda.Event]] = []
+        self.items: List[Tuple[str, float, float, torch.cuda.Event, torch.cuda.Event, str]] = []
 
     def __enter__(self):
         global _active
@@ -30,7 +30,7 @@ class Recorder:
     def summary(self) -> Dict[str, dict]:
         """kernel class -> {launches, total_ms, avg_ms, flops, bytes} (call after torch.cuda.synchronize())."""
         acc = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
-        for name, flops, nbytes, e0, e1 in self.items:
+        for name, flops, nbytes, e0, e1, _tag in self.items:
             a = acc[name]
             a["launches"] += 1
             a["total_ms"] += e0.elapsed_time(e1)
@@ -41,12 +41,23 @@ class Recorder:
         return dict(acc)
 
 
-class span:
-    """with span(name, flops, bytes): <one C-ABI launch>"""
-    __slots__ = ("name", "flops", "nbytes", "e0")
+    def by_tag(self) -> Dict[Tuple[str, str], dict]:
+        """(kernel class, tag) -> {launches, total_ms, flops}: per-shape breakdown for tuning."""
+        acc = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0.0})
+        for name, flops, _nbytes, e0, e1, tag in self.items:
+            a = acc[(name, tag)]
+            a["launches"] += 1
+            a["total_ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+        return dict(acc)
 
-    def __init__(self, name: str, flops: float, nbytes: float = 0.0):
-        self.name, self.flops, self.nbytes, self.e0 = name, flops, nbytes, None
+
+class span:
+    """with span(name, flops, bytes, tag): <one C-ABI launch>; `tag` (e.g. the GEMM shape) only refines by_tag()."""
+    __slots__ = ("name", "flops", "nbytes", "e0", "tag")
+
+    def __init__(self, name: str, flops: float, nbytes: float = 0.0, tag: str = ""):
+        self.name, self.flops, self.nbytes, self.e0, self.tag = name, flops, nbytes, None, tag
 
     def __enter__(self):
         if _active is not None:
@@ -58,4 +69,4 @@ class span:
         if self.e0 is not None and _active is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _active.items.append((self.name, self.flops, self.nbytes, self.e0, e1))
+            _active.items.append((self.name, self.flops, self.nbytes, self.e0, e1, self.tag))

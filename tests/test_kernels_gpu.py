@@ -134,6 +134,30 @@ def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 768, 3072), (64, 2304, 768), (37, 200, 64), (5, 36, 448)])
+def test_gemm_skinny_rows(M, N, K):
+    """M <= 64 in bf16 takes the split-K-over-waves kernel (the shape encoder's 64 latent tokens): ragged M and N,
+    1..48 chunks per wave, every epilogue stage, both output dtypes."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    dtype = torch.bfloat16
+    a, w = _q(_rand((M, K), 21), dtype), _q(_rand((N, K), 22, 0.05), dtype)
+    bias, gamma, res = _rand((N,), 23), 1 + 0.1 * _rand((N,), 24), _rand((M, N), 25)
+    v = a.double() @ w.double().T + bias.double()
+    g = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), out, bias=bias.to(DEV), act=ACT_GELU)
+    assert rel_err(out.float(), g) < TOL[dtype]
+    out2 = torch.zeros((M + 3, N), dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), out2, bias=bias.to(DEV), gamma=gamma.to(DEV), residual=res.to(DEV),
+             row_map=(M, M, 3))
+    assert rel_err(out2[3:], v * gamma.double() + res.double()) < 2e-5
+    assert float(out2[:3].abs().max()) == 0.0
+    x = res.clone().to(DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), x, residual=x)
+    assert rel_err(x, res.double() + a.double() @ w.double().T) < 1e-5
+
+
 def test_gemm_rejects_bad_k():
     ops = _ops()
     from motion324_amd.lib import M324Error
