@@ -41,8 +41,11 @@ constexpr int ASTAGE = 16384;   // K tile (8 KiB) + Vt tile (8 KiB)
 // NQ: 32-row query blocks per wave (1 or 2).  With NQ = 2 every K / Vt fragment read from LDS feeds two
 // MFMAs, a wave issues 32 MFMAs per barrier instead of 16, and the two blocks' softmax chains are
 // independent, so the scheduler can run one block's exp2 / pack work under the other block's MFMAs.
-template <bool PRESCALED, int NQ>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
+// NWV: waves per workgroup (4 or 8).  Eight waves = 256 queries share every K / Vt tile, which halves the LDS-DMA
+// pieces per FLOP (the texture path is ~90 % busy at four waves) and, for the 10 368-token global attention, turns
+// 972 workgroups on 768 slots (two rounds, the second a quarter full) into 492 on 256 slots (1.92 rounds).
+template <bool PRESCALED, int NQ, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
                                                         int Lkp, float scale_log2e, float* __restrict__ lse) {
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = (blockIdx.x * NW + wave) * (QW * NQ);
+    const int q0 = (blockIdx.x * NWV + wave) * (QW * NQ);
 
     const bf16_t* Qh = Q + (long)b * q_bstride + (long)h * Lq * 64;
     const bf16_t* Kh = K + ((long)b * H + h) * (long)Lk * 64;
@@ -70,23 +73,32 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         }
     }
 
-    // LDS-DMA staging.  A wave-instruction fills 8 tile rows (1 KiB); wave w moves row groups 2w, 2w+1 of the
-    // K tile and of the Vt tile.  Lane l fills row r = 8g + (l >> 3), slot l & 7, which holds chunk
-    // (l & 7) ^ ((r >> 1) & 7).  K rows past Lk are clamped (their scores are masked); Vt is zero padded.
-    const int srow0 = (wave * 2) * 8 + (lane >> 3), srow1 = srow0 + 8;
-    const int sc0 = ((lane & 7) ^ ((srow0 >> 1) & 7)) * 8, sc1 = ((lane & 7) ^ ((srow1 >> 1) & 7)) * 8;
-    const bf16_t* gv0 = Vh + (long)srow0 * Lkp + sc0;
-    const bf16_t* gv1 = Vh + (long)srow1 * Lkp + sc1;
+    // LDS-DMA staging.  A wave-instruction fills 8 tile rows (1 KiB); the 8 row groups of the K tile and of the Vt
+    // tile are dealt to the waves (NWV = 4: groups 2w, 2w+1; NWV = 8: group w).  Lane l fills row r = 8g + (l >> 3),
+    // slot l & 7, which holds chunk (l & 7) ^ ((r >> 1) & 7).  K rows past Lk are clamped (their scores are masked);
+    // Vt is zero padded.
+    constexpr int GPW = 8 / NWV;                 // row groups per wave per operand
+    constexpr int PPT = 2 * GPW;                 // LDS-DMA pieces per wave per tile
+    int srow[GPW], scol[GPW];
+    const bf16_t* gv[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        srow[i] = (wave * GPW + i) * 8 + (lane >> 3);
+        scol[i] = ((lane & 7) ^ ((srow[i] >> 1) & 7)) * 8;
+        gv[i] = Vh + (long)srow[i] * Lkp + scol[i];
+    }
     auto issue_tile = [&](int t) {
         const int kv0 = t * KV;
-        unsigned char* sk = smem + (t % 3) * ASTAGE + wave * 2048;
+        unsigned char* sk = smem + (t % 3) * ASTAGE + wave * (GPW * 1024);
         unsigned char* sv = sk + 8192;
-        const bf16_t* gk0 = Kh + (long)min(kv0 + srow0, Lk - 1) * 64 + sc0;
-        const bf16_t* gk1 = Kh + (long)min(kv0 + srow1, Lk - 1) * 64 + sc1;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t*)gk0, (lds_ptr_t*)sk, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t*)gk1, (lds_ptr_t*)(sk + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gv0 + kv0), (lds_ptr_t*)sv, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gv1 + kv0), (lds_ptr_t*)(sv + 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const bf16_t* gk = Kh + (long)min(kv0 + srow[i], Lk - 1) * 64 + scol[i];
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)gk, (lds_ptr_t*)(sk + i * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < GPW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gv[i] + kv0), (lds_ptr_t*)(sv + i * 1024), 16, 0, 0);
     };
 
     f32x16 o[NQ][2];
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     for (int t = 0; t < nt; ++t) {
         // tile t landed (this wave's 4 pieces; tile t+1's may still fly), then the barrier publishes every
         // wave's pieces and retires all reads of the stage that tile t+2 is about to overwrite
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -632,18 +644,21 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         // NQ = 2 (two query blocks per wave) measured slower than NQ = 1 on MI355X (254 VGPRs -> one wave per
         // SIMD); it stays selectable for experiments only.
         const bool nq2 = getenv("M324_ATTN_NQ2") != nullptr && Lq >= 1024;
-        dim3 g2(ceil_div(Lq, nq2 ? 2 * QB : QB), H, B);
+        // eight waves per workgroup for long query sets (M324_ATTN_NW=4|8 forces; read per call for A/B runs)
+        const char* fnw = getenv("M324_ATTN_NW");
+        const bool w8 = !nq2 && (fnw ? atoi(fnw) == 8 : (Lq >= 2048 && Lk >= 512));
+        dim3 g2(ceil_div(Lq, nq2 ? 2 * QB : (w8 ? 2 * QB : QB)), H, B);
         // Co-residency: the NQ = 1 kernel fits 3 workgroups per CU (168 VGPRs, 32 KiB LDS).  Interleaved A/B on
         // MI355X: 3 per CU beats 2 per CU (422 vs 453 us on the 10 368-token global attention) even though the
         // grid then ends in a partly filled round -- latency hiding wins over round quantisation.
         // M324_ATTN_OCC=2 pads the LDS allocation to force two per CU (experiments only).
         const char* focc = getenv("M324_ATTN_OCC");
         const unsigned pad = (focc && atoi(focc) == 2) ? 24 * 1024 : 0;
-#define M324_ATTN(PS, NQ)                                                                                                \
-    hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ>), g2, dim3(256), pad, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K, \
-                       (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse)
-        if (q_prescaled) { if (nq2) M324_ATTN(true, 2); else M324_ATTN(true, 1); }
-        else { if (nq2) M324_ATTN(false, 2); else M324_ATTN(false, 1); }
+#define M324_ATTN(PS, NQ, NWV)                                                                                          \
+    hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ, NWV>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,         \
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse)
+        if (q_prescaled) { if (nq2) M324_ATTN(true, 2, 4); else if (w8) M324_ATTN(true, 1, 8); else M324_ATTN(true, 1, 4); }
+        else { if (nq2) M324_ATTN(false, 2, 4); else if (w8) M324_ATTN(false, 1, 8); else M324_ATTN(false, 1, 4); }
 #undef M324_ATTN
     } else if (dtype == M324_F32) {
         M324_REQUIRE(ldo % 4 == 0, "m324_attention: ldo misaligned");
