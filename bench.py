@@ -154,6 +154,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = frames_per_step * args.steps / dt
         summ = rec.summary()
+        stages = {k: summ.pop(k) for k in list(summ) if k.startswith("stage:")}
         dom = max(summ, key=lambda k: summ[k]["total_ms"])
         d = summ[dom]
         peak = PEAK_BF16_TFLOPS if dom.endswith("bf16") else PEAK_F32_TFLOPS
@@ -186,6 +187,13 @@ def main():
             "end_to_end_frac_of_bf16_peak": round(flops * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roof,
         }
+        blk = stages.get("stage:decoder_cross_attn_block")
+        if blk:        # north_star target: >= 40 % of the dense bf16 MFMA peak on this block (reference FLOP count)
+            bms = blk["total_ms"] / args.steps
+            line["decoder_cross_attn_block"] = {
+                "ms_per_step": round(bms, 3), "algorithmic_gflop": round(blk["flops"] / args.steps / 1e9, 1),
+                "tflops": round(blk["flops"] / args.steps / (bms * 1e-3) / 1e12, 1),
+                "frac_of_bf16_peak": round(blk["flops"] / args.steps / (bms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
         if not args.no_cpu_baseline and world == 1:
             cb, ref = cpu_baseline(sd, sample_np, w["frames"])
             line["cpu_baseline"] = cb

@@ -14,6 +14,9 @@ There is no CPU path: inputs must live on a HIP device and libm324.so must be bu
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 from typing import Dict
 
 import torch
@@ -26,6 +29,7 @@ from .image_encoder import DINO_EPS, DinoEncoder
 from .lib import ACT_GELU, M324Error
 from .loss import MSELossComputer
 from .prepared import Prepared, bump_generation, compute_dtype, pad_k
+from .timing import span
 from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
 DECODE_ROWS = 1 << 17     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
@@ -68,6 +72,18 @@ def resize_pos_embed(posemb, src_shape, target_shape):
     posemb = posemb.reshape(1, src_shape[0], src_shape[1], src_shape[2], -1).permute(0, 4, 1, 2, 3)
     posemb = F.interpolate(posemb, size=target_shape, mode="trilinear", align_corners=False)
     return posemb.permute(0, 2, 3, 4, 1).reshape(1, target_shape[0] * target_shape[1] * target_shape[2], -1)
+
+
+# inference only: run the shape encoder on a side stream (M324_OVERLAP=0 disables, for A/B measurements)
+OVERLAP_SHAPE_ENCODER = os.environ.get("M324_OVERLAP", "1") != "0"
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[idx]
 
 
 class _TrainStepFunction(torch.autograd.Function):
@@ -232,17 +248,24 @@ class Motion_Latent_Model(nn.Module):
         C, K = self.embed_dim, self.num_learnable_tokens
         S = sample["ref_shape_pcd"].shape[1]
 
-        # A. shape encoder (reference :456-464)
-        pts = self._point_features(P, self._f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
-                                   self._f32c(sample["ref_shape_normals"]), self._f32c(sample["ref_shape_rgbs"]))
-        query = P.f32(self.learnable_tokens).reshape(K, C).repeat(B, 1)          # fp32 [B*K, C]
-        mesh = self.encoder_cross_attn.run(P, query, pts, B, K, S)
-        if cap is not None:
-            cap["shape_point_feat"], cap["encoder_out"] = pts.clone(), mesh.clone()
-        for blk in self.points_transformer_blocks:
-            blk.run(P, mesh, B, K)
-        if cap is not None:
-            cap["mesh_feat"] = mesh.clone()
+        # A. shape encoder (reference :456-464).  Its ~60 launches work on B*64 latent rows (latency-bound, a few
+        # dozen workgroups each) and do not depend on the video, so they run on a second HIP stream underneath the
+        # image encoder's chip-filling GEMMs and join before the token assembly (fork/join is captured into the graph).
+        main_stream = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if OVERLAP_SHAPE_ENCODER and cap is None else None
+        if side is not None:
+            side.wait_stream(main_stream)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            pts = self._point_features(P, self._f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
+                                       self._f32c(sample["ref_shape_normals"]), self._f32c(sample["ref_shape_rgbs"]))
+            query = P.f32(self.learnable_tokens).reshape(K, C).repeat(B, 1)          # fp32 [B*K, C]
+            mesh = self.encoder_cross_attn.run(P, query, pts, B, K, S)
+            if cap is not None:
+                cap["shape_point_feat"], cap["encoder_out"] = pts.clone(), mesh.clone()
+            for blk in self.points_transformer_blocks:
+                blk.run(P, mesh, B, K)
+            if cap is not None:
+                cap["mesh_feat"] = mesh.clone()
 
         # B. image encoder (reference :466-475): resize + normalise + patchify + ViT, frozen
         video = sample["rgb_video"]
@@ -260,6 +283,10 @@ class Motion_Latent_Model(nn.Module):
         _, T, Hin, Win, _ = video.shape
         dino_x = self.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))
         Pn = self.num_patches_h * self.num_patches_w
+
+        if side is not None:                      # join: the assembly reads the latent tokens
+            main_stream.wait_stream(side)
+            mesh.record_stream(main_stream)
 
         # C. DINO final norm + pos-embed + token assembly + input LN in one pass (reference :477-510)
         enc = self.image_encoder.model
@@ -308,15 +335,21 @@ class Motion_Latent_Model(nn.Module):
         out = torch.empty((B, T, N, 3), dtype=torch.float32, device=dev)
         head_ln, head_fc1, head_fc2 = self.shared_mlp_output[0], self.shared_mlp_output[1], self.shared_mlp_output[3]
         w3, b3 = P.f32(head_fc2.weight), P.vec(head_fc2.bias)
-        Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))           # latent tokens 4..4+K of every frame
+        # reference FLOPs of the decoder cross-attention block (to_q counted once per frame as the
+        # reference computes it) -- attached to the stage span bench.py reports the 40 % MFMA target on
+        lin = lambda mm, i, o: 2.0 * mm * i * o
+        dec_flops = B * T * (2 * lin(N, C, C) + 2 * lin(K, C, C) + 2 * lin(N, C, 4 * C) + 4.0 * 12 * N * K * 64)
+        with span("stage:decoder_cross_attn_block", dec_flops):
+            Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))       # latent tokens 4..4+K of every frame
         nchunk = max(1, min(N, DECODE_ROWS // T))
         pcd, nrm, rgb = (self._f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
         for b in range(B):
             for n0 in range(0, N, nchunk):
                 n1 = min(N, n0 + nchunk)
                 pf = self._point_features(P, pcd[b, n0:n1], nrm[b, n0:n1].contiguous(), rgb[b, n0:n1].contiguous())
-                Q = dec.project_q(P, pf, 1, n1 - n0)
-                x = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True)
+                with span("stage:decoder_cross_attn_block", 0.0):
+                    Q = dec.project_q(P, pf, 1, n1 - n0)
+                    x = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True)
                 if cap is not None and n0 == 0 and n1 == N:
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
                 h = torch.empty(x.shape, dtype=P.dtype, device=dev)
