@@ -32,7 +32,7 @@ from .prepared import Prepared, bump_generation, compute_dtype, pad_k
 from .timing import span
 from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
-DECODE_ROWS = 1 << 17     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
+DECODE_ROWS = int(os.environ.get("M324_DECODE_ROWS", 1 << 17))     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
 
 
 def _get(cfg, key, default=None):

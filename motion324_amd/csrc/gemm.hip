@@ -267,7 +267,54 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             }
         }
     };
-    if (mw + MI * 32 <= M && nw + 64 <= N) body(std::false_type{});
+    // bf16 interior tiles without residual / row remap: 8 columns per lane, so a row is 8 lanes x 16 bytes and one
+    // store instruction writes 8 whole 128-byte lines (half as many store instructions as the 4-column form)
+    auto body8 = [&]() {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const int n8 = nw + c8;
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, g0 = make_float4(1.f, 1.f, 1.f, 1.f), g1 = g0;
+        if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
+        if (ep.gamma) { g0 = *reinterpret_cast<const float4*>(ep.gamma + n8); g1 = *reinterpret_cast<const float4*>(ep.gamma + n8 + 4); }
+        const float* rd8 = scr + r8 * EP_LD + c8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            float4 v0[4], v1[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
+                v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 x = v0[p], y = v1[p];
+                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                if (ACT == 1) { apply_gelu4<TOUT>(x); apply_gelu4<TOUT>(y); }
+                if (ep.gamma) {
+                    x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
+                    y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
+                }
+                const long m = mw + i * 32 + p * 8 + r8;
+                *reinterpret_cast<uint4*>(C + m * ldc + n8) = make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w),
+                                                                         pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+            }
+        }
+    };
+    const bool interior = mw + MI * 32 <= M && nw + 64 <= N;
+    if constexpr (sizeof(TOUT) == 2 && RES == 0) {
+        if (interior && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+            (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0)) {
+            body8();
+            return;
+        }
+    }
+    if (interior) body(std::false_type{});
     else body(std::true_type{});
 }
 
