@@ -20,6 +20,20 @@ def load(path, name):
 
 
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+if "--json" in sys.argv:        # per kernel class (the names bench.py's roofline object uses) -> profiles/rNN_traffic.json
+    import json
+    out = {"note": "HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes over `bench.py --eager "
+                   "--steps 2 --warmup 1`); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); "
+                   "KB -> bytes x1024"}
+    for cls, pat in (("gemm_bf16", "gemm_"), ("attention_bf16", "attn_bf16")):
+        nf = sum(v[0] for k, v in f.items() if pat in k)
+        fb = sum(v[1] for k, v in f.items() if pat in k) * 2.0 * 1024
+        nw = sum(v[0] for k, v in w.items() if pat in k)
+        wb = sum(v[1] for k, v in w.items() if pat in k) * 1024
+        if nf and nw:
+            out[cls] = {"launches": nf, "fetch_bytes_per_launch": round(fb / nf), "write_bytes_per_launch": round(wb / nw),
+                        "traffic_bytes_per_launch": round(fb / nf + wb / nw)}
+    json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 print("| kernel | launches | fetch MB/launch (x2 corrected) | write MB/launch | total MB/launch |")
 print("|---|---|---|---|---|")
 rows = []
