@@ -171,6 +171,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(c
                     for (int r = 0; r < 16; ++r)
                         if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[n][kb][r] = -INFINITY;
         }
+        // each lane checks its own half of the row against THR; the wave-wide vote combines the halves, so the
+        // cross-half exchange (an LDS round trip and a wait in the middle of the tile) is only paid when the reference moves
         float mx[NQ];
         bool calm = true;
 #pragma unroll
@@ -180,13 +182,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(c
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v = fmaxf(v, s[n][kb][r]);
-            mx[n] = fmaxf(v, __shfl_xor(v, 32, 64));
-            calm = calm && (mx[n] <= THR);
+            mx[n] = v;
+            calm = calm && (v <= THR);
         }
         // move the reference only when needed (wave-uniform decision)
         if (first || !__all(calm)) {
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
+                mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], 32, 64));
                 const float shift = first ? mx[n] : fmaxf(mx[n], 0.f);     // m_ref never decreases
                 const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-shift);
                 m_ref[n] += shift;
