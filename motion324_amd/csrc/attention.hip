@@ -339,6 +339,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __r
     const int nt = (Lk + KV - 1) / KV;
     issue(0);
     for (int t = 0; t < nt; ++t) {
+        // the LDS-DMA of tile t must have landed: stated explicitly -- __syncthreads() alone is compiled to
+        // `s_waitcnt lgkmcnt(0); s_barrier` here (no vmcnt), which let a workgroup read a stage that was still in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) issue(t + 1);
         const unsigned char* sk = smem + (t & 1) * 24576;
@@ -436,6 +439,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
     const int nt = (Lq + KV - 1) / KV;
     issue(0);
     for (int t = 0; t < nt; ++t) {
+        // the LDS-DMA of tile t must have landed: stated explicitly -- __syncthreads() alone is compiled to
+        // `s_waitcnt lgkmcnt(0); s_barrier` here (no vmcnt), which let a workgroup read a stage that was still in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) issue(t + 1);
         const unsigned char* sq = smem + (t & 1) * 32768;

@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
     const int arow0 = wm * 64 + l31, brow0 = wn * 64 + l31;
     issue_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (never left to __syncthreads()'s fence)
         __syncthreads();
         if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
         const unsigned char* sa = smem + (kt & 1) * 2 * TILE_BYTES;
@@ -624,6 +625,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
     const int arow0 = wm * 128 + l31, brow0 = wn * 64 + l31;
     issue_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (never left to __syncthreads()'s fence)
         __syncthreads();
         if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);
         const unsigned char* sa = smem + (kt & 1) * STAGE5;

@@ -77,7 +77,8 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, slices: int) -> torch.Tensor:
     args.M, args.N, args.K = M, N, ks
     args.in_dtype, args.out_dtype = code_of(a.dtype), F32
     args.batch, args.strideA, args.strideW, args.strideC = slices, ks, ks, M * N
-    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * main, esz * (M + N) * main + 4.0 * slices * M * N):
+    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * main, esz * (M + N) * main + 4.0 * slices * M * N,
+              f"split-K M={M} N={N} K={main} slices={slices}"):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     if main < K:                                        # remainder of the contraction
         gemm(a[:, main:], w[:, main:], part[slices])

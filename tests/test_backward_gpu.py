@@ -329,3 +329,40 @@ def test_colsum_wide_few_rows():
     assert rel_err(ops.colsum(x.to(DEV)), x.double().sum(0)) < 1e-6
     xb = x.to(torch.bfloat16)
     assert rel_err(ops.colsum(xb.to(DEV)), xb.double().sum(0)) < 1e-6
+
+
+def test_attention_backward_mfma_many_workgroups_is_race_free():
+    """Regression: the dQ kernel once relied on __syncthreads() to wait for its LDS-DMA tiles; the compiler emitted no
+    vmcnt wait there, so under load a workgroup could read a stage still in flight (one NaN block in ~1 of 20 launches at
+    the training shapes B*T = 96, L = 324).  Many co-resident workgroups, LDS poisoned with NaN patterns between launches,
+    every launch compared with the first and with the fp32-arithmetic reference kernels."""
+    from motion324_amd import ops
+    dtype = torch.bfloat16
+    B, H, L = 24, 12, 324
+    C = H * 64
+    dev = lambda t: t.to(dtype).to(DEV)
+    q_tok, k_tok, v_tok = (_rand((B * L, C), sd_, 1.0) for sd_ in (51, 52, 53))
+    dO_tok = _rand((B * L, C), 54)
+    spq = ops.qkv_split(dev(q_tok), None, None, None, None, 0.0, B, L, H, dtype, q_scale=ops.Q_PRESCALE, train=True)
+    spk = ops.qkv_split(None, dev(k_tok), dev(v_tok), None, None, 0.0, B, L, H, dtype, train=True)
+    out = torch.empty((B * L, C), dtype=dtype, device=DEV)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=DEV)
+    ops.attention(spq["Q"], spk["K"], spk["Vt"], out, prescaled=True, lse=lse)
+    D = ops.attention_delta(out, dev(dO_tok), B, H, L)
+    spdo = ops.qkv_split(dev(dO_tok), None, None, None, None, 0.0, B, L, H, dtype, train=True)
+    rQ, rK, rV = ops.attention_bwd(spq["Q"], spk["K"], spk["V"], spdo["Q"], lse, D)
+    poison = torch.full((8192, 768), float("nan"), dtype=dtype, device=DEV)
+    scratch = torch.empty((8192, 768), dtype=dtype, device=DEV)
+    first = None
+    for it in range(12):
+        ops.gemm(poison, poison[:768], scratch)            # leaves NaN bit patterns in every CU's LDS
+        dQ, dK, dV = ops.attention_bwd_mfma(spq, spk, spdo, lse, D)
+        for a in (dQ, dK, dV):
+            assert torch.isfinite(a.float()).all(), f"non-finite gradient in launch {it}"
+        if first is None:
+            first = (dQ.clone(), dK.clone(), dV.clone())
+            for a, b_ in zip(first, (rQ, rK, rV)):
+                assert rel_err(a.float(), b_.float()) < 1.5e-2
+        else:
+            for a, b_ in zip((dQ, dK, dV), first):
+                assert torch.equal(a, b_), f"launch {it} differs from launch 0"

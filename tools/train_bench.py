@@ -60,6 +60,16 @@ torch.cuda.synchronize()
 if world > 1:
     torch.distributed.barrier()
 dt = (time.perf_counter() - t0) / args.steps
+if args.profile and rank == 0:          # per-shape HIP-event table of one more step (GEMM / attention launches)
+    from motion324_amd import timing
+    with timing.Recorder() as rec:
+        step(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    rows = sorted(rec.by_tag().items(), key=lambda kv: -kv[1]["total_ms"])
+    print(f"instrumented launches: {sum(v['total_ms'] for _, v in rows):.1f} ms of the step", file=sys.stderr)
+    for (name, tag), v in rows[:45]:
+        print(f"{name:15s} {tag:62s} x{v['launches']:4d} {v['total_ms']:8.3f} ms {v['total_ms'] / v['launches'] * 1e3:8.1f} us each "
+              f"{v['flops'] / max(v['total_ms'], 1e-9) / 1e9:7.0f} TF/s", file=sys.stderr)
 if rank == 0:
     print(json.dumps({"metric": "training samples/sec (dyscene.yaml shapes, synthetic)", "value": round(world * args.batch / dt, 2),
                       "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 1), "batch_per_gpu": args.batch,
