@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Static check of the compiled kernels: every s_barrier of a kernel that stages tiles by LDS-DMA (global_load_lds) must
+have a vmcnt wait in the 14 instructions before it -- __syncthreads() alone does NOT make the compiler wait for an
+in-flight LDS-DMA (round 1: the attention dQ kernel read a stage that had not landed).  gemm_stag (v6) is exempt by
+design: its phase barriers sit between counted waits.
+usage: tools/audit_barriers.py   (compiles motion324_amd/csrc/{gemm,attention}.hip to assembly with hipcc)"""
+import os, re, subprocess, sys, tempfile
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+bad_total = 0
+for src in ("gemm.hip", "attention.hip"):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                        "--cuda-device-only", "-S", "-o", out, os.path.join(root, "motion324_amd", "csrc", src)],
+                       check=True, stderr=subprocess.DEVNULL)
+        kernels, name = {}, None
+        for line in open(out):
+            m = re.match(r"^(_ZN\S+):", line)
+            if m:
+                name = m.group(1)
+                kernels[name] = []
+            if name:
+                kernels[name].append(line)
+    for k, ls in kernels.items():
+        if not any("global_load_lds" in l for l in ls) or "gemm_stag" in k:
+            continue
+        bad = sum(1 for i, l in enumerate(ls) if "s_barrier" in l and "vmcnt" not in "".join(ls[max(0, i - 14):i]))
+        if bad:
+            bad_total += bad
+            print(f"{src}: {re.sub(r'_ZN12_GLOBAL__N_1[0-9]+', '', k)[:90]}: {bad} barrier(s) without a vmcnt wait")
+print("OK: every LDS-DMA kernel waits (vmcnt) before its barriers" if not bad_total else f"{bad_total} suspicious barriers")
+sys.exit(1 if bad_total else 0)
