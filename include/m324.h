@@ -27,6 +27,12 @@ extern "C" {
 typedef enum { M324_OK = 0, M324_ERR_INVALID = -1, M324_ERR_HIP = -2, M324_ERR_UNSUPPORTED = -3 } m324_status;
 typedef enum { M324_F32 = 0, M324_BF16 = 1 } m324_dtype;
 typedef enum { M324_ACT_NONE = 0, M324_ACT_GELU = 1 } m324_act;
+/* aux_mode of m324_gemm (aux has the output dtype and layout [M, ldaux], no row remap):
+ *   M324_AUX_STORE_PREACT  : aux[m,n] = acc + bias, the value the activation is applied to -- one launch gives the
+ *                            MLP both gelu(z) (C) and z (aux), which the backward needs (autograd of transformer.py:73-78);
+ *   M324_AUX_MUL_GELU_GRAD : the result is multiplied by gelu'(aux[m,n]) = Phi(z) + z phi(z) before it is stored -- the
+ *                            dgrad GEMM of the MLP's second Linear then delivers d(pre-activation) directly.           */
+typedef enum { M324_AUX_NONE = 0, M324_AUX_STORE_PREACT = 1, M324_AUX_MUL_GELU_GRAD = 2 } m324_aux_mode;
 
 /* ABI version of this header (bumped on any signature change). */
 int m324_abi_version(void);
@@ -62,6 +68,7 @@ typedef struct {
     int row_gin, row_gout, row_off;                  /* row_gin <= 0 -> identity */
     int batch;                                       /* <= 1: single GEMM; else `batch` independent GEMMs ...   */
     long strideA, strideW, strideC;                  /* ... whose A / W / C start strideX elements apart          */
+    void* aux; long ldaux; int aux_mode;             /* training: second operand of the epilogue, see M324_AUX_*  */
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
 

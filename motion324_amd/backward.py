@@ -15,6 +15,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .lib import ACT_GELU
 from .prepared import Prepared
 
 RMS_EPS = 1e-5
@@ -65,8 +66,10 @@ def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
     return P.derived("matT", (weight,), lambda: ops.transpose(P.mat(weight)))
 
 
-def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: torch.Tensor, need_da: bool = True):
-    """y = a W^T + b.  a [M, Ka] and dy [M, N] in the compute dtype.  Returns da [M, Ka] (compute dtype) or None."""
+def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: torch.Tensor, need_da: bool = True,
+               gelu_grad_of: Optional[torch.Tensor] = None):
+    """y = a W^T + b.  a [M, Ka] and dy [M, N] in the compute dtype.  Returns da [M, Ka] (compute dtype) or None.
+    gelu_grad_of = z with a = gelu(z): the returned tensor is dz = da * gelu'(z) (fused into the dgrad GEMM's epilogue)."""
     M, N = dy.shape
     if bias is not None:
         G.add(bias, ops.colsum(dy))
@@ -81,7 +84,7 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
     if Wt.shape[1] != N:
         raise RuntimeError("linear_bwd: output width must be a multiple of 64")
     da = torch.empty((M, Wt.shape[0]), dtype=dy.dtype, device=dy.device)
-    ops.gemm(dy, Wt, da)
+    ops.gemm(dy, Wt, da, gelu_grad_of=gelu_grad_of)
     return da
 
 
@@ -92,11 +95,10 @@ def mlp_residual_bwd(P: Prepared, G: GradStore, norm2, mlp, x_mid: torch.Tensor,
     h2 = torch.empty((rows, C), dtype=P.dtype, device=dx.device)
     ops.layernorm(x_mid, P.vec(norm2.weight), P.vec(norm2.bias), norm2.eps, h2)
     z = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=dx.device)
-    ops.gemm(h2, P.mat(fc1.weight), z, bias=P.vec(fc1.bias))
-    g = ops.gelu(z)
+    g = torch.empty_like(z)
+    ops.gemm(h2, P.mat(fc1.weight), g, bias=P.vec(fc1.bias), act=ACT_GELU, preact_out=z)     # g = gelu(z) and z in one launch
     dxT = ops.cast(dx, P.dtype)
-    dg = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT)
-    dz = ops.gelu_bwd(z, dg)
+    dz = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT, gelu_grad_of=z)                      # (dxT W2) * gelu'(z)
     dh2 = linear_bwd(P, G, fc1.weight, fc1.bias, h2, dz)
     dw, db = ops.layernorm_bwd(x_mid, P.vec(norm2.weight), norm2.eps, dh2, dx, accumulate=True)
     G.add(norm2.weight, dw)

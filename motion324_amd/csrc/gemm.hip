@@ -30,6 +30,9 @@ struct Epilogue {
     int act;
     int row_gin, row_gout, row_off;
     long strideA, strideW, strideC;
+    void* aux;
+    long ldaux;
+    int aux_mode;
 };
 
 // GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
@@ -80,6 +83,36 @@ __device__ __forceinline__ void apply_gelu4(float4& v) {
         v = make_float4(a.x, a.y, b.x, b.y);
     } else {
         v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+    }
+}
+
+// d gelu(z) / dz = Phi(z) + z phi(z).  fp32 outputs: erff / expf; bf16 outputs: the polynomial erf above and exp2.
+template <typename TOUT>
+__device__ __forceinline__ float gelu_grad(float z) {
+    if constexpr (sizeof(TOUT) == 2) {
+        const float t = __builtin_amdgcn_fmed3f(z * 0.70710678118654752440f, -3.0f, 3.0f), t2 = t * t;
+        float p = 4.074096087e-08f;
+        p = fmaf(p, t2, -1.944782217e-06f); p = fmaf(p, t2, 4.105993727e-05f); p = fmaf(p, t2, -5.110323815e-04f);
+        p = fmaf(p, t2, 4.235408041e-03f); p = fmaf(p, t2, -2.510281415e-02f); p = fmaf(p, t2, 1.110792751e-01f);
+        p = fmaf(p, t2, -3.753148415e-01f); p = fmaf(p, t2, 1.128268421e+00f);
+        const float cdf = fmaf(0.5f * t, p, 0.5f);
+        const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);
+        return fmaf(z, pdf, cdf);
+    } else {
+        const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+        return cdf + z * pdf;
+    }
+}
+
+template <typename TOUT>
+__device__ __forceinline__ float4 load4_out(const TOUT* p) {
+    if constexpr (sizeof(TOUT) == 2) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xFFFF0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(p);
     }
 }
 
@@ -233,13 +266,20 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int mb = mw + i * 32 + rr;       // row of pass p: mb + 4 p
-            float4 res[8];
+            float4 res[8], az[8];
             if (has_res) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
                     if (res_mod) mr %= ep.res_rows;
                     res[p] = *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
+                }
+            }
+            if (ep.aux_mode == 2) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
+                    az[p] = load4_out<TOUT>(static_cast<const TOUT*>(ep.aux) + (long)mr * ep.ldaux + ncl);
                 }
             }
 #pragma unroll
@@ -255,10 +295,16 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             for (int p = 0; p < 8; ++p) {
                 float4 x = v[p];
                 x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
+                const int m = mb + 4 * p;
+                if (ep.aux_mode == 1 && (!CHECK || (m < M && nok)))
+                    store4_out<TOUT>(static_cast<TOUT*>(ep.aux) + (long)m * ep.ldaux + n, x.x, x.y, x.z, x.w);
                 if (ACT == 1) apply_gelu4<TOUT>(x);
                 if (ep.gamma) { x.x *= ga.x; x.y *= ga.y; x.z *= ga.z; x.w *= ga.w; }
                 if (has_res) { x.x += res[p].x; x.y += res[p].y; x.z += res[p].z; x.w += res[p].w; }
-                const int m = mb + 4 * p;
+                if (ep.aux_mode == 2) {
+                    x.x *= gelu_grad<TOUT>(az[p].x); x.y *= gelu_grad<TOUT>(az[p].y);
+                    x.z *= gelu_grad<TOUT>(az[p].z); x.w *= gelu_grad<TOUT>(az[p].w);
+                }
                 if (!CHECK || (m < M && nok)) {
                     long orow = m;
                     if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
@@ -284,7 +330,15 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            float4 v0[4], v1[4];
+            float4 v0[4], v1[4], z0[4], z1[4];
+            if (ep.aux_mode == 2) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const TOUT* zp = static_cast<const TOUT*>(ep.aux) + (long)(mw + i * 32 + p * 8 + r8) * ep.ldaux + n8;
+                    z0[p] = load4_out<TOUT>(zp);
+                    z1[p] = load4_out<TOUT>(zp + 4);
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
@@ -295,12 +349,21 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 float4 x = v0[p], y = v1[p];
                 x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
                 y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                const long m = mw + i * 32 + p * 8 + r8;
+                if (ep.aux_mode == 1)
+                    *reinterpret_cast<uint4*>(static_cast<TOUT*>(ep.aux) + m * ep.ldaux + n8) =
+                        make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
                 if (ACT == 1) { apply_gelu4<TOUT>(x); apply_gelu4<TOUT>(y); }
                 if (ep.gamma) {
                     x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
                     y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
                 }
-                const long m = mw + i * 32 + p * 8 + r8;
+                if (ep.aux_mode == 2) {
+                    x.x *= gelu_grad<TOUT>(z0[p].x); x.y *= gelu_grad<TOUT>(z0[p].y);
+                    x.z *= gelu_grad<TOUT>(z0[p].z); x.w *= gelu_grad<TOUT>(z0[p].w);
+                    y.x *= gelu_grad<TOUT>(z1[p].x); y.y *= gelu_grad<TOUT>(z1[p].y);
+                    y.z *= gelu_grad<TOUT>(z1[p].z); y.w *= gelu_grad<TOUT>(z1[p].w);
+                }
                 *reinterpret_cast<uint4*>(C + m * ldc + n8) = make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w),
                                                                          pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
             }
@@ -309,7 +372,8 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
     const bool interior = mw + MI * 32 <= M && nw + 64 <= N;
     if constexpr (sizeof(TOUT) == 2 && RES == 0) {
         if (interior && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-            (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0)) {
+            (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0) &&
+            (!ep.aux_mode || ((ep.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0))) {
             body8();
             return;
         }
@@ -1101,7 +1165,7 @@ static int pick_variant(const m324_gemm_args* a) {
     if (f >= 71 && f <= 199) return f;
 #endif
     if (f >= 1 && f <= 8 && f != 4) return (f >= 6 && a->in_dtype != M324_BF16) ? 5 : f;
-    if (a->M <= 64 && a->in_dtype == M324_BF16 && (f == 0 || f == 9)) return 9;
+    if (a->M <= 64 && a->in_dtype == M324_BF16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
     // CU) balance better.  Measured on the c2 shapes (tools/gemm_lab): v7 wins at >= 0.70 fill, v2 below.
@@ -1145,7 +1209,7 @@ static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& 
 template <typename TIN, typename TOUT>
 int launch(const m324_gemm_args* a, hipStream_t s) {
     Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off,
-                a->strideA, a->strideW, a->strideC};
+                a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
@@ -1209,6 +1273,15 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
     M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
                  "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
+    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 2, "m324_gemm: aux_mode %d", a->aux_mode);
+    if (a->aux_mode) {
+        const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
+        M324_REQUIRE(a->aux && a->ldaux >= a->N && a->ldaux % 4 == 0 && ((uintptr_t)a->aux % (4 * osz)) == 0 && vec_ok(a) &&
+                         a->row_gin <= 0 && a->batch <= 1,
+                     "m324_gemm: aux operand needs a vectorisable, un-remapped, un-batched problem with ldaux >= N");
+        M324_REQUIRE(a->aux_mode != M324_AUX_STORE_PREACT || a->act == M324_ACT_GELU,
+                     "m324_gemm: M324_AUX_STORE_PREACT only makes sense with an activation");
+    }
     hipStream_t s = (hipStream_t)stream;
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16) return launch<bf16_t, bf16_t>(a, s);
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_F32) return launch<bf16_t, float>(a, s);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libm324.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class M324Error(RuntimeError):
@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("row_gin", C.c_int), ("row_gout", C.c_int), ("row_off", C.c_int),
         ("batch", C.c_int),
         ("strideA", C.c_long), ("strideW", C.c_long), ("strideC", C.c_long),
+        ("aux", C.c_void_p), ("ldaux", C.c_long), ("aux_mode", C.c_int),
     ]
 
 

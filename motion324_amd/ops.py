@@ -86,8 +86,11 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, slices: int) -> torch.Tensor:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = L.ACT_NONE, gamma=None,
-         residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0)) -> torch.Tensor:
-    """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm."""
+         residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0),
+         preact_out: Optional[torch.Tensor] = None, gelu_grad_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm.
+    preact_out [M, N] (out's dtype) also receives the value the activation is applied to (M324_AUX_STORE_PREACT);
+    gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only."""
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K or a.dtype != w.dtype:
@@ -111,6 +114,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     if out.shape[0] < need or out.shape[1] < N:
         raise L.M324Error(f"gemm: out{tuple(out.shape)} too small for {need} x {N}")
     args.row_gin, args.row_gout, args.row_off = gin, gout, off
+    aux = preact_out if preact_out is not None else gelu_grad_of
+    if aux is not None:
+        if preact_out is not None and gelu_grad_of is not None:
+            raise L.M324Error("gemm: preact_out and gelu_grad_of are mutually exclusive")
+        if aux.dtype != out.dtype or aux.shape[0] < M or aux.shape[1] < N:
+            raise L.M324Error(f"gemm: aux operand {aux.dtype}{tuple(aux.shape)} does not match out {out.dtype} [{M}, {N}]")
+        args.aux, args.ldaux = _rows(aux, "aux")
+        args.aux_mode = 1 if preact_out is not None else 2
     esz = a.element_size()
     tag = f"M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}{' gamma' if gamma is not None else ''}" \
           f"{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}"

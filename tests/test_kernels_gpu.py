@@ -158,6 +158,34 @@ def test_gemm_skinny_rows(M, N, K):
     assert rel_err(x, res.double() + a.double() @ w.double().T) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(300, 328, 192), (512, 768, 256), (40, 64, 64)])
+def test_gemm_training_aux_operand(dtype, M, N, K):
+    """M324_AUX_STORE_PREACT: one launch yields gelu(z) and z; M324_AUX_MUL_GELU_GRAD: result * gelu'(z)
+    (ragged tiles, interior 16-byte-store path at N % 64 == 0, and the small-M route around the skinny kernel)."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU, M324Error
+    a, w = _q(_rand((M, K), 31), dtype), _q(_rand((N, K), 32, 0.1), dtype)
+    bias = _rand((N,), 33)
+    zref = a.double() @ w.double().T + bias.double()
+    gref = 0.5 * zref * (1 + torch.erf(zref / math.sqrt(2.0)))
+    g = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    z = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), g, bias=bias.to(DEV), act=ACT_GELU, preact_out=z)
+    assert rel_err(z.float(), zref) < TOL[dtype] and rel_err(g.float(), gref) < TOL[dtype]
+    # backward form: dz = (dy @ W2) * gelu'(z) with z as stored above
+    dy = _q(_rand((M, K), 34), dtype)
+    zs = z.float().cpu().double()
+    cdf = 0.5 * (1 + torch.erf(zs / math.sqrt(2.0)))
+    pdf = torch.exp(-0.5 * zs * zs) / math.sqrt(2 * math.pi)
+    dref = (dy.double() @ w.double().T) * (cdf + zs * pdf)
+    dz = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(dy.to(dtype).to(DEV), w.to(dtype).to(DEV), dz, gelu_grad_of=z)
+    assert rel_err(dz.float(), dref) < TOL[dtype]
+    with pytest.raises(M324Error):          # the pre-activation output needs an activation
+        ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), g, preact_out=z)
+
+
 def test_gemm_rejects_bad_k():
     ops = _ops()
     from motion324_amd.lib import M324Error
