@@ -275,7 +275,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     res[p] = *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
                 }
             }
-            if (ep.aux_mode == 2) {
+            if constexpr (ACT == 3) {
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     const int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
@@ -296,12 +296,12 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 float4 x = v[p];
                 x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
                 const int m = mb + 4 * p;
-                if (ep.aux_mode == 1 && (!CHECK || (m < M && nok)))
+                if (ACT == 2 && (!CHECK || (m < M && nok)))
                     store4_out<TOUT>(static_cast<TOUT*>(ep.aux) + (long)m * ep.ldaux + n, x.x, x.y, x.z, x.w);
-                if (ACT == 1) apply_gelu4<TOUT>(x);
+                if (ACT == 1 || ACT == 2) apply_gelu4<TOUT>(x);
                 if (ep.gamma) { x.x *= ga.x; x.y *= ga.y; x.z *= ga.z; x.w *= ga.w; }
                 if (has_res) { x.x += res[p].x; x.y += res[p].y; x.z += res[p].z; x.w += res[p].w; }
-                if (ep.aux_mode == 2) {
+                if constexpr (ACT == 3) {
                     x.x *= gelu_grad<TOUT>(az[p].x); x.y *= gelu_grad<TOUT>(az[p].y);
                     x.z *= gelu_grad<TOUT>(az[p].z); x.w *= gelu_grad<TOUT>(az[p].w);
                 }
@@ -331,7 +331,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
             float4 v0[4], v1[4], z0[4], z1[4];
-            if (ep.aux_mode == 2) {
+            if constexpr (ACT == 3) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const TOUT* zp = static_cast<const TOUT*>(ep.aux) + (long)(mw + i * 32 + p * 8 + r8) * ep.ldaux + n8;
@@ -350,15 +350,15 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
                 y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
                 const long m = mw + i * 32 + p * 8 + r8;
-                if (ep.aux_mode == 1)
+                if constexpr (ACT == 2)
                     *reinterpret_cast<uint4*>(static_cast<TOUT*>(ep.aux) + m * ep.ldaux + n8) =
                         make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-                if (ACT == 1) { apply_gelu4<TOUT>(x); apply_gelu4<TOUT>(y); }
+                if (ACT == 1 || ACT == 2) { apply_gelu4<TOUT>(x); apply_gelu4<TOUT>(y); }
                 if (ep.gamma) {
                     x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
                     y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
                 }
-                if (ep.aux_mode == 2) {
+                if constexpr (ACT == 3) {
                     x.x *= gelu_grad<TOUT>(z0[p].x); x.y *= gelu_grad<TOUT>(z0[p].y);
                     x.z *= gelu_grad<TOUT>(z0[p].z); x.w *= gelu_grad<TOUT>(z0[p].w);
                     y.x *= gelu_grad<TOUT>(z1[p].x); y.y *= gelu_grad<TOUT>(z1[p].y);
@@ -373,7 +373,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
     if constexpr (sizeof(TOUT) == 2 && RES == 0) {
         if (interior && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
             (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0) &&
-            (!ep.aux_mode || ((ep.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0))) {
+            (ACT < 2 || ((ep.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0))) {
             body8();
             return;
         }
@@ -1247,7 +1247,11 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
                                a->K, ep, (int)grid.x, xcd_remap());                                                      \
     } while (0)
-        if (a->act == M324_ACT_GELU) {
+        if (a->aux_mode == M324_AUX_STORE_PREACT) {
+            M324_GLDS(2, 0);
+        } else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD) {
+            M324_GLDS(3, 0);
+        } else if (a->act == M324_ACT_GELU) {
             if (res == 0) M324_GLDS(1, 0); else M324_GLDS(1, 2);
         } else {
             if (res == 0) M324_GLDS(0, 0); else if (res == 1) M324_GLDS(0, 1); else M324_GLDS(0, 2);
@@ -1281,6 +1285,9 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
                      "m324_gemm: aux operand needs a vectorisable, un-remapped, un-batched problem with ldaux >= N");
         M324_REQUIRE(a->aux_mode != M324_AUX_STORE_PREACT || a->act == M324_ACT_GELU,
                      "m324_gemm: M324_AUX_STORE_PREACT only makes sense with an activation");
+        M324_REQUIRE(a->aux_mode != M324_AUX_MUL_GELU_GRAD || a->act == M324_ACT_NONE,
+                     "m324_gemm: M324_AUX_MUL_GELU_GRAD excludes an activation");
+        M324_REQUIRE(!a->residual, "m324_gemm: the aux operand excludes a residual");
     }
     hipStream_t s = (hipStream_t)stream;
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16) return launch<bf16_t, bf16_t>(a, s);
