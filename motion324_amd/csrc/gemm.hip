@@ -544,92 +544,6 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
 
 
 // ------------------------------------------------------------------------------------------------
-// v3: 256 x 128 tile, 8 waves (4 x 2, each 64 x 64), THREE LDS stages of 48 KiB and counted waits.
-// v2 has one K-tile of prefetch distance: a wave computes 512 cycles of MFMA per tile, far less than
-// the 1-2 us an LDS-DMA fill takes under load, so every iteration stalls on the fill it issued one
-// iteration earlier.  Here tile kt+2 is issued while tile kt is computed and the wait before the
-// barrier is `s_waitcnt vmcnt(6)` -- "everything but my 6 newest DMA pieces" -- so two tiles
-// (96 KiB per CU) stay in flight across the barrier.  A raw s_barrier is used because
-// __syncthreads() would drain the DMA queue (vmcnt(0)).
-//   RAW: a wave's own pieces of tile kt have landed (counted wait), then the barrier -> all pieces.
-//   WAR: the stage refilled in iteration kt was last read in iteration kt-1; every wave has consumed
-//        those ds_reads (its MFMAs waited for them) before it arrives at iteration kt's barrier.
-constexpr int BM3 = 256;
-constexpr int STAGE3 = (BM3 + BN) * ROWB;   // 48 KiB
-
-template <typename TIN, typename TOUT, int ACT, int RES>
-__global__ __launch_bounds__(512, 2) void gemm_glds3_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
-                                                            long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep,
-                                                            int ntn, int xcd_remap) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE3];
-    constexpr int EPC = Elem<TIN>::PER16;
-    constexpr int BK = ROWB / sizeof(TIN);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * BM3, n0 = (lid % ntn) * BN;
-
-    // staging: A row groups g = wave*4 + i (i < 4), W row groups g = wave*2 + i (i < 2); 8 rows per group
-    const TIN* ga[4];
-    const TIN* gb[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3);
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + ((lane & 7) ^ ((r >> 1) & 7)) * EPC;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 8 + (lane >> 3);
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + ((lane & 7) ^ ((r >> 1) & 7)) * EPC;
-    }
-    auto issue_tile = [&](int kt, int stage) {
-        unsigned char* sa = smem + stage * STAGE3 + wave * 4096;
-        unsigned char* sb = smem + stage * STAGE3 + BM3 * ROWB + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)kt * BK), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)kt * BK), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = K / BK;
-    const int arow0 = wm * 64 + l31, brow0 = wn * 64 + l31;
-    issue_tile(0, 0);
-    if (nk > 1) issue_tile(1, 1);
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue_tile(kt + 2, stage >= 1 ? stage - 1 : 2);      // (stage + 2) % 3
-        const unsigned char* sa = smem + stage * STAGE3;
-        mma_tile<TIN, true>(sa, sa + BM3 * ROWB, arow0, brow0, hi, acc);
-        stage = stage == 2 ? 0 : stage + 1;
-    }
-    __syncthreads();
-    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 64,
-                                      n0 + wn * 64, lane, ep);
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // v5: 256 x 256 tile, 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block = 4 x 2 accumulators
 // (128 VGPR).  Per K-tile a wave issues 32 MFMAs (1024 matrix-pipe cycles) against 24 fragment reads,
 // and the workgroup moves 64 KiB by LDS-DMA per 8.4 MFLOP -- half the LDS traffic per FLOP of the
@@ -733,23 +647,8 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
 
 
 // ------------------------------------------------------------------------------------------------
-// v6: 256 x 256 tile with a STAGGERED two-group schedule (bf16 only).
-// Waves 0-3 (group A, rows 0..127) and 4-7 (group B, rows 128..255) share every SIMD pairwise (wave w and
-// w+4).  Work is cut into phases of one k-step = 8 MFMAs per wave (256 matrix-pipe cycles).  A phase is
-//     [ds_read the 6 fragments of the k-step | issue LDS-DMA]  s_barrier  [8 MFMAs]  s_barrier
-// and group B runs ONE barrier behind group A, so between any two barriers one wave of each SIMD is
-// feeding the matrix pipe while its partner fetches fragments / issues DMA: the pipe never waits for the
-// LDS, and no wave ever waits at a barrier for work it could have overlapped.
-// K is streamed in half-tiles of 32 (one 32 KiB LDS slot = A[256][32] + W[256][32], 64-byte rows with chunk
-// swizzle c ^ ((row >> 2) & 3)); 4 slots form a ring, three half-tiles are in flight, waits are counted.
-//   barrier numbering (after the prologue barrier #0): group A's phase Q uses barriers 2Q+1, 2Q+2;
-//   group B first takes barrier #1 alone, then its phase Q uses 2Q+2, 2Q+3; A takes one extra at the end.
-//   RAW: half-tile h is first read after barrier 4h.  Every wave waits (counted vmcnt) for its own DMA
-//        pieces of half-tile h+1 in the odd phase of half-tile h, before that phase's first barrier
-//        (#4h+3 for A, #4h+4 for B) -- both <= 4(h+1).
-//   WAR: the DMA for half-tile h+3 (slot of half-tile h-1) is issued in the odd phase of half-tile h, i.e.
-//        after barrier 4h+2 (A) / 4h+3 (B); the last reads of half-tile h-1 retire right after barrier
-//        4h-1 (A) / 4h (B): at least two barriers earlier.
+// 64-byte-row half-tile image shared by the pipelined kernel: one 32 KiB LDS slot = A[256][32] + W[256][32] (bf16),
+// 16-byte chunks swizzled c ^ ((row >> 2) & 3) (applied to the LDS-DMA source address and to the fragment reads).
 constexpr int ROWB6 = 64;                        // bytes of K per LDS row in a half-tile
 constexpr int PART6 = 256 * ROWB6;               // 16 KiB: one operand's half-tile
 constexpr int SLOT6 = 2 * PART6;                 // 32 KiB
@@ -761,14 +660,27 @@ __device__ __forceinline__ int lds_off6(int row, int chunk) { return row * ROWB6
         __builtin_amdgcn_sched_barrier(0);         \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------
+// v7: software-pipelined 256 x 256 kernel (bf16), 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block = 4 x 2
+// accumulators.  K is streamed in half-tiles of 32 through a 4-slot ring (128 KiB, one workgroup per CU) with ONE
+// barrier per half-tile, and the overlap is done inside each wave: while the 8 MFMAs of a k-step run, the 6 fragment
+// reads of the next k-step and the wave's LDS-DMA pieces of half-tile h+3 are issued between them (pinned with
+// sched_group_barrier), so the matrix pipe is fed without relying on the SIMD partner's phase.
+//   barrier h (top of iteration h): every wave's pieces of half-tile h+1 have landed (counted vmcnt: only the 4 pieces
+//   of h+2 may still fly) and every wave has finished reading half-tile h-1, whose slot now receives half-tile h+3.
+//   Fragments of (h+1, k-step 0) are fetched during (h, k-step 1), i.e. before barrier h+1: MFMAs restart immediately.
+//   The steady state is branch-free: past the end of K the last half-tile is fetched again into a free slot (an L2
+//   hit nobody reads), so the wait is always vmcnt(4); all pieces are drained before the ring becomes epilogue scratch.
+// Measured (tools/gemm_lab, 4096^3): MFMA-only loop 1825 TF/s, + fragment reads 1490, + LDS-DMA issue 1316, all 1190.
 template <typename TOUT, int ACT, int RES>
-__global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16_t* __restrict__ A, long lda,
-                                                           const bf16_t* __restrict__ W, long ldw, TOUT* C, long ldc, int M,
-                                                           int N, int K, Epilogue ep, int ntn, int xcd_remap) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * SLOT6];
+__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
+                                                           int xcd_remap) {
+    constexpr int RING = 4, PPW = 4;             // ring slots; LDS-DMA pieces per wave per half-tile (2 of A, 2 of W)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOT6];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;     // wm = group (0 = A, 1 = B)
+    const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
     int lid = blockIdx.x;
     if (xcd_remap & 1) {
@@ -777,154 +689,28 @@ __global__ __launch_bounds__(512, 2) void gemm_stag_kernel(const bf16_t* __restr
     }
     const int m0 = (lid / ntn) * BM5, n0 = (lid % ntn) * BN5;
 
-    // DMA: a wave-instruction fills 16 rows x 64 B.  Per half-tile each wave moves row groups
-    // g = wave*2 + i (i < 2) of A and of W.
+    // LDS-DMA: a wave-instruction fills 16 rows x 64 B; wave w moves row groups 2w, 2w+1 of A and of W
     const bf16_t* ga[2];
     const bf16_t* gb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c * 8;
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c * 8;
-    }
-    auto issue_half = [&](int h) {
-        unsigned char* sa = smem + (h & 3) * SLOT6 + wave * 2048;
-        unsigned char* sb = sa + PART6;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)h * 32), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)h * 32), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
-        }
-    };
-    auto wait_dma = [&](int halves_in_flight) {     // allow that many later half-tiles (4 pieces each) in flight
-        if (halves_in_flight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (halves_in_flight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int NH = K / 32;
-    const int arow0 = wm * 128 + l31, brow0 = wn * 64 + l31;
-    bf16x8 fa[4], fb[2];
-    auto load_frags = [&](int h, int ks) {
-        const unsigned char* sa = smem + (h & 3) * SLOT6;
-        const unsigned char* sb = sa + PART6;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off6(brow0 + j * 32, ks * 2 + hi));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off6(arow0 + i * 32, ks * 2 + hi));
-    };
-    auto mma8 = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // prologue: three half-tiles in flight, half-tile 0 landed everywhere
-    const int pre = NH < 3 ? NH : 3;
-    for (int h = 0; h < pre; ++h) issue_half(h);
-    wait_dma(pre - 1);
-    M324_BARRIER();                 // #0
-    if (wm == 1) M324_BARRIER();    // group B starts one barrier late
-
-    for (int h = 0; h < NH; ++h) {
-        // ---- even phase: k-step 0 of half-tile h
-        load_frags(h, 0);
-        M324_BARRIER();
-        mma8();
-        M324_BARRIER();
-        // ---- odd phase: k-step 1; refill the slot of half-tile h-1 with half-tile h+3
-        load_frags(h, 1);
-        if (h + 3 < NH) issue_half(h + 3);
-        {
-            const int last = (h + 3 < NH ? h + 3 : NH - 1);      // newest half-tile issued so far
-            wait_dma(last - (h + 1));                            // half-tile h+1 landed (this wave's pieces)
-        }
-        M324_BARRIER();
-        mma8();
-        M324_BARRIER();
-    }
-    if (wm == 0) M324_BARRIER();    // group A's matching extra barrier
-    __syncthreads();
-    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
-                                      n0 + wn * 64, lane, ep);
-}
-
-// ------------------------------------------------------------------------------------------------
-// v7 / v8: software-pipelined LDS-DMA kernel (bf16).  Same 64-byte-row half-tile ring as v6, but ONE barrier per
-// half-tile and the overlap is done inside each wave: the fragments of k-step s+1 are fetched into a second register
-// set while the 8 MFMAs of k-step s run, and the LDS-DMA pieces of a later half-tile are issued between MFMAs, so a
-// wave keeps the matrix pipe fed by itself instead of relying on its SIMD partner's phase.
-//   WN = 4 (v7): 256 x 256 tile, 8 waves, 4-slot ring (128 KiB, one workgroup per CU); fragments of (h+1, step 0) are
-//               fetched before barrier h+1 (XPF), so MFMAs restart right after every barrier.
-//               barrier h guarantees half-tile h+1 landed; DMA of h+3 goes to the slot of h-1.
-//   WN = 2 (v8): 256 x 128 tile, 4 waves, 3-slot ring (72 KiB): TWO workgroups per CU, so one tile's prologue and
-//               epilogue (HBM-bound for fp32 residual outputs, VALU-bound for GELU) overlap the other's main loop.
-//               barrier h guarantees half-tile h landed; DMA of h+2 goes to the slot of h-1.
-//   WAR in both: the last fragment reads of half-tile h-1 are consumed by MFMAs issued before barrier h.
-template <typename TOUT, int ACT, int RES, int WN, int RING, bool XPF, int DBG = 0>
-__global__ __launch_bounds__(WN * 128, 2) void gemm_pipe_kernel(const bf16_t* __restrict__ A, long lda,
-                                                                const bf16_t* __restrict__ W, long ldw, TOUT* C, long ldc,
-                                                                int M, int N, int K, Epilogue ep, int ntn, int xcd_remap) {
-    constexpr int NW = 2 * WN, BNt = WN * 64;
-    constexpr int PARTA = 256 * ROWB6, PARTB = BNt * ROWB6, SLOT = PARTA + PARTB;
-    constexpr int PA = 16 / NW, PB = (BNt / 16) / NW, PPW = PA + PB;      // DMA pieces per wave per half-tile
-    static_assert(!XPF || RING == 4, "cross-barrier fragment prefetch needs the 4-slot ring");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOT];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * 256, n0 = (lid % ntn) * BNt;
-    if constexpr ((DBG & 24) != 0) {   // lab: de-phase the CUs so that epilogue store bursts do not coincide
-        if (blockIdx.x < 256) {
-            const int ph = (DBG & 16) ? ((blockIdx.x >> 3) & 3) : 2 * ((blockIdx.x >> 3) & 1);
-            for (int i = 0; i < ph; ++i) { __builtin_amdgcn_s_sleep(127); }
-        }
-    }
-
-    const bf16_t* ga[PA];
-    const bf16_t* gb[PB];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int r = (wave * PA + i) * 16 + (lane >> 2);
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int r = (wave * PB + i) * 16 + (lane >> 2);
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+        const int c = ((lane & 3) ^ ((r >> 2) & 3)) * 8;
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
     }
     auto issue_a = [&](int h, int slot) {
-        unsigned char* sa = smem + slot * SLOT + wave * (PA * 1024);
+        unsigned char* sa = smem + slot * SLOT6 + wave * 2048;
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
+        for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)h * 32), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
     };
     auto issue_b = [&](int h, int slot) {
-        unsigned char* sb = smem + slot * SLOT + PARTA + wave * (PB * 1024);
+        unsigned char* sb = smem + slot * SLOT6 + PART6 + wave * 2048;
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
+        for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)h * 32), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
     };
-    auto issue_half = [&](int h, int slot) { issue_a(h, slot); issue_b(h, slot); };
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -935,11 +721,11 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_pipe_kernel(const bf16_t* __
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int NH = K / 32;
-    const int aoff = lds_off6(wm * 128 + l31, hi), boff = PARTA + lds_off6(wn * 64 + l31, hi);   // k-step 1: ^ 32
+    const int aoff = lds_off6(wm * 128 + l31, hi), boff = PART6 + lds_off6(wn * 64 + l31, hi);
     bf16x8 fa[2][4], fb[2][2];
     auto load_frags = [&](int set, int slot, int ks) {
-        const unsigned char* base = smem + slot * SLOT;
-        const int x = ks << 5;          // chunk + 2  ==  byte offset ^ 32 (the swizzle only touches bits 4-5)
+        const unsigned char* base = smem + slot * SLOT6;
+        const int x = ks << 5;          // k-step 1 = chunk + 2 = byte offset ^ 32 (the swizzle only touches bits 4-5)
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(base + ((boff + j * 2048) ^ x));
 #pragma unroll
@@ -952,85 +738,45 @@ __global__ __launch_bounds__(WN * 128, 2) void gemm_pipe_kernel(const bf16_t* __
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
     };
-    // one MFMA, then one LDS read (6 per k-step), the remaining MFMAs back to back
-    // k-step schedules (sched_group_barrier: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read).  The 6 fragment reads of the
-    // next k-step ride on the first MFMAs (so they have landed when that k-step starts), the LDS-DMA pieces on the
-    // last ones.  LDS-DMA instructions also match the DS mask: they are emitted after the reads in program order.
+    // k-step schedule (sched_group_barrier: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read): the 6 fragment reads of the next
+    // k-step ride on the first 6 MFMAs (landed when that k-step starts), the 2 LDS-DMA pieces on the last two.  LDS-DMA
+    // instructions also match the DS mask: they come after the reads in program order, so the DS groups take the reads.
 #define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-    auto sched_reads_then_dma = [&](auto ndma) {
-        constexpr int D = decltype(ndma)::value;
-        static_assert(D >= 0 && D <= 4, "at most 4 DMA pieces per k-step");
-        if constexpr (D <= 2) {
-            M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
-            M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
-            M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
-            if constexpr (D >= 1) { M324_SG(0x008, 1); M324_SG(0x020, 1); } else { M324_SG(0x008, 1); }
-            if constexpr (D >= 2) { M324_SG(0x008, 1); M324_SG(0x020, 1); } else { M324_SG(0x008, 1); }
-        } else {
-            M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x100, 2);
-            M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 1);
-            M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
-            if constexpr (D >= 4) { M324_SG(0x008, 1); M324_SG(0x020, 1); } else { M324_SG(0x008, 1); }
-            M324_SG(0x008, 1);
-        }
+    auto sched_kstep = [&]() {
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
     };
-    using std::integral_constant;
 #define M324_WAIT_PIECES(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-    // The steady state is branch-free: every iteration issues PPW pieces (past the end of K the last half-tile is
-    // fetched again into a free slot -- an L2 hit nobody reads), so the counted wait is always vmcnt(PPW).
-    constexpr int AHEAD = RING - 1;            // half-tiles issued ahead of the one being computed
-    for (int h = 0; h < AHEAD; ++h) issue_half(h < NH ? h : NH - 1, h);
-    if constexpr (XPF) {
-        M324_WAIT_PIECES(2 * PPW);             // half-tile 0 landed
-        M324_BARRIER();
-        load_frags(0, 0, 0);
+    for (int h = 0; h < RING - 1; ++h) {
+        issue_a(h < NH ? h : NH - 1, h);
+        issue_b(h < NH ? h : NH - 1, h);
     }
-    int slot = 0;                               // h % RING
-    for (int h = 0; h < ((DBG & 64) ? 0 : NH); ++h) {
-        const int nslot = slot + 1 == RING ? 0 : slot + 1;
-        if constexpr (!(DBG & 4)) {
-            M324_WAIT_PIECES(PPW);              // XPF: half-tile h+1 landed; else: half-tile h landed (own pieces)
-            M324_BARRIER();
-        }
-        const int hn = h + AHEAD < NH ? h + AHEAD : NH - 1, fslot = slot == 0 ? RING - 1 : slot - 1;
-        if constexpr (XPF) {
-            if constexpr (!(DBG & 2)) load_frags(1, slot, 1);
-            if constexpr (!(DBG & 1)) issue_a(hn, fslot);
-            mma8(0);
-            sched_reads_then_dma(integral_constant<int, PA>{});
-            if constexpr (!(DBG & 2)) load_frags(0, nslot, 0);            // past the end: stale but valid LDS, never used
-            if constexpr (!(DBG & 1)) issue_b(hn, fslot);
-            mma8(1);
-            sched_reads_then_dma(integral_constant<int, PB>{});
-        } else {
-            load_frags(0, slot, 0);
-            M324_SG(0x100, 6);
-            load_frags(1, slot, 1);
-            issue_a(hn, fslot);
-            mma8(0);
-            sched_reads_then_dma(integral_constant<int, PA>{});
-            issue_b(hn, fslot);
-            mma8(1);
-            M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 6);
-        }
+    M324_WAIT_PIECES(2 * PPW);                   // half-tile 0 landed
+    M324_BARRIER();
+    load_frags(0, 0, 0);
+    int slot = 0;                                // h % RING
+    for (int h = 0; h < NH; ++h) {
+        const int nslot = (slot + 1) & 3, fslot = (slot + 3) & 3;
+        const int hn = h + 3 < NH ? h + 3 : NH - 1;
+        M324_WAIT_PIECES(PPW);                   // half-tile h+1 landed (this wave's pieces)
+        M324_BARRIER();
+        load_frags(1, slot, 1);
+        issue_a(hn, fslot);
+        mma8(0);
+        sched_kstep();
+        load_frags(0, nslot, 0);                 // past the end: stale but valid LDS, never used
+        issue_b(hn, fslot);
+        mma8(1);
+        sched_kstep();
         slot = nslot;
     }
-    M324_WAIT_PIECES(0);                        // no LDS-DMA may outlive the workgroup
-    if constexpr ((DBG & 32) != 0) {            // lab: no epilogue (keep the accumulators alive)
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 123.456f) C[0] = (TOUT)1;
-        return;
-    }
+    M324_WAIT_PIECES(0);                         // no LDS-DMA may outlive the main loop: the ring becomes scratch
 #undef M324_WAIT_PIECES
 #undef M324_SG
-    M324_BARRIER();                             // every wave is done with the ring: reuse it as epilogue scratch
+    M324_BARRIER();
     store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
                                       n0 + wn * 64, lane, ep);
 }
@@ -1152,7 +898,7 @@ static int xcd_remap() {
     return v;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v3|v5|v6|v7|v8 forces a variant (A/B measurements, tests).
+// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9 forces a variant (A/B measurements, tests).
 static int forced_variant() {      // read per call: lets one process A/B-toggle the variant
     const char* e = getenv("M324_GEMM");
     return (e && e[0] == 'v') ? atoi(e + 1) : 0;
@@ -1161,49 +907,24 @@ static int forced_variant() {      // read per call: lets one process A/B-toggle
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
     const int f = forced_variant();
-#ifdef M324_LAB
-    if (f >= 71 && f <= 199) return f;
-#endif
-    if (f >= 1 && f <= 8 && f != 4) return (f >= 6 && a->in_dtype != M324_BF16) ? 5 : f;
-    if (a->M <= 64 && a->in_dtype == M324_BF16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
+    const bool bf16 = a->in_dtype == M324_BF16;
+    if (f == 1 || f == 2 || f == 5) return f;
+    if (f == 7) return bf16 ? 7 : 5;
+    if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
     // CU) balance better.  Measured on the c2 shapes (tools/gemm_lab): v7 wins at >= 0.70 fill, v2 below.
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
-    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.70) return (a->in_dtype == M324_BF16 && a->K >= 96) ? 7 : 5;
+    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.70) return (bf16 && a->K >= 96) ? 7 : 5;
     return 2;
 }
 
 template <typename TOUT, int ACT, int RES>
-static void launch_stag(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep) {
-    hipLaunchKernelGGL((gemm_stag_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep) {
+    hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
                        (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
                        ceil_div(a->N, BN5), xcd_remap());
-}
-
-template <typename TOUT, int ACT, int RES>
-static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
-#ifdef M324_LAB
-#define M324_DBG_LAUNCH(D)                                                                                                  \
-    if (variant == 70 + D) {                                                                                                \
-        hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, 0, 0, 4, 4, true, D>), dim3(ceil_div(a->N, 256) * ceil_div(a->M, 256)),    \
-                           dim3(512), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc,  \
-                           a->M, a->N, a->K, ep, ceil_div(a->N, 256), xcd_remap());                                         \
-        return;                                                                                                             \
-    }
-    M324_DBG_LAUNCH(1) M324_DBG_LAUNCH(2) M324_DBG_LAUNCH(3) M324_DBG_LAUNCH(4) M324_DBG_LAUNCH(5) M324_DBG_LAUNCH(6) M324_DBG_LAUNCH(7)
-    M324_DBG_LAUNCH(8) M324_DBG_LAUNCH(16) M324_DBG_LAUNCH(32) M324_DBG_LAUNCH(64) M324_DBG_LAUNCH(96)
-#undef M324_DBG_LAUNCH
-#endif
-    if (variant == 7)
-        hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES, 4, 4, true>), dim3(ceil_div(a->N, 256) * ceil_div(a->M, 256)),
-                           dim3(512), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc,
-                           a->M, a->N, a->K, ep, ceil_div(a->N, 256), xcd_remap());
-    else
-        hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES, 2, 3, false>), dim3(ceil_div(a->N, 128) * ceil_div(a->M, 256)),
-                           dim3(256), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc,
-                           a->M, a->N, a->K, ep, ceil_div(a->N, 128), xcd_remap());
 }
 
 template <typename TIN, typename TOUT>
@@ -1226,22 +947,15 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
     } else {
         const int res = !a->residual && a->row_gin <= 0 ? 0
                         : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
-        const int ntm3 = ceil_div(a->M, BM3);
 #define M324_GLDS(ACT, RES)                                                                                              \
     do {                                                                                                                 \
-        if (variant >= 7)                                                                                                \
-            launch_pipe<TOUT, ACT, RES>(a, s, ep, variant);                                                             \
-        else if (variant == 6)                                                                                           \
-            launch_stag<TOUT, ACT, RES>(a, s, ep);                                                                      \
+        if (variant == 7)                                                                                                \
+            launch_pipe<TOUT, ACT, RES>(a, s, ep);                                                                       \
         else if (variant == 5)                                                                                           \
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
                                dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
                                a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,              \
                                ceil_div(a->N, BN5), xcd_remap());                                                        \
-        else if (variant == 3)                                                                                           \
-            hipLaunchKernelGGL((gemm_glds3_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * ntm3), dim3(512), 0, s,           \
-                               (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
-                               a->K, ep, (int)grid.x, xcd_remap());                                                      \
         else                                                                                                             \
             hipLaunchKernelGGL((gemm_glds_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * grid.y, nbatch), dim3(256), 0, s,  \
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \

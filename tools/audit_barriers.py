@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Static check of the compiled kernels: every s_barrier of a kernel that stages tiles by LDS-DMA (global_load_lds) must
 have a vmcnt wait in the 14 instructions before it -- __syncthreads() alone does NOT make the compiler wait for an
-in-flight LDS-DMA (round 1: the attention dQ kernel read a stage that had not landed).  gemm_stag (v6) is exempt by
-design: its phase barriers sit between counted waits.
+in-flight LDS-DMA (round 1: the attention dQ kernel read a stage that had not landed).
 usage: tools/audit_barriers.py   (compiles motion324_amd/csrc/{gemm,attention}.hip to assembly with hipcc)"""
 import os, re, subprocess, sys, tempfile
 
@@ -23,7 +22,7 @@ for src in ("gemm.hip", "attention.hip"):
             if name:
                 kernels[name].append(line)
     for k, ls in kernels.items():
-        if not any("global_load_lds" in l for l in ls) or "gemm_stag" in k:
+        if not any("global_load_lds" in l for l in ls):
             continue
         bad = sum(1 for i, l in enumerate(ls) if "s_barrier" in l and "vmcnt" not in "".join(ls[max(0, i - 14):i]))
         if bad:
