@@ -329,6 +329,32 @@ def test_attention_online_softmax_rescale(dtype):
     assert rel_err(out.float()[7], ref[7]) < (1e-5 if dtype == torch.float32 else 8e-3)
 
 
+@pytest.mark.parametrize("sched", ["nw4", "nw8"])
+@pytest.mark.parametrize("Lq,Lk,odd", [(2100, 2100, False), (2304, 1088, True), (2048, 640, False)])
+def test_attention_long_sequence_schedules(monkeypatch, sched, Lq, Lk, odd):
+    """The long-sequence forward schedules (4- and 8-wave workgroups: M324_ATTN_NW, read per call) on ragged lengths, odd
+    and even tile counts, prescaled Q, late / early dominant keys that force the lazy reference to move, and the LSE."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    monkeypatch.setenv("M324_ATTN_NW", "4" if sched == "nw4" else "8")
+    B, H = 1, 2
+    q, k, v = (_rand((B, H, L, 64), s_, 1.5) for L, s_ in ((Lq, 61), (Lk, 62), (Lk, 63)))
+    k[0, 0, Lk - 70] = q[0, 0, 9] * 3.0                       # q9 . k >> everything, second-to-last tile
+    k[0, 1, 130] = q[0, 1, 300] * 3.0                         # and an early one for the other head
+    k, v = _q(k, dtype), _q(v, dtype)
+    qs = _q(q * ops.Q_PRESCALE, dtype)
+    out = torch.full((B * Lq, H * 64), float("nan"), dtype=dtype, device=DEV)
+    lse = torch.full((B, H, Lq), float("nan"), dtype=torch.float32, device=DEV)
+    ops.attention(qs.to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV), out, prescaled=True, lse=lse)
+    sc = torch.einsum("bhqd,bhkd->bhqk", qs.double(), k.double())                      # log2-domain scores
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc * math.log(2.0), dim=-1), v.double()).reshape(B * Lq, H * 64)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out.float(), ref) < 8e-3
+    assert rel_err(out.float()[9], ref[9]) < 1e-2
+    lse_ref = torch.logsumexp(sc * math.log(2.0), dim=-1) / math.log(2.0)
+    assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-2
+
+
 def test_attention_nan_propagates():
     """No silent clamping: a NaN key poisons the rows that see it (failure detection)."""
     ops = _ops()
