@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from . import lib as L
-from .timing import span
+from .timing import active as _timing, span
 
 F32, BF16 = L.F32, L.BF16
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
@@ -78,7 +78,7 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, slices: int) -> torch.Tensor:
     args.in_dtype, args.out_dtype = code_of(a.dtype), F32
     args.batch, args.strideA, args.strideW, args.strideC = slices, ks, ks, M * N
     with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * main, esz * (M + N) * main + 4.0 * slices * M * N,
-              f"split-K M={M} N={N} K={main} slices={slices}"):
+              f"split-K M={M} N={N} K={main} slices={slices}" if _timing() else ""):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     if main < K:                                        # remainder of the contraction
         gemm(a[:, main:], w[:, main:], part[slices])
@@ -123,8 +123,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
         args.aux, args.ldaux = _rows(aux, "aux")
         args.aux_mode = 1 if preact_out is not None else 2
     esz = a.element_size()
-    tag = f"M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}{' gamma' if gamma is not None else ''}" \
-          f"{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}"
+    tag = "" if not _timing() else (
+        f"M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}{' gamma' if gamma is not None else ''}"
+        f"{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}")
     with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, esz * (M * K + N * K) + out.element_size() * M * N, tag):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     return out
@@ -211,7 +212,8 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     scale = 64 ** -0.5 if scale is None else scale
     esz = Q.element_size()
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
-              esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq), f"B={B} H={H} Lq={Lq} Lk={Lk}"):
+              esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq),
+              f"B={B} H={H} Lq={Lq} Lk={Lk}" if _timing() else ""):
         L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, int(prescaled), _p(lse),
                                         code_of(Q.dtype), _stream()), "m324_attention")
     return out

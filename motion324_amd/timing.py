@@ -52,6 +52,11 @@ class Recorder:
         return dict(acc)
 
 
+def active() -> bool:
+    """True while a Recorder is collecting (callers skip building tags otherwise)."""
+    return _active is not None
+
+
 class span:
     """with span(name, flops, bytes, tag): <one C-ABI launch>; `tag` (e.g. the GEMM shape) only refines by_tag()."""
     __slots__ = ("name", "flops", "nbytes", "e0", "tag")
