@@ -91,13 +91,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # M324_BENCH_BACKEND=gloo runs the N > 1 control flow with several ranks on ONE device (rehearsal of the launch line on a
+    # single-GPU box; the numbers mean nothing): the driver's real runs use RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("M324_BENCH_BACKEND", "nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to benchmark")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to benchmark")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
