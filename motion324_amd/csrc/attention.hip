@@ -275,14 +275,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(c
 //       dV^T += dOt P, dK^T += Qst dS          (A = dOt / Qst rows [d][q], permuted query order)
 // Every operand is staged by LDS-DMA into XOR-swizzled [64][128 B] tiles; two stages, one barrier per tile.
 // Scale conventions as m324_attention_bwd (include/m324.h): dQ = scale * dS K, dK = ln2 * dS^T Qs.
+// one 64-row x 128-byte tile by LDS-DMA: the 8 row groups are dealt to the NWV waves (2 pieces per wave at 4 waves, 1 at 8)
+template <int NWV>
 __device__ __forceinline__ void dma_rows(unsigned char* part, const bf16_t* src, long row_stride, int row0, int max_row, long col0,
                                          int wave, int lane) {
+    constexpr int G = 8 / NWV;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wave * 16 + i * 8 + (lane >> 3);
+    for (int i = 0; i < G; ++i) {
+        const int r = (wave * G + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const bf16_t* g = src + (long)min(row0 + r, max_row) * row_stride + col0 + c * 8;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t*)g, (lds_ptr_t*)(part + (wave * 16 + i * 8) * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)g, (lds_ptr_t*)(part + (wave * G + i) * 8 * 128), 16, 0, 0);
     }
 }
 
@@ -298,7 +301,8 @@ __device__ __forceinline__ void pack_frags(const f32x16 (&x)[2], bf16x8 (&f)[4])
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __restrict__ Qs, long q_bstride,
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_bwd_dq_mfma_kernel(const bf16_t* __restrict__ Qs, long q_bstride,
                                                                const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ dO,
                                                                const float* __restrict__ lse, const float* __restrict__ D,
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = (blockIdx.x * NW + wave) * QW + l31;
+    const int q = (blockIdx.x * NWV + wave) * QW + l31;
     const long bh = (long)b * H + h;
     const bool qok = q < Lq;
     const bf16_t* Qh = Qs + (long)b * q_bstride + (long)h * Lq * 64;
@@ -327,9 +331,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __r
     const float l2 = qok ? lse[bh * Lq + q] : 0.f, dl = qok ? D[bh * Lq + q] : 0.f;
     auto issue = [&](int t) {
         unsigned char* st = smem + (t & 1) * 24576;
-        dma_rows(st, Kh, 64, t * KV, Lk - 1, 0, wave, lane);
-        dma_rows(st + 8192, Vh, 64, t * KV, Lk - 1, 0, wave, lane);
-        dma_rows(st + 16384, Kth, Lkp, 0, 63, (long)t * KV, wave, lane);
+        dma_rows<NWV>(st, Kh, 64, t * KV, Lk - 1, 0, wave, lane);
+        dma_rows<NWV>(st + 8192, Vh, 64, t * KV, Lk - 1, 0, wave, lane);
+        dma_rows<NWV>(st + 16384, Kth, Lkp, 0, 63, (long)t * KV, wave, lane);
     };
     f32x16 acc[2];
 #pragma unroll
@@ -394,7 +398,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16_t* __r
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ Qst,
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ Qst,
                                                                 long q_bstride, long qt_bstride, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                                 const bf16_t* __restrict__ dOt, const float* __restrict__ lse,
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int kv = (blockIdx.x * NW + wave) * QW + l31;
+    const int kv = (blockIdx.x * NWV + wave) * QW + l31;
     const long bh = (long)b * H + h;
     const bool kok = kv < Lk;
     const bf16_t* Qh = Qs + (long)b * q_bstride + (long)h * Lq * 64;
@@ -426,10 +431,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16_t* __
     }
     auto issue = [&](int t) {
         unsigned char* st = smem + (t & 1) * 32768;
-        dma_rows(st, Qh, 64, t * KV, Lq - 1, 0, wave, lane);
-        dma_rows(st + 8192, dOh, 64, t * KV, Lq - 1, 0, wave, lane);
-        dma_rows(st + 16384, Qth, Lqp, 0, 63, (long)t * KV, wave, lane);
-        dma_rows(st + 24576, dOth, Lqp, 0, 63, (long)t * KV, wave, lane);
+        dma_rows<NWV>(st, Qh, 64, t * KV, Lq - 1, 0, wave, lane);
+        dma_rows<NWV>(st + 8192, dOh, 64, t * KV, Lq - 1, 0, wave, lane);
+        dma_rows<NWV>(st + 16384, Qth, Lqp, 0, 63, (long)t * KV, wave, lane);
+        dma_rows<NWV>(st + 24576, dOth, Lqp, 0, 63, (long)t * KV, wave, lane);
     };
     f32x16 ak[2], av[2];
 #pragma unroll
@@ -688,12 +693,26 @@ extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_b
     M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && H <= 65535 && B <= 65535, "m324_attention_bwd_mfma: bad sizes");
     const int Lkp = (Lk + 63) / 64 * 64, Lqp = (Lq + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(ceil_div(Lq, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs, q_bstride,
-                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D, (bf16_t*)dQ, H, Lq, Lk, Lkp,
-                       scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(ceil_div(Lk, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs,
-                       (const bf16_t*)Qst, q_bstride, qt_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO,
-                       (const bf16_t*)dOt, lse, D, (bf16_t*)dK, (bf16_t*)dV, H, Lq, Lk, Lqp);
+    // M324_ATTN_BWD_NW=8 (read per call) selects eight waves per workgroup: every staged tile then feeds 256 instead of
+    // 128 rows (half the LDS-DMA pieces per FLOP).  Unlike the forward it measured 0.7 % SLOWER on the training step
+    // (B = 8, L = 3888), so four waves stay the default.
+    const char* fnw = getenv("M324_ATTN_BWD_NW");
+    const bool w8 = fnw && atoi(fnw) == 8;
+    if (w8) {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<8>, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
+                           q_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D,
+                           (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<8>, dim3(ceil_div(Lk, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
+                           (const bf16_t*)Qst, q_bstride, qt_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO,
+                           (const bf16_t*)dOt, lse, D, (bf16_t*)dK, (bf16_t*)dV, H, Lq, Lk, Lqp);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<4>, dim3(ceil_div(Lq, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs,
+                           q_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D,
+                           (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<4>, dim3(ceil_div(Lk, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs,
+                           (const bf16_t*)Qst, q_bstride, qt_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO,
+                           (const bf16_t*)dOt, lse, D, (bf16_t*)dK, (bf16_t*)dV, H, Lq, Lk, Lqp);
+    }
     M324_CHECK_LAUNCH("m324_attention_bwd_mfma");
     return M324_OK;
 }
