@@ -73,6 +73,17 @@ typedef struct {
 int m324_gemm(const m324_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * m324_gemm_tn: C[s][n][j] (fp32) = sum over the tokens m of slice s of X[m, n] * Y[m, j]  -- the weight gradient
+ *   dW = dY^T . A of every nn.Linear (autograd of transformer.py:73-78,112-116,182-183 under train.py:166), computed
+ *   straight from the token-major bf16 activations (no transposed copies).  X [M, ldx] (N columns), Y [M, ldy] (Kc columns),
+ *   bf16; the M tokens are cut into `slices` ranges of whole 64-row tiles, slice s writes its partial at C + s * strideC
+ *   ([N, ldc]); the caller sums the partials (m324_colsum over [slices, N * ldc]) -- deterministic, no atomics.
+ *   N % 8 == 0, Kc % 8 == 0, ldx / ldy multiples of 8, 16-byte aligned bases.
+ * ------------------------------------------------------------------------------------------ */
+int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, float* C, long ldc, int M, int N, int Kc,
+                 int slices, long strideC, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * m324_layernorm: y = (x - mean) * rsqrt(var + eps) * w (+ b) over the last dim of fp32 x.
  *   replaces: nn.LayerNorm at model/transformer.py:345-346,357,400,411 (bias=False, eps 1e-5),
  *             model/Pcd_motion.py:326,337 and DINOv2 norm1/norm2/norm (eps 1e-6, with bias).

@@ -61,6 +61,17 @@ def _wgrad(dYt: torch.Tensor, At: torch.Tensor) -> torch.Tensor:
     return ops.gemm_splitk(dYt, At, slices)
 
 
+def weight_grad(dy: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    """dW [N, Ka] fp32 = dy[M, N]^T a[M, Ka].  bf16: m324_gemm_tn straight from the token-major operands (transposing LDS
+    reads); fp32 parity mode: two transposed copies + the NN kernel with split-K."""
+    M, N = dy.shape
+    Ka = a.shape[1]
+    if dy.dtype == torch.bfloat16 and N % 8 == 0 and Ka % 8 == 0:
+        tiles = ((N + 127) // 128) * ((Ka + 127) // 128)
+        return ops.gemm_tn(dy, a, max(1, min(32, (640 + tiles - 1) // tiles, M // 512)))
+    return _wgrad(ops.transpose(dy), ops.transpose(a))
+
+
 def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
     """[K', N_pad] transposed GEMM operand of a weight (for dgrad), cached like P.mat."""
     return P.derived("matT", (weight,), lambda: ops.transpose(P.mat(weight)))
@@ -73,9 +84,7 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
     M, N = dy.shape
     if bias is not None:
         G.add(bias, ops.colsum(dy))
-    dYt = ops.transpose(dy)                                   # [N, Mp]
-    At = ops.transpose(a)                                     # [Ka, Mp]
-    dW = _wgrad(dYt, At)
+    dW = weight_grad(dy, a)
     k_true = weight[0].numel()
     G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
     if not need_da:
@@ -190,8 +199,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
         bsum = ops.colsum(dkvp)
         G.add(a.to_k.bias, bsum[:C])
         G.add(a.to_v.bias, bsum[C:])
-    dYt, At = ops.transpose(dkvp), ops.transpose(kn)
-    dWkv = _wgrad(dYt, At)
+    dWkv = weight_grad(dkvp, kn)
     G.add(a.to_k.weight, dWkv[:C])
     G.add(a.to_v.weight, dWkv[C:])
     if d_kv is not None:

@@ -883,6 +883,107 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const bf16_t* __restri
     store4_out<TOUT>(C + orow * ldc + n, x.x, x.y, x.z, x.w);
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN kernel for weight gradients: C[n, j] = sum_m X[m, n] * Y[m, j]  (X = dY [M, N], Y = A [M, Kc], both token-major, as
+// the forward / dgrad GEMMs leave them).  The contraction index m is the ROW index of both operands, so the MFMA
+// fragments (8 consecutive m for one n) are columns of the LDS tile: they are fetched with gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: within a 16-lane group lane i supplies 8 bytes of row i >> 2, and lane c receives column c of
+// the resulting 4 x 16 block -- measured with tools/tr_lab), two reads per fragment.  This removes the two transpose
+// passes per Linear that the NN formulation needed (10 % of the training step).
+//   tile 128 (n) x 128 (j), 64 tokens per stage; LDS stage = X[64][128] + Y[64][128] bf16 (256-byte rows), two stages;
+//   an LDS-DMA piece = 4 rows x 256 B; slot of (row r, 16-byte chunk c) = c ^ 4 (r & 3): the four rows of a transposed
+//   read and the two column blocks of a 32-lane access land in 8 disjoint bank groups;
+//   grid.y = split-K slices over the tokens (partials summed by m324_colsum, deterministic); rows past the slice end are
+//   zeroed in LDS (X only) before they are contracted.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ Y,
+                                                         long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc, int ks,
+                                                         long strideC, int ntj) {
+    constexpr int TROW = 256;                    // bytes per LDS row (128 bf16)
+    constexpr int TOP = 64 * TROW;               // one operand of a stage: 16 KiB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 2 * TOP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = (blockIdx.x / ntj) * 128, j0 = (blockIdx.x % ntj) * 128;
+    const int mbeg = blockIdx.y * ks;
+    const int mend = blockIdx.y == gridDim.y - 1 ? M : mbeg + ks;
+    C += (long)blockIdx.y * strideC;
+
+    // staging: piece p = rows 4p .. 4p+3; wave w moves pieces 4w .. 4w+3 of X and of Y
+    const int sr = lane >> 4, sc = (lane & 15) ^ (4 * sr);       // row within the piece, source chunk of this lane's slot
+    const bf16_t* gx = X + min(n0 + sc * 8, N - 8);
+    const bf16_t* gy = Y + min(j0 + sc * 8, Kc - 8);
+    auto issue = [&](int t, int stage) {
+        unsigned char* st = smem + stage * 2 * TOP + wave * 4096;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long row = min(mbeg + t * 64 + (wave * 4 + p) * 4 + sr, mend - 1);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gx + row * ldx), (lds_ptr_t*)(st + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gy + row * ldy), (lds_ptr_t*)(st + TOP + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed fragment reads: lane (group g = lane >> 4, i = lane & 15) supplies row (i >> 2) [+ 8 (g >> 1) + 4 rd + 16 ks]
+    // and columns base + 16 (g & 1) + 4 (i & 3) .. + 3 of the wave's 32-column block
+    const int g = lane >> 4, li = lane & 15;
+    const int frow = (g >> 1) * 8 + (li >> 2);
+    auto foff = [&](int colbase) {               // byte offset inside an operand tile of this lane's piece (rd = ks = 0)
+        const int col = colbase + 16 * (g & 1) + 4 * (li & 3);
+        return frow * TROW + (((col >> 3) ^ (4 * (li >> 2))) << 4) + ((col & 7) << 1);
+    };
+    int xo[2], yo[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) xo[b] = foff(wm * 64 + b * 32), yo[b] = TOP + foff(wn * 64 + b * 32);
+    auto frag = [&](const unsigned char* st, int off, int ks16) {
+        const unsigned char* p = st + off + ks16 * (16 * TROW);
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+        const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * TROW));
+        const s16x8_t v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    const int nt = (mend - mbeg + 63) / 64;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile t landed
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        unsigned char* st = smem + (t & 1) * 2 * TOP;
+        const int valid = mend - mbeg - t * 64;                 // rows of this tile inside the slice
+        if (valid < 64) {                                       // last tile of the slice: zero the X rows past its end
+            for (int e = tid; e < (64 - valid) * 16; e += 256)
+                *reinterpret_cast<uint4*>(st + (valid + (e >> 4)) * TROW + ((e & 15) << 4)) = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16) {
+            bf16x8 xf[2], yf[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xf[b] = frag(st, xo[b], k16), yf[b] = frag(st, yo[b], k16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    Epilogue ep{};
+    store_tile_lds<float, 0, 0, 2>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, N, Kc, n0 + wm * 64,
+                                   j0 + wn * 64, lane, ep);
+}
+
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
 static bool vec_ok(const m324_gemm_args* a) {
     const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
@@ -977,6 +1078,23 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, float* C, long ldc, int M, int N, int Kc,
+                            int slices, long strideC, void* stream) {
+    M324_REQUIRE(X && Y && C, "m324_gemm_tn: null pointer");
+    M324_REQUIRE(M > 0 && N >= 8 && Kc >= 8 && N % 8 == 0 && Kc % 8 == 0, "m324_gemm_tn: bad sizes M=%d N=%d Kc=%d", M, N, Kc);
+    M324_REQUIRE(ldx >= N && ldy >= Kc && ldx % 8 == 0 && ldy % 8 == 0 && ldc >= Kc && ldc % 4 == 0 &&
+                     ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)C % 16) == 0,
+                 "m324_gemm_tn: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+    M324_REQUIRE(slices >= 1 && slices <= 65535 && (slices == 1 || strideC >= (long)N * ldc), "m324_gemm_tn: bad slicing");
+    const int ks = ((M + slices - 1) / slices + 63) / 64 * 64;          // tokens per slice, whole 64-row tiles
+    M324_REQUIRE((long)ks * (slices - 1) < M, "m324_gemm_tn: %d slices leave an empty slice for M=%d", slices, M);
+    const int ntj = ceil_div(Kc, 128);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(N, 128) * ntj, slices), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
+    M324_CHECK_LAUNCH("m324_gemm_tn");
+    return M324_OK;
+}
 
 extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
     M324_REQUIRE(a && a->A && a->W && a->C, "m324_gemm: null pointer");

@@ -186,6 +186,24 @@ def test_gemm_training_aux_operand(dtype, M, N, K):
         ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), g, preact_out=z)
 
 
+@pytest.mark.parametrize("M,N,Kc,slices", [(64, 128, 128, 1), (150, 192, 328, 1), (1000, 768, 64, 3), (4096, 2304, 768, 4),
+                                           (700, 8, 3072, 2), (65, 136, 72, 9)])
+def test_gemm_tn_weight_gradient(M, N, Kc, slices):
+    """m324_gemm_tn: dW = dY^T A straight from token-major bf16 operands (transposing LDS reads), ragged tiles in every
+    dimension, a token count that is not a multiple of the 64-row stage, split-K slices with a short last slice."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    x, y = _q(_rand((M, N), 71), dtype), _q(_rand((M, Kc), 72, 0.3), dtype)
+    out = ops.gemm_tn(x.to(dtype).to(DEV), y.to(dtype).to(DEV), slices)
+    ref = x.double().T @ y.double()
+    assert out.shape == (N, Kc) and torch.isfinite(out).all()
+    assert rel_err(out, ref) < 2e-5                       # bf16 operands, fp32 accumulation: exact products
+    # strided operands (column slices of a wider buffer, as dqkv / qkv are)
+    wide = _q(_rand((M, N + 64), 73), dtype).to(dtype).to(DEV)
+    out2 = ops.gemm_tn(wide[:, 64:], y.to(dtype).to(DEV), slices)
+    assert rel_err(out2, wide[:, 64:].float().cpu().double().T @ y.double()) < 2e-5
+
+
 def test_gemm_rejects_bad_k():
     ops = _ops()
     from motion324_amd.lib import M324Error
