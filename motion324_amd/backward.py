@@ -67,8 +67,12 @@ def weight_grad(dy: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
     M, N = dy.shape
     Ka = a.shape[1]
     if dy.dtype == torch.bfloat16 and N % 8 == 0 and Ka % 8 == 0:
-        tiles = ((N + 127) // 128) * ((Ka + 127) // 128)
-        return ops.gemm_tn(dy, a, max(1, min(32, (640 + tiles - 1) // tiles, M // 512)))
+        if N % 256 == 0 and Ka % 256 == 0 and M % 32 == 0:       # 256 x 256 tiles, one 8-wave workgroup per CU: fill 256 CUs
+            slices = max(1, min(64, 252 // ((N // 256) * (Ka // 256)), M // 512))
+        else:                                                    # 128 x 128 tiles, two workgroups per CU
+            tiles = ((N + 127) // 128) * ((Ka + 127) // 128)
+            slices = max(1, min(32, (640 + tiles - 1) // tiles, M // 512))
+        return ops.gemm_tn(dy, a, slices)
     return _wgrad(ops.transpose(dy), ops.transpose(a))
 
 

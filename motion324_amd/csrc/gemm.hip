@@ -984,6 +984,129 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
                                    j0 + wn * 64, lane, ep);
 }
 
+// TN kernel, 256 x 256 tile on the v7 pipeline (used when the slices are whole 32-token half-tiles and the output is at
+// least one 256 x 256 tile): half the LDS-DMA pieces per FLOP of the 128 x 128 kernel above, which is texture-path-bound.
+// Ring slot = X[32 m][256 n] + Y[32 m][256 j] (512-byte rows, 16 KiB each); an LDS-DMA piece = 2 rows x 512 B; slot of
+// (row r, 16-byte chunk c) = c ^ 4 (r & 3).  Per k-step a wave reads 6 fragments = 12 transposing reads for 8 MFMAs.
+__global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ Y,
+                                                              long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc,
+                                                              int ks, long strideC, int ntj) {
+    constexpr int TROW = 512, TOP = 32 * TROW;   // bytes per LDS row; one operand of a slot (16 KiB)
+    constexpr int RING = 4, PPW = 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * 2 * TOP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int n0 = (blockIdx.x / ntj) * 256, j0 = (blockIdx.x % ntj) * 256;
+    const int mbeg = blockIdx.y * ks;
+    const int mend = blockIdx.y == gridDim.y - 1 ? M : mbeg + ks;      // (mend - mbeg) % 32 == 0 (host-checked)
+    C += (long)blockIdx.y * strideC;
+
+    // staging: piece p = rows 2p, 2p+1 of the half-tile; wave w moves pieces 2w, 2w+1 (rows 4w .. 4w+3) of X and of Y
+    const int sr = lane >> 5;                    // row within the piece
+    const bf16_t* gx[2];
+    const bf16_t* gy[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (wave * 2 + p) * 2 + sr;   // row within the half-tile
+        const int c = (lane & 31) ^ (4 * (r & 3));
+        gx[p] = X + (long)(mbeg + r) * ldx + min(n0 + c * 8, N - 8);
+        gy[p] = Y + (long)(mbeg + r) * ldy + min(j0 + c * 8, Kc - 8);
+    }
+    auto issue_x = [&](int h, int slot) {
+        unsigned char* st = smem + slot * 2 * TOP + wave * 2048;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gx[p] + (long)h * 32 * ldx), (lds_ptr_t*)(st + p * 1024), 16, 0, 0);
+    };
+    auto issue_y = [&](int h, int slot) {
+        unsigned char* st = smem + slot * 2 * TOP + TOP + wave * 2048;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gy[p] + (long)h * 32 * ldy), (lds_ptr_t*)(st + p * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int g = lane >> 4, li = lane & 15;
+    const int frow = (g >> 1) * 8 + (li >> 2);
+    auto foff = [&](int colbase) {
+        const int col = colbase + 16 * (g & 1) + 4 * (li & 3);
+        return frow * TROW + (((col >> 3) ^ (4 * (li >> 2))) << 4) + ((col & 7) << 1);
+    };
+    int xo[4], yo[2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xo[b] = foff(wm * 128 + b * 32);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) yo[b] = TOP + foff(wn * 64 + b * 32);
+    bf16x8 fx[2][4], fy[2][2];
+    auto frag = [&](const unsigned char* p) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+        const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 4 * TROW));
+        const s16x8_t v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto load_frags = [&](int set, int slot, int k16) {
+        const unsigned char* base = smem + slot * 2 * TOP + k16 * (16 * TROW);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fy[set][b] = frag(base + yo[b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fx[set][b] = frag(base + xo[b]);
+    };
+    auto mma8 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[set][j], fx[set][i], acc[i][j], 0, 0, 0);
+    };
+#define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    auto sched_kstep = [&]() {                   // 12 transposing reads on the first 6 MFMAs, 2 LDS-DMA pieces on the last two
+        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x100, 2);
+        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x100, 2);
+        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x100, 2);
+        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
+    };
+#define M324_WAIT_PIECES(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    const int NH = (mend - mbeg) / 32;
+    for (int h = 0; h < RING - 1; ++h) {
+        issue_x(h < NH ? h : NH - 1, h);
+        issue_y(h < NH ? h : NH - 1, h);
+    }
+    M324_WAIT_PIECES(2 * PPW);
+    M324_BARRIER();
+    load_frags(0, 0, 0);
+    int slot = 0;
+    for (int h = 0; h < NH; ++h) {
+        const int nslot = (slot + 1) & 3, fslot = (slot + 3) & 3;
+        const int hn = h + 3 < NH ? h + 3 : NH - 1;
+        M324_WAIT_PIECES(PPW);
+        M324_BARRIER();
+        load_frags(1, slot, 1);
+        issue_x(hn, fslot);
+        mma8(0);
+        sched_kstep();
+        load_frags(0, nslot, 0);
+        issue_y(hn, fslot);
+        mma8(1);
+        sched_kstep();
+        slot = nslot;
+    }
+    M324_WAIT_PIECES(0);
+#undef M324_WAIT_PIECES
+#undef M324_SG
+    M324_BARRIER();
+    Epilogue ep{};
+    store_tile_lds<float, 0, 0, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, N, Kc, n0 + wm * 128,
+                                   j0 + wn * 64, lane, ep);
+}
+
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
 static bool vec_ok(const m324_gemm_args* a) {
     const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
@@ -1089,9 +1212,19 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
     M324_REQUIRE(slices >= 1 && slices <= 65535 && (slices == 1 || strideC >= (long)N * ldc), "m324_gemm_tn: bad slicing");
     const int ks = ((M + slices - 1) / slices + 63) / 64 * 64;          // tokens per slice, whole 64-row tiles
     M324_REQUIRE((long)ks * (slices - 1) < M, "m324_gemm_tn: %d slices leave an empty slice for M=%d", slices, M);
-    const int ntj = ceil_div(Kc, 128);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(N, 128) * ntj, slices), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
+    // 256 x 256 tiles on the pipelined kernel when every slice is whole 32-token half-tiles and the output fills the tiles
+    // (M324_GEMM_TN=128 forces the small kernel, read per call)
+    const char* ftn = getenv("M324_GEMM_TN");
+    const bool big = !(ftn && atoi(ftn) == 128) && M % 32 == 0 && N % 256 == 0 && Kc % 256 == 0 && M / slices >= 256;
+    if (big) {
+        const int ntj = Kc / 256;
+        hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3((N / 256) * ntj, slices), dim3(512), 0, (hipStream_t)stream,
+                           (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
+    } else {
+        const int ntj = ceil_div(Kc, 128);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(N, 128) * ntj, slices), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
+    }
     M324_CHECK_LAUNCH("m324_gemm_tn");
     return M324_OK;
 }

@@ -187,7 +187,8 @@ def test_gemm_training_aux_operand(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,Kc,slices", [(64, 128, 128, 1), (150, 192, 328, 1), (1000, 768, 64, 3), (4096, 2304, 768, 4),
-                                           (700, 8, 3072, 2), (65, 136, 72, 9)])
+                                           (700, 8, 3072, 2), (65, 136, 72, 9), (1024, 256, 256, 2), (8192, 768, 3072, 5),
+                                           (2080, 512, 256, 3)])
 def test_gemm_tn_weight_gradient(M, N, Kc, slices):
     """m324_gemm_tn: dW = dY^T A straight from token-major bf16 operands (transposing LDS reads), ragged tiles in every
     dimension, a token count that is not a multiple of the 64-row stage, split-K slices with a short last slice."""
@@ -202,6 +203,20 @@ def test_gemm_tn_weight_gradient(M, N, Kc, slices):
     wide = _q(_rand((M, N + 64), 73), dtype).to(dtype).to(DEV)
     out2 = ops.gemm_tn(wide[:, 64:], y.to(dtype).to(DEV), slices)
     assert rel_err(out2, wide[:, 64:].float().cpu().double().T @ y.double()) < 2e-5
+
+
+def test_gemm_tn_tile_kernels_agree(monkeypatch):
+    """The 256 x 256 pipelined TN kernel (default where it applies) and the 128 x 128 kernel (M324_GEMM_TN=128) compute
+    the same sums over the same slices: only the order inside a slice differs."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    M, N, Kc = 12288, 768, 3072
+    x, y = _q(_rand((M, N), 74), dtype).to(dtype).to(DEV), _q(_rand((M, Kc), 75, 0.3), dtype).to(dtype).to(DEV)
+    big = ops.gemm_tn(x, y, 4)
+    monkeypatch.setenv("M324_GEMM_TN", "128")
+    small = ops.gemm_tn(x, y, 4)
+    assert rel_err(big, small) < 1e-6
+    assert rel_err(big, x.float().cpu().double().T @ y.float().cpu().double()) < 2e-5
 
 
 def test_gemm_rejects_bad_k():
