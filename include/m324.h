@@ -32,7 +32,7 @@ typedef enum { M324_ACT_NONE = 0, M324_ACT_GELU = 1 } m324_act;
  *                            MLP both gelu(z) (C) and z (aux), which the backward needs (autograd of transformer.py:73-78);
  *   M324_AUX_MUL_GELU_GRAD : the result is multiplied by gelu'(aux[m,n]) = Phi(z) + z phi(z) before it is stored -- the
  *                            dgrad GEMM of the MLP's second Linear then delivers d(pre-activation) directly.           */
-typedef enum { M324_AUX_NONE = 0, M324_AUX_STORE_PREACT = 1, M324_AUX_MUL_GELU_GRAD = 2 } m324_aux_mode;
+typedef enum { M324_AUX_NONE = 0, M324_AUX_STORE_PREACT = 1, M324_AUX_MUL_GELU_GRAD = 2, M324_AUX_QKV_HEADS = 3 } m324_aux_mode;
 
 /* ABI version of this header (bumped on any signature change). */
 int m324_abi_version(void);
@@ -69,6 +69,14 @@ typedef struct {
     int batch;                                       /* <= 1: single GEMM; else `batch` independent GEMMs ...   */
     long strideA, strideW, strideC;                  /* ... whose A / W / C start strideX elements apart          */
     void* aux; long ldaux; int aux_mode;             /* training: second operand of the epilogue, see M324_AUX_*  */
+    /* M324_AUX_QKV_HEADS (inference, bf16): the [M, 3*H*64] result of a fused q|k|v projection is not stored token-major
+     * in C (C may be NULL) but split into head-major qkv_q / qkv_k / qkv_v [B, H, L, 64] (row m = b * qkv_L + l), with
+     * the per-head RMSNorm of q and k (weights qkv_qw / qkv_kw [64], NULL = none, eps qkv_eps) and q * qkv_qscale
+     * applied on the fp32 accumulators -- what m324_qkv_split does in a second pass (transformer.py:36-42,200-207).   */
+    void* qkv_q; void* qkv_k; void* qkv_v;
+    const float* qkv_qw; const float* qkv_kw;
+    float qkv_eps, qkv_qscale;
+    int qkv_L, qkv_H;
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
 
@@ -124,8 +132,11 @@ int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, con
  *   Q[Bq,H,Lq,64] (q_bstride elements between batches; 0 = one query set shared by every batch, as the
  *   decoder does with the mesh points, Pcd_motion.py:534-560), K[B,H,Lk,64], Vt[B,H,64,Lkp]
  *   (Lkp = round_up(Lk,64), zero padded).  O[B, Lq, H*64] token-major (ldo = row stride), same dtype.
- *   q_prescaled != 0: Q already holds q * scale * log2(e) (see m324_qkv_split) and `scale` is ignored.
+ *   q_prescaled is a flag word: M324_ATTN_Q_PRESCALED (1): Q already holds q * scale * log2(e) (see m324_qkv_split) and
+ *   `scale` is ignored; M324_ATTN_V_ROWMAJOR (2, bf16 only): the `Vt` argument is row-major V[B,H,Lk,64] (not transposed,
+ *   not padded) and the kernel transposes its fragments in the LDS read.
  * ------------------------------------------------------------------------------------------ */
+enum { M324_ATTN_Q_PRESCALED = 1, M324_ATTN_V_ROWMAJOR = 2 };
 int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo,
                    int B, int H, int Lq, int Lk, float scale, int q_prescaled, float* lse, int dtype, void* stream);
 /*   lse (optional, [B,H,Lq] fp32): log2-domain log-sum-exp of every score row, saved for the backward pass. */

@@ -44,8 +44,16 @@ constexpr int ASTAGE = 16384;   // K tile (8 KiB) + Vt tile (8 KiB)
 // NWV: waves per workgroup (4 or 8).  Eight waves = 256 queries share every K / Vt tile, which halves the LDS-DMA
 // pieces per FLOP (the texture path is ~90 % busy at four waves) and, for the 10 368-token global attention, turns
 // 972 workgroups on 768 slots (two rounds, the second a quarter full) into 492 on 256 slots (1.92 rounds).
-template <bool PRESCALED, int NQ, int NWV>
-__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
+// VROW: the V operand is row-major V[B,H,Lk,64] (what a fused QKV projection epilogue writes) instead of the transposed,
+// key-permuted Vt: the V tile is staged like the K tile and the A fragments of O^T = V^T P^T (8 keys of one d) are
+// fetched with the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group turns a [4 keys][16 d] block into one
+// column per lane; semantics measured with tools/tr_lab), picking the keys in the order the swapped MFMA contracts them.
+typedef __attribute__((ext_vector_type(4))) short a_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short a_s16x8_t;
+typedef __attribute__((address_space(3))) a_s16x4_t a_lds_s16x4_t;
+
+template <bool PRESCALED, int NQ, int NWV, bool VROW = false>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
                                                         int Lkp, float scale_log2e, float* __restrict__ lse) {
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(c
 
     const bf16_t* Qh = Q + (long)b * q_bstride + (long)h * Lq * 64;
     const bf16_t* Kh = K + ((long)b * H + h) * (long)Lk * 64;
-    const bf16_t* Vh = Vt + ((long)b * H + h) * 64 * (long)Lkp;
+    const bf16_t* Vh = Vt + ((long)b * H + h) * (VROW ? (long)Lk * 64 : 64 * (long)Lkp);
 
     // Q fragments (B operand): lane (q = l31, hi) holds Q[q][ks*16 + hi*8 .. +7] for ks = 0..3
     bf16x8 qf[NQ][4];
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(c
     for (int i = 0; i < GPW; ++i) {
         srow[i] = (wave * GPW + i) * 8 + (lane >> 3);
         scol[i] = ((lane & 7) ^ ((srow[i] >> 1) & 7)) * 8;
-        gv[i] = Vh + (long)srow[i] * Lkp + scol[i];
+        // VROW: V rows are keys; slot swizzle c ^ 4 ((row >> 1) & 1) keeps the 4 rows x 64 B of a transposing read apart
+        gv[i] = VROW ? Vh + ((lane & 7) ^ (4 * ((srow[i] >> 1) & 1))) * 8 : Vh + (long)srow[i] * Lkp + scol[i];
     }
     auto issue_tile = [&](int t) {
         const int kv0 = t * KV;
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(c
         }
 #pragma unroll
         for (int i = 0; i < GPW; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gv[i] + kv0), (lds_ptr_t*)(sv + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(VROW ? gv[i] + (long)min(kv0 + srow[i], Lk - 1) * 64 : gv[i] + kv0),
+                                             (lds_ptr_t*)(sv + i * 1024), 16, 0, 0);
     };
 
     f32x16 o[NQ][2];
@@ -231,7 +241,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 1) void attn_bf16_kernel(c
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + k_off(db * 32 + l31, 2 * j + hi));
+                bf16x8 vf;
+                if constexpr (VROW) {
+                    // lane (group g = lane >> 4, i = lane & 15) supplies key row j*16 + 4 hi + 8 rd + (i >> 2), d columns
+                    // db*32 + 16 (g & 1) + 4 (i & 3) .. + 3; it receives keys {4hi..4hi+3} (rd 0) and {8+4hi..} (rd 1) of d = l31
+                    const int li = lane & 15, gg = lane >> 4;
+                    const int d0 = db * 32 + 16 * (gg & 1) + 4 * (li & 3);
+                    const int off = (j * 16 + 4 * hi + (li >> 2)) * 128 + (((d0 >> 3) ^ (4 * ((li >> 3) & 1))) << 4) + ((d0 & 7) << 1);
+                    const a_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s16x4_t*)(sv + off));
+                    const a_s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s16x4_t*)(sv + off + 8 * 128));
+                    const a_s16x8_t v8 = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    vf = __builtin_bit_cast(bf16x8, v8);
+                } else {
+                    vf = *reinterpret_cast<const bf16x8*>(sv + k_off(db * 32 + l31, 2 * j + hi));
+                }
 #pragma unroll
                 for (int n = 0; n < NQ; ++n)
                     o[n][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[n][j], o[n][db], 0, 0, 0);
@@ -652,12 +675,15 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
     const int Lkp = (Lk + 63) / 64 * 64;
     dim3 grid(ceil_div(Lq, QB), H, B);
     hipStream_t s = (hipStream_t)stream;
+    const bool vrow = (q_prescaled & M324_ATTN_V_ROWMAJOR) != 0;
+    q_prescaled &= M324_ATTN_Q_PRESCALED;
+    M324_REQUIRE(!vrow || dtype == M324_BF16, "m324_attention: row-major V needs the bf16 kernel (transposing LDS reads)");
     const float sl = q_prescaled ? 1.0f : scale * LOG2E;
     if (dtype == M324_BF16) {
         M324_REQUIRE((ldo * 2) % 8 == 0, "m324_attention: ldo misaligned");
         // NQ = 2 (two query blocks per wave) measured slower than NQ = 1 on MI355X (254 VGPRs -> one wave per
         // SIMD); it stays selectable for experiments only.
-        const bool nq2 = getenv("M324_ATTN_NQ2") != nullptr && Lq >= 1024;
+        const bool nq2 = getenv("M324_ATTN_NQ2") != nullptr && Lq >= 1024 && !vrow;
         // eight waves per workgroup for long query sets (M324_ATTN_NW=4|8 forces; read per call for A/B runs)
         const char* fnw = getenv("M324_ATTN_NW");
         const bool w8 = !nq2 && (fnw ? atoi(fnw) == 8 : (Lq >= 2048 && Lk >= 512));
@@ -671,8 +697,15 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
 #define M324_ATTN(PS, NQ, NWV)                                                                                          \
     hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ, NWV>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,         \
                        (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse)
-        if (q_prescaled) { if (nq2) M324_ATTN(true, 2, 4); else if (w8) M324_ATTN(true, 1, 8); else M324_ATTN(true, 1, 4); }
+#define M324_ATTN_VR(PS, NWV)                                                                                            \
+    hipLaunchKernelGGL((attn_bf16_kernel<PS, 1, NWV, true>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,    \
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse)
+        if (vrow) {
+            if (q_prescaled) { if (w8) M324_ATTN_VR(true, 8); else M324_ATTN_VR(true, 4); }
+            else { if (w8) M324_ATTN_VR(false, 8); else M324_ATTN_VR(false, 4); }
+        } else if (q_prescaled) { if (nq2) M324_ATTN(true, 2, 4); else if (w8) M324_ATTN(true, 1, 8); else M324_ATTN(true, 1, 4); }
         else { if (nq2) M324_ATTN(false, 2, 4); else if (w8) M324_ATTN(false, 1, 8); else M324_ATTN(false, 1, 4); }
+#undef M324_ATTN_VR
 #undef M324_ATTN
     } else if (dtype == M324_F32) {
         M324_REQUIRE(ldo % 4 == 0, "m324_attention: ldo misaligned");

@@ -33,6 +33,10 @@ struct Epilogue {
     void* aux;
     long ldaux;
     int aux_mode;
+    bf16_t* qkv_out[3];          // M324_AUX_QKV_HEADS: head-major q, k, v
+    const float* qkv_w[2];       // RMSNorm weights of q, k (or null)
+    float qkv_eps, qkv_qscale;
+    int qkv_L, qkv_H;
 };
 
 // GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
@@ -369,8 +373,67 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             }
         }
     };
+    // fused q|k|v projection (M324_AUX_QKV_HEADS): this wave's 64 columns are one head of q (which = 0), k (1) or v (2).
+    // 8 columns per lane: a row's 64 values sit in the 8 lanes that share lane >> 3, so the per-head RMSNorm is three
+    // xor-shuffles inside the group, and a (token, head) row leaves as 8 x 16 bytes = one 128-byte line.
+    auto body_qkv = [&]() {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const int hc = ep.qkv_H * 64, which = nw / hc, head = (nw % hc) >> 6;
+        const int n8 = nw + c8;
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, w0 = make_float4(1.f, 1.f, 1.f, 1.f), w1 = w0;
+        if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
+        const bool norm = which < 2 && ep.qkv_w[which] != nullptr;
+        if (norm) {
+            w0 = *reinterpret_cast<const float4*>(ep.qkv_w[which] + c8);
+            w1 = *reinterpret_cast<const float4*>(ep.qkv_w[which] + c8 + 4);
+        }
+        const float post = which == 0 ? ep.qkv_qscale : 1.0f;
+        bf16_t* const base = ep.qkv_out[which] + (long)head * ep.qkv_L * 64 + c8;
+        const float* rd8 = scr + r8 * EP_LD + c8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            float4 v0[4], v1[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
+                v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
+            }
+            // token of pass p: m = mw + 32 i + r8 + 8 p  ->  (batch, position); one division per block, then steps of 8
+            const int m0r = mw + i * 32 + r8;
+            int bb = m0r / ep.qkv_L, ll = m0r - bb * ep.qkv_L;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 x = v0[p], y = v1[p];
+                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                float rs = post;
+                if (norm) {
+                    float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w + y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+                    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                    rs *= rsqrtf(ss * (1.0f / 64.0f) + ep.qkv_eps);
+                }
+                x.x *= rs * w0.x; x.y *= rs * w0.y; x.z *= rs * w0.z; x.w *= rs * w0.w;
+                y.x *= rs * w1.x; y.y *= rs * w1.y; y.z *= rs * w1.z; y.w *= rs * w1.w;
+                if (m0r + 8 * p < M && n8 < N)
+                    *reinterpret_cast<uint4*>(base + (((long)bb * ep.qkv_H) * ep.qkv_L + ll) * 64) =
+                        make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+                ll += 8;
+                while (ll >= ep.qkv_L) { ll -= ep.qkv_L; ++bb; }
+            }
+        }
+    };
     const bool interior = mw + MI * 32 <= M && nw + 64 <= N;
-    if constexpr (sizeof(TOUT) == 2 && RES == 0) {
+    if constexpr (ACT == 4) {
+        body_qkv();
+        return;
+    }
+    if constexpr (sizeof(TOUT) == 2 && RES == 0 && ACT != 4) {
         if (interior && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
             (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0) &&
             (ACT < 2 || ((ep.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0))) {
@@ -1154,7 +1217,9 @@ static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& 
 template <typename TIN, typename TOUT>
 int launch(const m324_gemm_args* a, hipStream_t s) {
     Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off,
-                a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode};
+                a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode,
+                {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
+                a->qkv_L, a->qkv_H};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
@@ -1185,7 +1250,9 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
                                a->K, ep, (int)grid.x, xcd_remap());                                                      \
     } while (0)
-        if (a->aux_mode == M324_AUX_STORE_PREACT) {
+        if (a->aux_mode == M324_AUX_QKV_HEADS) {
+            if constexpr (sizeof(TOUT) == 2) M324_GLDS(4, 0);
+        } else if (a->aux_mode == M324_AUX_STORE_PREACT) {
             M324_GLDS(2, 0);
         } else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD) {
             M324_GLDS(3, 0);
@@ -1230,7 +1297,7 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
 }
 
 extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
-    M324_REQUIRE(a && a->A && a->W && a->C, "m324_gemm: null pointer");
+    M324_REQUIRE(a && a->A && a->W && (a->C || a->aux_mode == M324_AUX_QKV_HEADS), "m324_gemm: null pointer");
     M324_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "m324_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     const int bk = a->in_dtype == M324_BF16 ? 64 : 32;
     M324_REQUIRE(a->K % bk == 0, "m324_gemm: K=%d must be a multiple of %d", a->K, bk);
@@ -1242,8 +1309,16 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
     M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
                  "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
-    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 2, "m324_gemm: aux_mode %d", a->aux_mode);
-    if (a->aux_mode) {
+    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 3, "m324_gemm: aux_mode %d", a->aux_mode);
+    if (a->aux_mode == M324_AUX_QKV_HEADS) {
+        M324_REQUIRE(a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16 && a->qkv_q && a->qkv_k && a->qkv_v && a->qkv_H > 0 &&
+                         a->qkv_L > 0 && a->N == 3 * a->qkv_H * 64 && a->M % a->qkv_L == 0 && !a->residual && !a->gamma &&
+                         a->act == M324_ACT_NONE && a->row_gin <= 0 && a->batch <= 1 && a->M > 64 && vec_ok(a),
+                     "m324_gemm: M324_AUX_QKV_HEADS needs a plain bf16 [B*L, 3*H*64] projection with M > 64");
+        M324_REQUIRE(((uintptr_t)a->qkv_q % 16) == 0 && ((uintptr_t)a->qkv_k % 16) == 0 && ((uintptr_t)a->qkv_v % 16) == 0 &&
+                         (!a->qkv_qw || ((uintptr_t)a->qkv_qw % 16) == 0) && (!a->qkv_kw || ((uintptr_t)a->qkv_kw % 16) == 0),
+                     "m324_gemm: misaligned qkv outputs / norm weights");
+    } else if (a->aux_mode) {
         const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
         M324_REQUIRE(a->aux && a->ldaux >= a->N && a->ldaux % 4 == 0 && ((uintptr_t)a->aux % (4 * osz)) == 0 && vec_ok(a) &&
                          a->row_gin <= 0 && a->batch <= 1,

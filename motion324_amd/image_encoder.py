@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from . import ops
 from .lib import ACT_GELU
 from .prepared import Prepared, pad_k
+from .transformer import fuse_qkv
 
 DINO_EPS = 1e-6
 
@@ -137,14 +138,23 @@ class DinoEncoder(nn.Module):
                  residual=pos[1:], res_rows=g * g, row_map=(g * g, Lt, 1))
         ops.dino_cls_rows(P.f32(m.cls_token).reshape(-1), pos[0], x, Fr, Lt)
         h = torch.empty((Fr * Lt, C), dtype=P.dtype, device=video.device)
-        qkv = torch.empty((Fr * Lt, 3 * C), dtype=P.dtype, device=video.device)
+        fused = fuse_qkv(P, Fr * Lt, Lt)           # projection epilogue writes head-major Q / K / V (no m324_qkv_split pass)
+        if fused:
+            Qh, Kh, Vh = (torch.empty((Fr, H, Lt, 64), dtype=P.dtype, device=video.device) for _ in range(3))
+        else:
+            qkv = torch.empty((Fr * Lt, 3 * C), dtype=P.dtype, device=video.device)
         h1 = torch.empty((Fr * Lt, m.blocks[0].mlp.fc1.out_features), dtype=P.dtype, device=video.device)
         for blk in m.blocks:
             ops.layernorm(x, P.vec(blk.norm1.weight), P.vec(blk.norm1.bias), DINO_EPS, h)
-            ops.gemm(h, P.mat(blk.attn.qkv.weight), qkv, bias=P.vec(blk.attn.qkv.bias))
-            Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, None, 0.0, Fr, Lt, H, P.dtype,
-                                     q_scale=ops.Q_PRESCALE)
-            ops.attention(Q, K, Vt, h, prescaled=True)
+            if fused:
+                ops.gemm(h, P.mat(blk.attn.qkv.weight), None, bias=P.vec(blk.attn.qkv.bias),
+                         qkv_heads=(Qh, Kh, Vh, None, None, 0.0, ops.Q_PRESCALE, Lt, H))
+                ops.attention(Qh, Kh, Vh, h, prescaled=True, v_rowmajor=True)
+            else:
+                ops.gemm(h, P.mat(blk.attn.qkv.weight), qkv, bias=P.vec(blk.attn.qkv.bias))
+                Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, None, 0.0, Fr, Lt, H, P.dtype,
+                                         q_scale=ops.Q_PRESCALE)
+                ops.attention(Q, K, Vt, h, prescaled=True)
             ops.gemm(h, P.mat(blk.attn.proj.weight), x, bias=P.vec(blk.attn.proj.bias), gamma=P.vec(blk.ls1.gamma),
                      residual=x)
             ops.layernorm(x, P.vec(blk.norm2.weight), P.vec(blk.norm2.bias), DINO_EPS, h)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libm324.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 8
 
 
 class M324Error(RuntimeError):
@@ -36,6 +36,9 @@ class GemmArgs(C.Structure):
         ("batch", C.c_int),
         ("strideA", C.c_long), ("strideW", C.c_long), ("strideC", C.c_long),
         ("aux", C.c_void_p), ("ldaux", C.c_long), ("aux_mode", C.c_int),
+        ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_v", C.c_void_p),
+        ("qkv_qw", C.c_void_p), ("qkv_kw", C.c_void_p),
+        ("qkv_eps", C.c_float), ("qkv_qscale", C.c_float), ("qkv_L", C.c_int), ("qkv_H", C.c_int),
     ]
 
 

@@ -106,10 +106,13 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = L.ACT_NONE, gamma=None,
          residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0),
-         preact_out: Optional[torch.Tensor] = None, gelu_grad_of: Optional[torch.Tensor] = None) -> torch.Tensor:
+         preact_out: Optional[torch.Tensor] = None, gelu_grad_of: Optional[torch.Tensor] = None,
+         qkv_heads: Optional[tuple] = None) -> torch.Tensor:
     """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm.
     preact_out [M, N] (out's dtype) also receives the value the activation is applied to (M324_AUX_STORE_PREACT);
-    gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only."""
+    gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only.
+    qkv_heads = (Q, K, V, q_w, k_w, eps, q_scale, L, H): the fused q|k|v projection is written head-major into Q / K / V
+    [B, H, L, 64] with per-head RMSNorm and the q pre-scale (M324_AUX_QKV_HEADS); `out` is ignored (may be None)."""
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K or a.dtype != w.dtype:
@@ -117,8 +120,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     args = L.GemmArgs()
     args.A, args.lda = _rows(a, "a")
     args.W, args.ldw = _rows(w, "w")
-    args.C, args.ldc = _rows(out, "out")
     args.M, args.N, args.K = M, N, K
+    if qkv_heads is not None:
+        Qo, Ko, Vo, qw, kw, eps, q_scale, Lh, Hh = qkv_heads
+        Bh = M // Lh
+        for t in (Qo, Ko, Vo):
+            if t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (Bh, Hh, Lh, 64):
+                raise L.M324Error(f"gemm: qkv_heads output {t.dtype}{tuple(t.shape)} (want bf16 {(Bh, Hh, Lh, 64)})")
+        args.C, args.ldc = None, N
+        args.in_dtype, args.out_dtype = code_of(a.dtype), BF16
+        args.bias = _vec(bias, N, "bias")
+        args.aux_mode = 3
+        args.qkv_q, args.qkv_k, args.qkv_v = _p(Qo), _p(Ko), _p(Vo)
+        args.qkv_qw, args.qkv_kw = _vec(qw, 64, "q_w"), _vec(kw, 64, "k_w")
+        args.qkv_eps, args.qkv_qscale, args.qkv_L, args.qkv_H = eps, q_scale, Lh, Hh
+        with span("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), f"M={M} N={N} K={K} qkv-heads" if _timing() else ""):
+            L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
+        return Qo
+    args.C, args.ldc = _rows(out, "out")
     args.in_dtype, args.out_dtype = code_of(a.dtype), code_of(out.dtype)
     args.bias = _vec(bias, N, "bias")
     args.act = act
@@ -211,13 +230,15 @@ def qkv_split(q_src, k_src, v_src, q_w, k_w, eps: float, B: int, Lq: int, H: int
 
 
 def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Tensor, *, shared_q: bool = False,
-              scale: Optional[float] = None, prescaled: bool = False, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+              scale: Optional[float] = None, prescaled: bool = False, lse: Optional[torch.Tensor] = None,
+              v_rowmajor: bool = False) -> torch.Tensor:
     """out[B*Lq, H*64] = softmax(Q K^T scale) V.  Q[Bq,H,Lq,64] (Bq == 1 with shared_q), K[B,H,Lk,64],
-    Vt[B,H,64,Lkp].  prescaled: Q was produced with qkv_split(q_scale=Q_PRESCALE)."""
+    Vt[B,H,64,Lkp] -- or, with v_rowmajor (bf16 only), V[B,H,Lk,64].  prescaled: Q carries Q_PRESCALE."""
     B, H, Lk, D = K.shape
     Lq = Q.shape[2]
-    if D != 64 or Q.shape[3] != 64 or Q.shape[1] != H or Vt.shape[:3] != (B, H, 64) or Vt.shape[3] != (Lk + 63) // 64 * 64:
-        raise L.M324Error(f"attention: Q{tuple(Q.shape)} K{tuple(K.shape)} Vt{tuple(Vt.shape)}")
+    vshape = (B, H, Lk, 64) if v_rowmajor else (B, H, 64, (Lk + 63) // 64 * 64)
+    if D != 64 or Q.shape[3] != 64 or Q.shape[1] != H or tuple(Vt.shape) != vshape:
+        raise L.M324Error(f"attention: Q{tuple(Q.shape)} K{tuple(K.shape)} V{tuple(Vt.shape)} (want {vshape})")
     if not (Q.is_contiguous() and K.is_contiguous() and Vt.is_contiguous()):
         raise L.M324Error("attention: operands must be contiguous")
     if Q.dtype != K.dtype or K.dtype != Vt.dtype or out.dtype != Q.dtype:
@@ -233,8 +254,9 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
               esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq),
               f"B={B} H={H} Lq={Lq} Lk={Lk}" if _timing() else ""):
-        L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale, int(prescaled), _p(lse),
-                                        code_of(Q.dtype), _stream()), "m324_attention")
+        L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale,
+                                        int(prescaled) | (2 if v_rowmajor else 0), _p(lse), code_of(Q.dtype), _stream()),
+                "m324_attention")
     return out
 
 

@@ -47,6 +47,14 @@ def _point_features_bwd(model, P: Prepared, G: bw.GradStore, enc, feat, d_pf: to
 
 def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None
                      ) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
+    """One training step's forward + hand-written backward (see _forward_backward); inference-only fusions are off."""
+    from .transformer import fusion_disabled
+    with fusion_disabled():
+        return _forward_backward(model, sample, grad_scale, drop_seed)
+
+
+def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None
+                      ) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
     """Returns (loss [0-dim fp32], pcd_moved [B,T,N,3] fp32, GradStore with d(grad_scale * loss)/d param).
     pos_drop (reference :369-370,490; p = transformer.drop_rate, default 0.1) is applied to the video tokens when
     model.training; its mask is a function of ``drop_seed`` (default: drawn from torch's CPU generator, so

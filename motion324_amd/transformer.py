@@ -14,6 +14,8 @@ the residual stream is always fp32, as it is in the reference under autocast (SU
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -105,6 +107,33 @@ def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor) -
     return x
 
 
+# Fused q|k|v projection epilogue (m324_gemm M324_AUX_QKV_HEADS + row-major-V attention) for bf16 inference on sequences
+# below 2048 tokens; longer ones keep m324_qkv_split's transposed V, whose 8-wave attention kernel is 9 % faster than
+# its transposing-read variant.  M324_FUSE_QKV=0 disables (A/B measurements).
+FUSE_QKV = os.environ.get("M324_FUSE_QKV", "1") != "0"
+
+
+_FUSE_OFF = 0
+
+
+class fusion_disabled:
+    """Training steps run their forward inside this context (the backward recomputes with m324_qkv_split's training
+    outputs, and an autograd.Function's forward runs with grad mode off, so grad mode alone cannot tell)."""
+
+    def __enter__(self):
+        global _FUSE_OFF
+        _FUSE_OFF += 1
+
+    def __exit__(self, *exc):
+        global _FUSE_OFF
+        _FUSE_OFF -= 1
+
+
+def fuse_qkv(P: Prepared, rows: int, L: int) -> bool:
+    return (FUSE_QKV and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64 and L < 2048
+            and not torch.is_grad_enabled())
+
+
 class QK_Norm_TransformerBlock(nn.Module):
     """Pre-norm self-attention block (reference transformer.py:379-423)."""
 
@@ -127,9 +156,18 @@ class QK_Norm_TransformerBlock(nn.Module):
         a = self.attn
         h = torch.empty((rows, C), dtype=P.dtype, device=x.device)
         ops.layernorm(x, P.vec(self.norm1.weight), P.vec(self.norm1.bias), self.norm1.eps, h)
+        qw, kw = a._qk_w(P)
+        if fuse_qkv(P, rows, L) and kv_gather is None:
+            # short sequences (the per-frame blocks): the projection's epilogue writes head-major Q / K / V itself
+            # (RMSNorm + q pre-scale on the fp32 accumulators) and the attention reads V row-major
+            Q, K, V = (torch.empty((B, a.num_heads, L, 64), dtype=P.dtype, device=x.device) for _ in range(3))
+            ops.gemm(h, P.mat(a.to_qkv.weight), None, bias=P.vec(a.to_qkv.bias),
+                     qkv_heads=(Q, K, V, qw, kw, RMS_EPS, ops.Q_PRESCALE, L, a.num_heads))
+            ops.attention(Q, K, V, h, prescaled=True, v_rowmajor=True)
+            ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
+            return _mlp_residual(P, self.norm2, self.mlp, x)
         qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)
         ops.gemm(h, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
-        qw, kw = a._qk_w(P)
         if kv_gather is None:
             Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads,
                                      P.dtype, q_scale=ops.Q_PRESCALE)

@@ -219,6 +219,39 @@ def test_gemm_tn_tile_kernels_agree(monkeypatch):
     assert rel_err(big, x.float().cpu().double().T @ y.float().cpu().double()) < 2e-5
 
 
+@pytest.mark.parametrize("B,L,H,norm,bias", [(2, 100, 3, True, False), (32, 324, 12, True, False), (3, 257, 12, False, True),
+                                            (1, 2100, 4, True, False)])
+def test_gemm_qkv_heads_epilogue(B, L, H, norm, bias):
+    """M324_AUX_QKV_HEADS: the fused q|k|v projection written head-major with per-head RMSNorm and the q pre-scale ==
+    m324_gemm followed by m324_qkv_split (both round q, k, v to bf16 once, from fp32); row-major V feeds m324_attention
+    with M324_ATTN_V_ROWMAJOR.  Ragged batches (L not a multiple of the 32-row blocks), DINO's bias-without-norm form."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    C, K = H * 64, 192
+    x = _q(_rand((B * L, K), 91), dtype).to(dtype).to(DEV)
+    w = _q(_rand((3 * C, K), 92, 0.1), dtype).to(dtype).to(DEV)
+    b = _rand((3 * C,), 93).to(DEV) if bias else None
+    qw, kw = ((1 + 0.1 * _rand((64,), 94)).to(DEV), (1 + 0.1 * _rand((64,), 95)).to(DEV)) if norm else (None, None)
+    Q, Kk, V = (torch.full((B, H, L, 64), float("nan"), dtype=dtype, device=DEV) for _ in range(3))
+    ops.gemm(x, w, None, bias=b, qkv_heads=(Q, Kk, V, qw, kw, 1e-5, ops.Q_PRESCALE, L, H))
+    # reference in fp64 from the same bf16 operands
+    y = x.float().cpu().double() @ w.float().cpu().double().T + (b.cpu().double() if bias else 0.0)
+    q, k, v = (t.reshape(B, L, H, 64).permute(0, 2, 1, 3) for t in y.chunk(3, dim=-1))
+    if norm:
+        q = q * torch.rsqrt((q * q).mean(-1, keepdim=True) + 1e-5) * qw.cpu().double()
+        k = k * torch.rsqrt((k * k).mean(-1, keepdim=True) + 1e-5) * kw.cpu().double()
+    q = q * ops.Q_PRESCALE
+    for got, ref in ((Q, q), (Kk, k), (V, v)):
+        assert torch.isfinite(got.float()).all()
+        assert rel_err(got.float(), ref) < 4e-3
+    # attention on the fused outputs == attention on the two-pass outputs (up to one bf16 rounding of qkv in between)
+    out_f = torch.empty((B * L, C), dtype=dtype, device=DEV)
+    ops.attention(Q, Kk, V, out_f, prescaled=True, v_rowmajor=True)
+    sc = torch.einsum("bhqd,bhkd->bhqk", q, k) * math.log(2.0)
+    ref_o = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, dim=-1), v).reshape(B * L, C)
+    assert rel_err(out_f.float(), ref_o) < 1e-2
+
+
 def test_gemm_rejects_bad_k():
     ops = _ops()
     from motion324_amd.lib import M324Error
@@ -386,6 +419,25 @@ def test_attention_long_sequence_schedules(monkeypatch, sched, Lq, Lk, odd):
     assert rel_err(out.float()[9], ref[9]) < 1e-2
     lse_ref = torch.logsumexp(sc * math.log(2.0), dim=-1) / math.log(2.0)
     assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 64, 64), (2, 3, 100, 100), (1, 12, 324, 324), (2, 12, 257, 257), (1, 2, 2100, 2100),
+                                       (3, 2, 200, 64), (1, 1, 70, 1000)])
+def test_attention_row_major_v(B, H, Lq, Lk):
+    """M324_ATTN_V_ROWMAJOR: V[B,H,Lk,64] as the fused QKV projection writes it, fragments transposed in the LDS read --
+    same result as the transposed / permuted Vt operand (only the bf16 rounding of P is shared; sums in the same order)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    q, k, v = (_q(_rand((B, H, L, 64), s_, sc), dtype) for L, s_, sc in ((Lq, 81, 1.5), (Lk, 82, 1.5), (Lk, 83, 1.0)))
+    dq, dk, dv = (t.to(dtype).to(DEV) for t in (q, k, v))
+    out_t = torch.empty((B * Lq, H * 64), dtype=dtype, device=DEV)
+    out_r = torch.full((B * Lq, H * 64), float("nan"), dtype=dtype, device=DEV)
+    ops.attention(dq, dk, vt_layout(v).to(dtype).to(DEV), out_t)
+    ops.attention(dq, dk, dv, out_r, v_rowmajor=True)
+    ref = _attn_ref(q, k, v, 64 ** -0.5).reshape(B * Lq, H * 64)
+    assert torch.isfinite(out_r.float()).all()
+    assert rel_err(out_r.float(), ref) < 8e-3
+    assert torch.equal(out_r, out_t)                       # identical arithmetic, different operand layout
 
 
 def test_attention_nan_propagates():

@@ -93,3 +93,8 @@ if args.what in ("attn", "all"):
         fn = lambda: ops.attention(q, k, vt, out, shared_q=shared, prescaled=True)
         ms = timeit(fn, max(3, args.iters // (1 + Lk // 20000 * 10)))
         print(f"attn {name:12s} B={B:3d} H={H} Lq={Lq:6d} Lk={Lk:6d}  {ms * 1e3:9.1f} us  {4.0 * B * H * Lq * Lk * 64 / ms / 1e9:7.1f} TF/s", flush=True)
+        if dt == torch.bfloat16:                    # row-major V operand (transposing LDS reads)
+            vr = torch.randn(B, H, Lk, 64, device=dev).to(dt)
+            fr = lambda: ops.attention(q, k, vr, out, shared_q=shared, prescaled=True, v_rowmajor=True)
+            ms2 = timeit(fr, max(3, args.iters // (1 + Lk // 20000 * 10)))
+            print(f"     {'row-major V':12s} {'':38s}{ms2 * 1e3:9.1f} us  {4.0 * B * H * Lq * Lk * 64 / ms2 / 1e9:7.1f} TF/s", flush=True)
