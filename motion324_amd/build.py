@@ -14,12 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libm324.so")
-SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "elementwise.hip", "backward.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "m324.h")]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "attention.hip", "elementwise.hip", "backward.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(HERE, "..", "include", "m324.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified 512-entry file), which removes the
 # v_accvgpr_read/write shuffling around every softmax / epilogue access of an accumulator
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-mllvm", "-amdgpu-mfma-vgpr-form"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# gemm_ring4.hip: 256 accumulators per wave -> they must stay in the AGPR half (see the file header)
+FLAGS_OF = {"gemm_ring4.hip": BASE_FLAGS}
 
 
 def _hipcc() -> str:
@@ -46,7 +48,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS_OF.get(src, FLAGS) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -12,438 +12,10 @@
 // ds_read_b128 (bf16) and 2-way ds_read_b64 (fp32 parity mode).
 // Pipeline: global -> registers (issued before the MFMAs of the current tile) -> LDS (after them),
 // double-buffered LDS, one barrier per K-tile.
-#include <stdlib.h>
-#include <type_traits>
-#include "common.h"
+
+#include "gemm_tile.h"
 
 namespace {
-
-constexpr int BM = 128, BN = 128, ROWB = 128;           // ROWB: bytes of K per LDS row
-constexpr int TILE_BYTES = BM * ROWB;                   // 16 KiB per operand per stage
-
-struct Epilogue {
-    const float* bias;
-    const float* gamma;
-    const float* residual;
-    long ldr;
-    int res_rows;
-    int act;
-    int row_gin, row_gout, row_off;
-    long strideA, strideW, strideC;
-    void* aux;
-    long ldaux;
-    int aux_mode;
-    bf16_t* qkv_out[3];          // M324_AUX_QKV_HEADS: head-major q, k, v
-    const float* qkv_w[2];       // RMSNorm weights of q, k (or null)
-    float qkv_eps, qkv_qscale;
-    int qkv_L, qkv_H;
-};
-
-// GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
-// bf16 rounding of the result); the fp32 parity path keeps erff.  ~12 VALU + 2 transcendental ops
-// instead of ocml's branchy erff -- the fc1 epilogue (128x128 GELUs per workgroup) is otherwise as
-// long as its whole K = 768 main loop.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 1 - erf(z), z >= 0
-    const float phi = x >= 0.f ? 1.0f - 0.5f * erfc_z : 0.5f * erfc_z;                       // Phi(x)
-    return x * phi;
-}
-
-// Two GELUs per instruction stream for the bf16 epilogue: erf(z) = z P(z^2) on |z| <= 3 (odd minimax polynomial, 9
-// coefficients, |erf error| <= 1.7e-5; beyond the clamp erf(3) = 0.99998 stands in for 1), evaluated with packed fp32
-// FMAs (v_pk_fma_f32) and no transcendental.  |GELU error| <= 7e-5 absolute -- below the bf16 rounding step of every
-// output larger than 0.02 -- at about a third of the issue slots of the rcp/exp form above.
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2v gelu_poly2(f32x2v x) {
-    f32x2v z = x * 0.70710678118654752440f;
-    z.x = __builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f);
-    z.y = __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f);
-    const f32x2v t = z * z;
-    f32x2v p = (f32x2v)(4.074096087e-08f);
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-1.944782217e-06f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.105993727e-05f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-5.110323815e-04f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.235408041e-03f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-2.510281415e-02f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.110792751e-01f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-3.753148415e-01f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.128268421e+00f));
-    const f32x2v hx = x * 0.5f;
-    return __builtin_elementwise_fma(hx, z * p, hx);
-}
-
-template <typename TOUT>
-__device__ __forceinline__ void apply_gelu4(float4& v) {
-    if constexpr (sizeof(TOUT) == 2) {
-        f32x2v a = {v.x, v.y}, b = {v.z, v.w};
-        a = gelu_poly2(a);
-        b = gelu_poly2(b);
-        v = make_float4(a.x, a.y, b.x, b.y);
-    } else {
-        v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-    }
-}
-
-// d gelu(z) / dz = Phi(z) + z phi(z).  fp32 outputs: erff / expf; bf16 outputs: the polynomial erf above and exp2.
-template <typename TOUT>
-__device__ __forceinline__ float gelu_grad(float z) {
-    if constexpr (sizeof(TOUT) == 2) {
-        const float t = __builtin_amdgcn_fmed3f(z * 0.70710678118654752440f, -3.0f, 3.0f), t2 = t * t;
-        float p = 4.074096087e-08f;
-        p = fmaf(p, t2, -1.944782217e-06f); p = fmaf(p, t2, 4.105993727e-05f); p = fmaf(p, t2, -5.110323815e-04f);
-        p = fmaf(p, t2, 4.235408041e-03f); p = fmaf(p, t2, -2.510281415e-02f); p = fmaf(p, t2, 1.110792751e-01f);
-        p = fmaf(p, t2, -3.753148415e-01f); p = fmaf(p, t2, 1.128268421e+00f);
-        const float cdf = fmaf(0.5f * t, p, 0.5f);
-        const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);
-        return fmaf(z, pdf, cdf);
-    } else {
-        const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
-        return cdf + z * pdf;
-    }
-}
-
-template <typename TOUT>
-__device__ __forceinline__ float4 load4_out(const TOUT* p) {
-    if constexpr (sizeof(TOUT) == 2) {
-        const uint2 u = *reinterpret_cast<const uint2*>(p);
-        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
-                           __uint_as_float(u.y & 0xFFFF0000u));
-    } else {
-        return *reinterpret_cast<const float4*>(p);
-    }
-}
-
-template <typename TOUT>
-__device__ __forceinline__ float apply_gelu(float v) {
-    if constexpr (sizeof(TOUT) == 2) return gelu_fast(v);
-    else return gelu_erf(v);
-}
-
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-
-// One K-tile of MFMAs for a wave's 64 x 64 block (2 x 2 accumulators of 32 x 32).
-// SWAP = false: acc[i][j] = A_i . W_j^T  (C layout: lane = column n, registers = rows m)
-// SWAP = true : acc[i][j] = W_j . A_i^T  (C layout: lane = row m, registers = 4-runs of columns n) --
-//               the transposed accumulator lets the epilogue read/write 4 consecutive columns per lane.
-template <typename TIN, bool SWAP = false>
-__device__ __forceinline__ void mma_tile(const unsigned char* sa, const unsigned char* sb, int arow0, int brow0, int hi,
-                                         f32x16 (&acc)[2][2]) {
-    if constexpr (sizeof(TIN) == 2) {
-        // bf16: 4 k-steps of 16; lane (row, hi) supplies k = ks*16 + hi*8 .. +7 = chunk ks*2 + hi
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(arow0 + i * 32, ks * 2 + hi));
-                bfr[i] = *reinterpret_cast<const bf16x8*>(sb + lds_off(brow0 + i * 32, ks * 2 + hi));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
-                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-    } else {
-        // f32 parity mode: chunk c holds k = 4c..4c+3; lane hi reads the 8 bytes at hi*8 of it
-        // (k = 4c+2hi, 4c+2hi+1) and feeds them to two 32x32x2 MFMAs.  A and W use the same map,
-        // so each k is contracted exactly once.
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            f32x2 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const f32x2*>(sa + lds_off(arow0 + i * 32, c) + hi * 8);
-                bfr[i] = *reinterpret_cast<const f32x2*>(sb + lds_off(brow0 + i * 32, c) + hi * 8);
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[j][e], af[i][e], acc[i][j], 0, 0, 0)
-                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
-        }
-    }
-}
-
-// Epilogue of a wave's 64 x 64 block.  32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-// Residual reads are issued as one batch of 16 unconditional loads per 32x32 block (indices clamped
-// into range) so they overlap instead of paying one HBM round trip per element; stores are predicated.
-// ACT: 0 none, 1 GELU, -1 decide at run time.  RES: 0 no residual / no row remap, 1 residual[m] (same row),
-// 2 generic (row-modulo residual and/or output row remap), -1 decide at run time.
-template <typename TOUT, int ACT, int RES>
-__device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], TOUT* C, long ldc, int M, int N, int mw, int nw,
-                                               int l31, int hi, const Epilogue& ep) {
-    const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
-    const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
-    const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
-    const bool gelu = ACT < 0 ? ep.act == M324_ACT_GELU : ACT == 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = nw + j * 32 + l31;
-        const bool nok = n < N;
-        const int nc = nok ? n : N - 1;
-        const float bias = ep.bias ? ep.bias[nc] : 0.f;
-        const float gamma = ep.gamma ? ep.gamma[nc] : 1.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mb = mw + i * 32 + 4 * hi;
-            float res[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) res[r] = 0.f;
-            if (has_res) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int mc = min(mb + (r & 3) + 8 * (r >> 2), M - 1);
-                    if (res_mod) mc %= ep.res_rows;
-                    res[r] = ep.residual[(long)mc * ep.ldr + nc];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + bias;
-                if (gelu) v = apply_gelu<TOUT>(v);
-                v = fmaf(v, gamma, res[r]);
-                long orow = m;
-                if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
-                if (nok && m < M) Elem<TOUT>::store(C + orow * ldc + n, v);
-            }
-        }
-    }
-}
-
-
-// SWAPPED accumulators (all LDS-DMA kernels): lane = output row m (32 rows per block), registers = columns
-// n = 8*g + 4*hi + e (g = r >> 2, e = r & 3): every lane owns runs of 4 consecutive columns.  Needs N % 4 == 0.
-template <typename TOUT>
-__device__ __forceinline__ void store4_out(TOUT* p, float a, float b, float c, float d);
-template <>
-__device__ __forceinline__ void store4_out<float>(float* p, float a, float b, float c, float d) {
-    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-}
-template <>
-__device__ __forceinline__ void store4_out<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
-}
-
-// LDS-transposed epilogue.  The swapped accumulator layout gives a lane 4-column runs of ONE row, so a direct store
-// instruction touches 32 different rows with 16-32 bytes each: the texture path handles one cache line per cycle and
-// the epilogue of a K = 768 GEMM cost as much as half its main loop.  Here every wave bounces each 32 x 64 block
-// through a wave-private LDS scratch (32 rows x 68 floats: the 4-float pad makes both the b128 writes -- 8 lanes = 8
-// rows -- and the row-contiguous b128 reads conflict-free) and then works on rows: 16 lanes cover the 64 columns of a
-// row, so bias / gamma are per-lane constants, residual reads and output stores are whole 128/256-byte lines.
-// DS operations of one wave execute in order, so no barrier or wait is needed between the write and read passes.
-constexpr int EP_LD = 68;
-constexpr int EP_WAVE_FLOATS = 32 * EP_LD;     // 8704 bytes per wave
-
-template <typename TOUT, int ACT, int RES, int MI>
-__device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float* scr, TOUT* C, long ldc, int M, int N, int mw,
-                                               int nw, int lane, const Epilogue& ep) {
-    const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
-    const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
-    const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int rr = lane >> 4, cc = (lane & 15) * 4;
-    const int n = nw + cc;
-    const bool nok = n < N;                    // N % 4 == 0: a lane's 4 columns are all in or all out
-    const int ncl = min(n, N - 4);
-    const float4 bi = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + ncl) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 ga = ep.gamma ? *reinterpret_cast<const float4*>(ep.gamma + ncl) : make_float4(1.f, 1.f, 1.f, 1.f);
-    float* wr = scr + l31 * EP_LD + 4 * hi;
-    const float* rd = scr + rr * EP_LD + cc;
-    // interior tiles (all but the last row / column of tiles) take a copy without per-store predicates, so the 8 LDS
-    // reads and the 8 stores of a block are scheduled as batches instead of read-wait-store chains
-    auto body = [&](auto checked) {
-        constexpr bool CHECK = decltype(checked)::value;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int mb = mw + i * 32 + rr;       // row of pass p: mb + 4 p
-            float4 res[8], az[8];
-            if (has_res) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
-                    if (res_mod) mr %= ep.res_rows;
-                    res[p] = *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
-                }
-            }
-            if constexpr (ACT == 3) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
-                    az[p] = load4_out<TOUT>(static_cast<const TOUT*>(ep.aux) + (long)mr * ep.ldaux + ncl);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
-                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            float4 v[8];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const float4*>(rd + p * 4 * EP_LD);
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                float4 x = v[p];
-                x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
-                const int m = mb + 4 * p;
-                if (ACT == 2 && (!CHECK || (m < M && nok)))
-                    store4_out<TOUT>(static_cast<TOUT*>(ep.aux) + (long)m * ep.ldaux + n, x.x, x.y, x.z, x.w);
-                if (ACT == 1 || ACT == 2) apply_gelu4<TOUT>(x);
-                if (ep.gamma) { x.x *= ga.x; x.y *= ga.y; x.z *= ga.z; x.w *= ga.w; }
-                if (has_res) { x.x += res[p].x; x.y += res[p].y; x.z += res[p].z; x.w += res[p].w; }
-                if constexpr (ACT == 3) {
-                    x.x *= gelu_grad<TOUT>(az[p].x); x.y *= gelu_grad<TOUT>(az[p].y);
-                    x.z *= gelu_grad<TOUT>(az[p].z); x.w *= gelu_grad<TOUT>(az[p].w);
-                }
-                if (!CHECK || (m < M && nok)) {
-                    long orow = m;
-                    if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
-                    store4_out<TOUT>(C + orow * ldc + n, x.x, x.y, x.z, x.w);
-                }
-            }
-        }
-    };
-    // bf16 interior tiles without residual / row remap: 8 columns per lane, so a row is 8 lanes x 16 bytes and one
-    // store instruction writes 8 whole 128-byte lines (half as many store instructions as the 4-column form)
-    auto body8 = [&]() {
-        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
-        const int n8 = nw + c8;
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, g0 = make_float4(1.f, 1.f, 1.f, 1.f), g1 = g0;
-        if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
-        if (ep.gamma) { g0 = *reinterpret_cast<const float4*>(ep.gamma + n8); g1 = *reinterpret_cast<const float4*>(ep.gamma + n8 + 4); }
-        const float* rd8 = scr + r8 * EP_LD + c8;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
-                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            float4 v0[4], v1[4], z0[4], z1[4];
-            if constexpr (ACT == 3) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const TOUT* zp = static_cast<const TOUT*>(ep.aux) + (long)(mw + i * 32 + p * 8 + r8) * ep.ldaux + n8;
-                    z0[p] = load4_out<TOUT>(zp);
-                    z1[p] = load4_out<TOUT>(zp + 4);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
-                v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float4 x = v0[p], y = v1[p];
-                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
-                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
-                const long m = mw + i * 32 + p * 8 + r8;
-                if constexpr (ACT == 2)
-                    *reinterpret_cast<uint4*>(static_cast<TOUT*>(ep.aux) + m * ep.ldaux + n8) =
-                        make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-                if (ACT == 1 || ACT == 2) { apply_gelu4<TOUT>(x); apply_gelu4<TOUT>(y); }
-                if (ep.gamma) {
-                    x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
-                    y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
-                }
-                if constexpr (ACT == 3) {
-                    x.x *= gelu_grad<TOUT>(z0[p].x); x.y *= gelu_grad<TOUT>(z0[p].y);
-                    x.z *= gelu_grad<TOUT>(z0[p].z); x.w *= gelu_grad<TOUT>(z0[p].w);
-                    y.x *= gelu_grad<TOUT>(z1[p].x); y.y *= gelu_grad<TOUT>(z1[p].y);
-                    y.z *= gelu_grad<TOUT>(z1[p].z); y.w *= gelu_grad<TOUT>(z1[p].w);
-                }
-                *reinterpret_cast<uint4*>(C + m * ldc + n8) = make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w),
-                                                                         pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-            }
-        }
-    };
-    // fused q|k|v projection (M324_AUX_QKV_HEADS): this wave's 64 columns are one head of q (which = 0), k (1) or v (2).
-    // 8 columns per lane: a row's 64 values sit in the 8 lanes that share lane >> 3, so the per-head RMSNorm is three
-    // xor-shuffles inside the group, and a (token, head) row leaves as 8 x 16 bytes = one 128-byte line.
-    auto body_qkv = [&]() {
-        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
-        const int hc = ep.qkv_H * 64, which = nw / hc, head = (nw % hc) >> 6;
-        const int n8 = nw + c8;
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, w0 = make_float4(1.f, 1.f, 1.f, 1.f), w1 = w0;
-        if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
-        const bool norm = which < 2 && ep.qkv_w[which] != nullptr;
-        if (norm) {
-            w0 = *reinterpret_cast<const float4*>(ep.qkv_w[which] + c8);
-            w1 = *reinterpret_cast<const float4*>(ep.qkv_w[which] + c8 + 4);
-        }
-        const float post = which == 0 ? ep.qkv_qscale : 1.0f;
-        bf16_t* const base = ep.qkv_out[which] + (long)head * ep.qkv_L * 64 + c8;
-        const float* rd8 = scr + r8 * EP_LD + c8;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
-                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            float4 v0[4], v1[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
-                v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
-            }
-            // token of pass p: m = mw + 32 i + r8 + 8 p  ->  (batch, position); one division per block, then steps of 8
-            const int m0r = mw + i * 32 + r8;
-            int bb = m0r / ep.qkv_L, ll = m0r - bb * ep.qkv_L;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float4 x = v0[p], y = v1[p];
-                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
-                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
-                float rs = post;
-                if (norm) {
-                    float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w + y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
-                    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-                    rs *= rsqrtf(ss * (1.0f / 64.0f) + ep.qkv_eps);
-                }
-                x.x *= rs * w0.x; x.y *= rs * w0.y; x.z *= rs * w0.z; x.w *= rs * w0.w;
-                y.x *= rs * w1.x; y.y *= rs * w1.y; y.z *= rs * w1.z; y.w *= rs * w1.w;
-                if (m0r + 8 * p < M && n8 < N)
-                    *reinterpret_cast<uint4*>(base + (((long)bb * ep.qkv_H) * ep.qkv_L + ll) * 64) =
-                        make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-                ll += 8;
-                while (ll >= ep.qkv_L) { ll -= ep.qkv_L; ++bb; }
-            }
-        }
-    };
-    const bool interior = mw + MI * 32 <= M && nw + 64 <= N;
-    if constexpr (ACT == 4) {
-        body_qkv();
-        return;
-    }
-    if constexpr (sizeof(TOUT) == 2 && RES == 0 && ACT != 4) {
-        if (interior && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-            (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0) &&
-            (ACT < 2 || ((ep.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0))) {
-            body8();
-            return;
-        }
-    }
-    if (interior) body(std::false_type{});
-    else body(std::true_type{});
-}
 
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
@@ -534,8 +106,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TIN* __restrict__ A,
 // Double-buffered; the barrier at the top of iteration kt both publishes tile kt (hipcc drains the
 // LDS-DMA queue, vmcnt(0), before s_barrier) and retires every wave's reads of the buffer that tile
 // kt+1 is about to overwrite.
-typedef __attribute__((address_space(3))) void lds_ptr_t;
-typedef __attribute__((address_space(1))) const void glb_ptr_t;
 
 template <typename TIN, typename TOUT, int ACT, int RES>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict__ A, long lda, const TIN* __restrict__ W,
@@ -612,7 +182,6 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
 // and the workgroup moves 64 KiB by LDS-DMA per 8.4 MFLOP -- half the LDS traffic per FLOP of the
 // 128-wide tiles and twice the work per barrier.  Two LDS stages of 64 KiB (one workgroup per CU).
 // Used where 256-wide column tiles quantise well (N % 256 == 0) and the grid still fills the chip.
-constexpr int BM5 = 256, BN5 = 256;
 constexpr int STAGE5 = (BM5 + BN5) * ROWB;   // 64 KiB
 
 template <typename TIN, typename TOUT, int ACT, int RES>
@@ -717,11 +286,6 @@ constexpr int PART6 = 256 * ROWB6;               // 16 KiB: one operand's half-t
 constexpr int SLOT6 = 2 * PART6;                 // 32 KiB
 __device__ __forceinline__ int lds_off6(int row, int chunk) { return row * ROWB6 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-#define M324_BARRIER()                             \
-    do {                                           \
-        asm volatile("s_barrier" ::: "memory");    \
-        __builtin_amdgcn_sched_barrier(0);         \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // v7: software-pipelined 256 x 256 kernel (bf16), 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block = 4 x 2
@@ -842,6 +406,193 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const bf16_t* __restr
     M324_BARRIER();
     store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
                                       n0 + wn * 64, lane, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v10: the v7 pipeline on whole cache lines.  tools/dma_lab: an LDS-DMA piece that covers 16 rows x 64 B (v7's half-tile
+// rows) costs the texture path 41 cycles per KiB, one that covers 8 rows x 128 B 29-33 -- with 64-byte rows the loads
+// alone cap a 256 x 256-tile GEMM at ~1700 TF/s, next to an MFMA-only ceiling of 1825.  Here an LDS row holds K = 64
+// (128 B, v2/v5's swizzle) and the 160 KiB of LDS are a ring of FIVE 32-KiB chunks, a chunk being one operand's
+// 256 rows x 64 k of one K-stage: chunk 2s = A of stage s, 2s+1 = W of stage s, chunk q at ring position q % 5, so
+// stages s, s+1 and the A half of s+2 are resident while stage s is multiplied (2.5 stages of look-ahead).
+// The MFMA work is rotated by one k-step against the LDS stages: an iteration runs the MFMAs of (s-1, k-step 3) --
+// fragments already in registers -- then (s, 0..2), so barrier X_s sits where stage s is no longer read from LDS and
+// the fragments of (s+1, 0) are fetched under MFMAs that do not need them:
+//   X_{s-1}: stage s landed, stage s-1 free
+//   phase 0: MFMA (s-1,3) | fragments (s,0) | 2 pieces of W_{s+1}      phase 2: MFMA (s,1) | fragments (s,2) | 2 pieces of A_{s+2}
+//   phase 1: MFMA (s,0)   | fragments (s,1) | 2 pieces of W_{s+1}      phase 3: MFMA (s,2) | fragments (s,3) | 2 pieces of A_{s+2}
+//   lgkmcnt(0) (stage s is in registers), vmcnt(4) (W_{s+1} landed; the 4 pieces of A_{s+2} may fly), X_s.
+// Past the end of K the last stage is fetched again into free chunks (never read), so the loop is branch-free.
+#ifdef M324_V10_PROF
+__device__ long long g_v10_prof[8];               // lab builds only: loop / vmcnt-wait / barrier ticks, samples, loop time (10 ns), prologue, epilogue ticks
+#define M324_PROF_T() (prof ? clock64() : 0)
+#else
+#define M324_PROF_T() 0
+#endif
+
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
+                                                           int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * CHUNK10];
+#ifdef M324_V10_PROF
+    const long long t_entry = clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lid = blockIdx.x;
+    if (xcd_remap & 1) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * BM5, n0 = (lid % ntn) * BN5;
+
+    // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
+    }
+    auto issue2 = [&](const bf16_t* const (&g)[4], int i0, int st, int pos) {
+        unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i0 + i] + (long)st * 64), (lds_ptr_t*)(d + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int NS = K / 64;
+    // fragment of k-step ks: chunk 2 ks + hi of the lane's row; the swizzle only touches chunk bits, so k-step ks is the
+    // k-step-0 offset ^ (ks << 5)
+    const int aoff = lds_off(wm * 128 + l31, hi), boff = lds_off(wn * 64 + l31, hi);
+    bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[1][i] = (bf16x8)(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[1][j] = (bf16x8)(0);
+    auto load_frags = [&](int set, int pa, int pw, int ks) {
+        const unsigned char* ba = smem + pa * CHUNK10;
+        const unsigned char* bw = smem + pw * CHUNK10;
+        const int x = ks << 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(bw + ((boff + j * 4096) ^ x));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(ba + ((aoff + i * 4096) ^ x));
+    };
+    auto mma8 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+    };
+#define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#ifndef M324_V10_SCHED
+#define M324_V10_SCHED 0
+#endif
+    auto sched_kstep = [&]() {
+#if M324_V10_SCHED == 0
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
+#elif M324_V10_SCHED == 1
+        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x100, 2);
+        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 1);
+        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 3);
+#elif M324_V10_SCHED == 2
+        M324_SG(0x100, 6); M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 4);
+#elif M324_V10_SCHED == 3
+        M324_SG(0x008, 1); M324_SG(0x100, 3); M324_SG(0x008, 1); M324_SG(0x100, 3);
+        M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 2);
+#endif
+    };
+
+    // prologue: A_0, W_0, A_1 (chunks 0, 1, 2)
+    issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
+    issue2(gb, 0, 0, 1); issue2(gb, 2, 0, 1);
+    {
+        const int s1 = NS > 1 ? 1 : 0;
+        issue2(ga, 0, s1, 2); issue2(ga, 2, s1, 2);
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // stage 0 landed (A_1 may fly)
+    M324_BARRIER();
+    int pa = 0, pw = 1;                                     // ring positions of A_s, W_s
+    [[maybe_unused]] long long t_vm = 0, t_bar = 0;
+#ifdef M324_V10_PROF
+    const bool prof = true;
+#else
+    constexpr bool prof = false;
+#endif
+    [[maybe_unused]] const long long t_loop0 = M324_PROF_T();
+#ifdef M324_V10_PROF
+    const long long r_loop0 = wall_clock64();
+#endif
+    for (int s = 0; s < NS; ++s) {
+        int pwn = pa + 3, pan = pa + 4;                     // positions of W_{s+1} (chunk 2s+3) and A_{s+2} (chunk 2s+4)
+        pwn = pwn >= 5 ? pwn - 5 : pwn;
+        pan = pan >= 5 ? pan - 5 : pan;
+        const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
+        load_frags(0, pa, pw, 0);
+        issue2(gb, 0, sw, pwn);
+        mma8(1);                                            // (s-1, k-step 3); zeros in the first iteration
+        sched_kstep();
+        load_frags(1, pa, pw, 1);
+        issue2(gb, 2, sw, pwn);
+        mma8(0);
+        sched_kstep();
+        load_frags(0, pa, pw, 2);
+        issue2(ga, 0, sa, pan);
+        mma8(1);
+        sched_kstep();
+        load_frags(1, pa, pw, 3);
+        issue2(ga, 2, sa, pan);
+        mma8(0);
+        sched_kstep();
+        const long long tw0 = M324_PROF_T();
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        const long long tw1 = M324_PROF_T();
+        M324_BARRIER();
+        const long long tw2 = M324_PROF_T();
+        t_vm += tw1 - tw0;
+        t_bar += tw2 - tw1;
+        pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
+        pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
+    }
+#ifdef M324_V10_PROF
+    const long long t_loop1 = clock64();
+    if (lane == 0 && (wave == 0 || wave == 5)) {
+        atomicAdd((unsigned long long*)&g_v10_prof[4], (unsigned long long)(wall_clock64() - r_loop0));
+        atomicAdd((unsigned long long*)&g_v10_prof[5], (unsigned long long)(t_loop0 - t_entry));
+        atomicAdd((unsigned long long*)&g_v10_prof[0], (unsigned long long)(t_loop1 - t_loop0));
+        atomicAdd((unsigned long long*)&g_v10_prof[1], (unsigned long long)t_vm);
+        atomicAdd((unsigned long long*)&g_v10_prof[2], (unsigned long long)t_bar);
+        atomicAdd((unsigned long long*)&g_v10_prof[3], 1ull);
+    }
+#endif
+    mma8(1);                                                // (NS-1, k-step 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
+#undef M324_SG
+    M324_BARRIER();
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep);
+#ifdef M324_V10_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && (wave == 0 || wave == 5)) atomicAdd((unsigned long long*)&g_v10_prof[6], (unsigned long long)(clock64() - t_loop1));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1185,7 +936,7 @@ static int xcd_remap() {
     return v;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9 forces a variant (A/B measurements, tests).
+// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11 forces a variant (A/B measurements, tests).
 static int forced_variant() {      // read per call: lets one process A/B-toggle the variant
     const char* e = getenv("M324_GEMM");
     return (e && e[0] == 'v') ? atoi(e + 1) : 0;
@@ -1195,20 +946,39 @@ static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
     const int f = forced_variant();
     const bool bf16 = a->in_dtype == M324_BF16;
+    const bool ring_ok = bf16 && a->K % 64 == 0 && a->K >= 128;      // v10 / v11: K-stages of 64, at least two
     if (f == 1 || f == 2 || f == 5) return f;
     if (f == 7) return bf16 ? 7 : 5;
+    if (f == 10 || f == 11) return ring_ok ? f : (bf16 ? 7 : 5);
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
-    // CU) balance better.  Measured on the c2 shapes (tools/gemm_lab): v7 wins at >= 0.70 fill, v2 below.
+    // CU) balance better.  Measured on the c2 shapes (tools/gemm_lab): the chunk-ring kernels win at >= 0.75 fill, v2
+    // below; of the two, the 4-wave persistent v11 wins when the output is fp32 (residual epilogues: little VALU work,
+    // 1.5x the LDS fragment traffic saved), the 8-wave v10 when it is bf16 (GELU / q|k|v epilogues want two waves per
+    // SIMD).  K that is not a multiple of 64 falls back to the half-tile ring of v7.
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
-    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.70) return (bf16 && a->K >= 96) ? 7 : 5;
+    if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) {
+        if (!bf16) return 5;
+        if (ring_ok) return a->out_dtype == M324_F32 ? 11 : 10;
+        return a->K >= 96 ? 7 : 5;
+    }
     return 2;
 }
 
 template <typename TOUT, int ACT, int RES>
-static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep) {
+static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
+    if (variant == 11) {
+        m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap());
+        return;
+    }
+    if (variant == 10) {
+        hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+                           (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
+                           ceil_div(a->N, BN5), xcd_remap());
+        return;
+    }
     hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
                        (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
                        ceil_div(a->N, BN5), xcd_remap());
@@ -1219,7 +989,8 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
     Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off,
                 a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode,
                 {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
-                a->qkv_L, a->qkv_H};
+                a->qkv_L, a->qkv_H,
+                (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > (128l << 20)) ? 1 : 0};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
@@ -1238,8 +1009,8 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                         : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
 #define M324_GLDS(ACT, RES)                                                                                              \
     do {                                                                                                                 \
-        if (variant == 7)                                                                                                \
-            launch_pipe<TOUT, ACT, RES>(a, s, ep);                                                                       \
+        if (variant == 7 || variant >= 10)                                                                               \
+            launch_pipe<TOUT, ACT, RES>(a, s, ep, variant);                                                              \
         else if (variant == 5)                                                                                           \
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
                                dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
@@ -1268,6 +1039,17 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef M324_V10_PROF
+extern "C" int m324_debug_v10_prof(long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_v10_prof), 64) != hipSuccess) return -1;
+    if (reset) {
+        long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_v10_prof), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, float* C, long ldc, int M, int N, int Kc,
                             int slices, long strideC, void* stream) {

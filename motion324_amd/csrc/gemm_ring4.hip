@@ -1,0 +1,195 @@
+// m324_gemm, schedule v11: the 4-wave 256 x 256 chunk-ring kernel.  Own translation unit because it must be compiled
+// WITHOUT -amdgpu-mfma-vgpr-form: a wave owns a 128 x 128 block = 256 accumulator registers, which fill the AGPR half
+// of the unified file while fragments, addresses and the epilogue use the VGPR half (400 registers, no spills); with
+// the flag hipcc keeps the accumulators in VGPRs and shuffles everything else through v_accvgpr_mov.
+#include "gemm_tile.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// v11: v10's chunk ring (see gemm.hip) with FOUR waves (one per SIMD), each a 128 x 128 block = 4 x 4 accumulators
+// (256 registers of the unified 512-entry file), as a PERSISTENT kernel: one workgroup per CU walks over tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...
+//  * Per K-stage the workgroup reads 128 KiB of fragments out of LDS instead of 192 KiB and the texture path sees 4
+//    instruction streams instead of 8 (tools/dma_lab: 29 instead of 33 cycles per KiB).  On this chip that matters
+//    through POWER: tools/clk_lab shows the MFMA stream alone pulls the shader clock down to ~1.78 GHz and the
+//    instrumented main loops run at 1.5-1.6 GHz -- every LDS / texture byte saved is clock regained.
+//  * At K = 768 a tile is 12 K-stages (~19 us) between a ~3.3 us prologue (cold first loads) and a ~3.5 us epilogue.
+//    The tile loop issues the first three chunks (A_0, W_0, A_1) of the NEXT tile right after the last fragment read
+//    of this one, so they land under the epilogue (whose LDS scratch lives in chunks 3-4).  Loads and stores of one
+//    wave share vmcnt and may retire out of order with respect to each other, so the top of the next tile waits for
+//    vmcnt(0): everything this wave has in flight.
+// Same stage / phase structure as v10; a phase is 16 MFMAs, 8 fragment reads and 4 LDS-DMA pieces.
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                         long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
+                                                         int ntiles, int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * CHUNK10];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int NS = K / 64;
+
+    // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 8w .. 8w+7 of A and of W
+    const bf16_t* ga[8];
+    const bf16_t* gb[8];
+    int m0 = 0, n0 = 0;
+    auto tile_setup = [&](int t) {
+        int lid = t;
+        if (xcd_remap & 1) {
+            const int q = ntiles >> 3, r = ntiles & 7, x = lid & 7, loc = lid >> 3;
+            lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+        }
+        m0 = (lid / ntn) * BM5;
+        n0 = (lid % ntn) * BN5;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (wave * 8 + i) * 8 + (lane >> 3);
+            const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+            ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
+            gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
+        }
+    };
+    auto issue4 = [&](const bf16_t* const (&g)[8], int i0, int st, int pos) {
+        unsigned char* d = smem + pos * CHUNK10 + wave * 8192 + i0 * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i0 + i] + (long)st * 64), (lds_ptr_t*)(d + i * 1024), 16, 0, 0);
+    };
+    auto issue_prologue = [&]() {                           // A_0, W_0, A_1 -> chunks 0, 1, 2
+        issue4(ga, 0, 0, 0); issue4(ga, 4, 0, 0);
+        issue4(gb, 0, 0, 1); issue4(gb, 4, 0, 1);
+        const int s1 = NS > 1 ? 1 : 0;
+        issue4(ga, 0, s1, 2); issue4(ga, 4, s1, 2);
+    };
+
+    const int aoff = lds_off(wm * 128 + l31, hi), boff = lds_off(wn * 128 + l31, hi);
+    bf16x8 fa[2][4], fb[2][4];
+    f32x16 acc[2][4][2];                                    // [column half][i][j]: the epilogue works on 128 x 64 halves
+    auto load_frags = [&](int set, int pa, int pw, int ks) {
+        const unsigned char* ba = smem + pa * CHUNK10;
+        const unsigned char* bw = smem + pw * CHUNK10;
+        const int x = ks << 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(bw + ((boff + j * 4096) ^ x));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(ba + ((aoff + i * 4096) ^ x));
+    };
+    auto mma16 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j >> 1][i][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[j >> 1][i][j & 1], 0, 0, 0);
+    };
+#define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    auto sched_phase = [&]() {
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
+        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
+        M324_SG(0x008, 4);
+    };
+
+    tile_setup(blockIdx.x);
+    issue_prologue();
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int mt = m0, nt = n0;                          // this tile's origin (m0 / n0 move on before the epilogue)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[1][i] = (bf16x8)(0); fb[1][i] = (bf16x8)(0); }
+        // Everything this wave has in flight must be done: the three prologue chunks and, after the first tile, the
+        // epilogue's stores (loads and stores share vmcnt and may retire out of order with respect to each other).
+        // The builtin, not inline asm: hipcc's own wait-count pass must see the drain, or it protects the epilogue's
+        // bias loads against the first fragment read of every K-stage with a vmcnt(0) of its own.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+        M324_BARRIER();
+        int pa = 0, pw = 1;
+        for (int s = 0; s < NS; ++s) {
+            int pwn = pa + 3, pan = pa + 4;
+            pwn = pwn >= 5 ? pwn - 5 : pwn;
+            pan = pan >= 5 ? pan - 5 : pan;
+            const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
+            load_frags(0, pa, pw, 0);
+            issue4(gb, 0, sw, pwn);
+            mma16(1);                                       // (s-1, k-step 3); zeros in the first iteration
+            sched_phase();
+            load_frags(1, pa, pw, 1);
+            issue4(gb, 4, sw, pwn);
+            mma16(0);
+            sched_phase();
+            load_frags(0, pa, pw, 2);
+            issue4(ga, 0, sa, pan);
+            mma16(1);
+            sched_phase();
+            load_frags(1, pa, pw, 3);
+            issue4(ga, 4, sa, pan);
+            mma16(0);
+            sched_phase();
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            M324_BARRIER();
+            pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
+            pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the re-fetched chunks too: the ring is about to be reused
+        M324_BARRIER();
+        if (t + (int)gridDim.x < ntiles) {                   // next tile's first chunks land under this tile's epilogue
+            tile_setup(t + gridDim.x);
+            issue_prologue();
+        }
+        mma16(1);                                           // (NS-1, k-step 3)
+        float* scr = reinterpret_cast<float*>(smem + 3 * CHUNK10) + wave * EP_WAVE_FLOATS;
+        store_tile_lds<TOUT, ACT, RES, 4>(acc[0], scr, C, ldc, M, N, mt + wm * 128, nt + wn * 128, lane, ep);
+        store_tile_lds<TOUT, ACT, RES, 4>(acc[1], scr, C, ldc, M, N, mt + wm * 128, nt + wn * 128 + 64, lane, ep);
+    }
+#undef M324_SG
+}
+
+}  // namespace
+
+namespace m324 {
+
+void launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap) {
+    const int ntn = ceil_div(a->N, BN5), ntiles = ntn * ceil_div(a->M, BM5);
+    static const int n_cu = [] {                            // one persistent workgroup per CU (160 KiB of LDS each)
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    const dim3 grid(ntiles < n_cu ? ntiles : n_cu);
+#define M324_R4(TOUT, ACT, RES)                                                                                              \
+    hipLaunchKernelGGL((gemm_ring4_kernel<TOUT, ACT, RES>), grid, dim3(256), 0, s, (const bf16_t*)a->A, a->lda,              \
+                       (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep, ntn, ntiles, xcd_remap)
+#define M324_R4_OUT(ACT, RES)                                      \
+    do {                                                           \
+        if (a->out_dtype == M324_BF16) M324_R4(bf16_t, ACT, RES);  \
+        else M324_R4(float, ACT, RES);                             \
+    } while (0)
+    const int key = act_code * 4 + res_code;
+    switch (key) {
+        case 0 * 4 + 0: M324_R4_OUT(0, 0); break;
+        case 0 * 4 + 1: M324_R4_OUT(0, 1); break;
+        case 0 * 4 + 2: M324_R4_OUT(0, 2); break;
+        case 1 * 4 + 0: M324_R4_OUT(1, 0); break;
+        case 1 * 4 + 2: M324_R4_OUT(1, 2); break;
+        case 2 * 4 + 0: M324_R4_OUT(2, 0); break;
+        case 3 * 4 + 0: M324_R4_OUT(3, 0); break;
+        case 4 * 4 + 0: M324_R4(bf16_t, 4, 0); break;
+        default: abort();          // m324_gemm only builds the combinations above
+    }
+#undef M324_R4_OUT
+#undef M324_R4
+}
+
+}  // namespace m324

@@ -1,0 +1,470 @@
+// Shared by the GEMM translation units (gemm.hip, gemm_ring4.hip): epilogue descriptor, GELU forms, LDS swizzles, the
+// MFMA k-tile of the 128 x 128 kernels and the LDS-transposed epilogue every LDS-DMA kernel ends with.
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace m324 {
+struct Epilogue {
+    const float* bias;
+    const float* gamma;
+    const float* residual;
+    long ldr;
+    int res_rows;
+    int act;
+    int row_gin, row_gout, row_off;
+    long strideA, strideW, strideC;
+    void* aux;
+    long ldaux;
+    int aux_mode;
+    bf16_t* qkv_out[3];          // M324_AUX_QKV_HEADS: head-major q, k, v
+    const float* qkv_w[2];       // RMSNorm weights of q, k (or null)
+    float qkv_eps, qkv_qscale;
+    int qkv_L, qkv_H;
+    int stream;                  // bf16 outputs without residual: store non-temporal (host: output larger than the MALL keeps)
+};
+
+// gemm_ring4.hip (own translation unit: built WITHOUT -amdgpu-mfma-vgpr-form, its 256 accumulators live in AGPRs).
+// act_code: the ACT template value (0 none, 1 GELU, 2 GELU + pre-activation, 3 x gelu', 4 q|k|v heads); res_code: RES.
+void launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap);
+}  // namespace m324
+
+namespace {
+
+
+constexpr int BM = 128, BN = 128, ROWB = 128;           // ROWB: bytes of K per LDS row
+constexpr int TILE_BYTES = BM * ROWB;                   // 16 KiB per operand per stage
+
+using m324::Epilogue;
+
+// GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
+// bf16 rounding of the result); the fp32 parity path keeps erff.  ~12 VALU + 2 transcendental ops
+// instead of ocml's branchy erff -- the fc1 epilogue (128x128 GELUs per workgroup) is otherwise as
+// long as its whole K = 768 main loop.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 1 - erf(z), z >= 0
+    const float phi = x >= 0.f ? 1.0f - 0.5f * erfc_z : 0.5f * erfc_z;                       // Phi(x)
+    return x * phi;
+}
+
+// Two GELUs per instruction stream for the bf16 epilogue: erf(z) = z P(z^2) on |z| <= 3 (odd minimax polynomial, 9
+// coefficients, |erf error| <= 1.7e-5; beyond the clamp erf(3) = 0.99998 stands in for 1), evaluated with packed fp32
+// FMAs (v_pk_fma_f32) and no transcendental.  |GELU error| <= 7e-5 absolute -- below the bf16 rounding step of every
+// output larger than 0.02 -- at about a third of the issue slots of the rcp/exp form above.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v gelu_poly2(f32x2v x) {
+    f32x2v z = x * 0.70710678118654752440f;
+    z.x = __builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f);
+    z.y = __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f);
+    const f32x2v t = z * z;
+    f32x2v p = (f32x2v)(4.074096087e-08f);
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-1.944782217e-06f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.105993727e-05f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-5.110323815e-04f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.235408041e-03f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-2.510281415e-02f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.110792751e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(-3.753148415e-01f));
+    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.128268421e+00f));
+    const f32x2v hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, z * p, hx);
+}
+
+template <typename TOUT>
+__device__ __forceinline__ void apply_gelu4(float4& v) {
+    if constexpr (sizeof(TOUT) == 2) {
+        f32x2v a = {v.x, v.y}, b = {v.z, v.w};
+        a = gelu_poly2(a);
+        b = gelu_poly2(b);
+        v = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+        v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+    }
+}
+
+// d gelu(z) / dz = Phi(z) + z phi(z).  fp32 outputs: erff / expf; bf16 outputs: the polynomial erf above and exp2.
+template <typename TOUT>
+__device__ __forceinline__ float gelu_grad(float z) {
+    if constexpr (sizeof(TOUT) == 2) {
+        const float t = __builtin_amdgcn_fmed3f(z * 0.70710678118654752440f, -3.0f, 3.0f), t2 = t * t;
+        float p = 4.074096087e-08f;
+        p = fmaf(p, t2, -1.944782217e-06f); p = fmaf(p, t2, 4.105993727e-05f); p = fmaf(p, t2, -5.110323815e-04f);
+        p = fmaf(p, t2, 4.235408041e-03f); p = fmaf(p, t2, -2.510281415e-02f); p = fmaf(p, t2, 1.110792751e-01f);
+        p = fmaf(p, t2, -3.753148415e-01f); p = fmaf(p, t2, 1.128268421e+00f);
+        const float cdf = fmaf(0.5f * t, p, 0.5f);
+        const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);
+        return fmaf(z, pdf, cdf);
+    } else {
+        const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+        return cdf + z * pdf;
+    }
+}
+
+template <typename TOUT>
+__device__ __forceinline__ float4 load4_out(const TOUT* p) {
+    if constexpr (sizeof(TOUT) == 2) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xFFFF0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
+}
+
+template <typename TOUT>
+__device__ __forceinline__ float apply_gelu(float v) {
+    if constexpr (sizeof(TOUT) == 2) return gelu_fast(v);
+    else return gelu_erf(v);
+}
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+
+// One K-tile of MFMAs for a wave's 64 x 64 block (2 x 2 accumulators of 32 x 32).
+// SWAP = false: acc[i][j] = A_i . W_j^T  (C layout: lane = column n, registers = rows m)
+// SWAP = true : acc[i][j] = W_j . A_i^T  (C layout: lane = row m, registers = 4-runs of columns n) --
+//               the transposed accumulator lets the epilogue read/write 4 consecutive columns per lane.
+template <typename TIN, bool SWAP = false>
+__device__ __forceinline__ void mma_tile(const unsigned char* sa, const unsigned char* sb, int arow0, int brow0, int hi,
+                                         f32x16 (&acc)[2][2]) {
+    if constexpr (sizeof(TIN) == 2) {
+        // bf16: 4 k-steps of 16; lane (row, hi) supplies k = ks*16 + hi*8 .. +7 = chunk ks*2 + hi
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(arow0 + i * 32, ks * 2 + hi));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(sb + lds_off(brow0 + i * 32, ks * 2 + hi));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+        // f32 parity mode: chunk c holds k = 4c..4c+3; lane hi reads the 8 bytes at hi*8 of it
+        // (k = 4c+2hi, 4c+2hi+1) and feeds them to two 32x32x2 MFMAs.  A and W use the same map,
+        // so each k is contracted exactly once.
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x2 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const f32x2*>(sa + lds_off(arow0 + i * 32, c) + hi * 8);
+                bfr[i] = *reinterpret_cast<const f32x2*>(sb + lds_off(brow0 + i * 32, c) + hi * 8);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[j][e], af[i][e], acc[i][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// Epilogue of a wave's 64 x 64 block.  32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+// Residual reads are issued as one batch of 16 unconditional loads per 32x32 block (indices clamped
+// into range) so they overlap instead of paying one HBM round trip per element; stores are predicated.
+// ACT: 0 none, 1 GELU, -1 decide at run time.  RES: 0 no residual / no row remap, 1 residual[m] (same row),
+// 2 generic (row-modulo residual and/or output row remap), -1 decide at run time.
+template <typename TOUT, int ACT, int RES>
+__device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], TOUT* C, long ldc, int M, int N, int mw, int nw,
+                                               int l31, int hi, const Epilogue& ep) {
+    const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
+    const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
+    const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
+    const bool gelu = ACT < 0 ? ep.act == M324_ACT_GELU : ACT == 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nw + j * 32 + l31;
+        const bool nok = n < N;
+        const int nc = nok ? n : N - 1;
+        const float bias = ep.bias ? ep.bias[nc] : 0.f;
+        const float gamma = ep.gamma ? ep.gamma[nc] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = mw + i * 32 + 4 * hi;
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int mc = min(mb + (r & 3) + 8 * (r >> 2), M - 1);
+                    if (res_mod) mc %= ep.res_rows;
+                    res[r] = ep.residual[(long)mc * ep.ldr + nc];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bias;
+                if (gelu) v = apply_gelu<TOUT>(v);
+                v = fmaf(v, gamma, res[r]);
+                long orow = m;
+                if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
+                if (nok && m < M) Elem<TOUT>::store(C + orow * ldc + n, v);
+            }
+        }
+    }
+}
+
+
+// SWAPPED accumulators (all LDS-DMA kernels): lane = output row m (32 rows per block), registers = columns
+// n = 8*g + 4*hi + e (g = r >> 2, e = r & 3): every lane owns runs of 4 consecutive columns.  Needs N % 4 == 0.
+template <typename TOUT>
+__device__ __forceinline__ void store4_out(TOUT* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4_out<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4_out<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+
+// Large bf16 outputs without residual (the decoder's MLP hidden: 403 MB) are stored NON-TEMPORAL: such an output is a
+// stream nobody finds in a cache again, and letting it allocate in the 4 MiB L2 of its XCD evicts the W panels every
+// workgroup of the XCD re-reads (tools/gemm_lab, 65536 x 3072 x 768: 330 -> 291 us).  Outputs the 256 MiB MALL can
+// keep for the consumer (the trunk's 64 MB hidden: the fc2 GEMM that reads it lost what fc1 gained), the fp32 residual
+// stream (read-modify-write of the same lines) and the head-major q|k|v keep plain stores; Epilogue::stream is the
+// host's decision (m324_gemm: more than 128 MiB of output).
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(void* p, bool stream, unsigned a, unsigned b, unsigned c, unsigned d) {
+    if (stream) __builtin_nontemporal_store((u32x4v){a, b, c, d}, reinterpret_cast<u32x4v*>(p));
+    else *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
+}
+
+// LDS-transposed epilogue.  The swapped accumulator layout gives a lane 4-column runs of ONE row, so a direct store
+// instruction touches 32 different rows with 16-32 bytes each: the texture path handles one cache line per cycle and
+// the epilogue of a K = 768 GEMM cost as much as half its main loop.  Here every wave bounces each 32 x 64 block
+// through a wave-private LDS scratch (32 rows x 68 floats: the 4-float pad makes both the b128 writes -- 8 lanes = 8
+// rows -- and the row-contiguous b128 reads conflict-free) and then works on rows: 16 lanes cover the 64 columns of a
+// row, so bias / gamma are per-lane constants, residual reads and output stores are whole 128/256-byte lines.
+// DS operations of one wave execute in order, so no barrier or wait is needed between the write and read passes.
+constexpr int EP_LD = 68;
+constexpr int EP_WAVE_FLOATS = 32 * EP_LD;     // 8704 bytes per wave
+
+template <typename TOUT, int ACT, int RES, int MI>
+__device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float* scr, TOUT* C, long ldc, int M, int N, int mw,
+                                               int nw, int lane, const Epilogue& ep) {
+    const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
+    const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
+    const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int rr = lane >> 4, cc = (lane & 15) * 4;
+    const int n = nw + cc;
+    const bool nok = n < N;                    // N % 4 == 0: a lane's 4 columns are all in or all out
+    const int ncl = min(n, N - 4);
+    const float4 bi = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + ncl) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ga = ep.gamma ? *reinterpret_cast<const float4*>(ep.gamma + ncl) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float* wr = scr + l31 * EP_LD + 4 * hi;
+    const float* rd = scr + rr * EP_LD + cc;
+    // interior tiles (all but the last row / column of tiles) take a copy without per-store predicates, so the 8 LDS
+    // reads and the 8 stores of a block are scheduled as batches instead of read-wait-store chains
+    auto body = [&](auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mb = mw + i * 32 + rr;       // row of pass p: mb + 4 p
+            float4 res[8], az[8];
+            if (has_res) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
+                    if (res_mod) mr %= ep.res_rows;
+                    res[p] = *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
+                }
+            }
+            if constexpr (ACT == 3) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
+                    az[p] = load4_out<TOUT>(static_cast<const TOUT*>(ep.aux) + (long)mr * ep.ldaux + ncl);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            float4 v[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const float4*>(rd + p * 4 * EP_LD);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float4 x = v[p];
+                x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
+                const int m = mb + 4 * p;
+                if (ACT == 2 && (!CHECK || (m < M && nok)))
+                    store4_out<TOUT>(static_cast<TOUT*>(ep.aux) + (long)m * ep.ldaux + n, x.x, x.y, x.z, x.w);
+                if (ACT == 1 || ACT == 2) apply_gelu4<TOUT>(x);
+                if (ep.gamma) { x.x *= ga.x; x.y *= ga.y; x.z *= ga.z; x.w *= ga.w; }
+                if (has_res) { x.x += res[p].x; x.y += res[p].y; x.z += res[p].z; x.w += res[p].w; }
+                if constexpr (ACT == 3) {
+                    x.x *= gelu_grad<TOUT>(az[p].x); x.y *= gelu_grad<TOUT>(az[p].y);
+                    x.z *= gelu_grad<TOUT>(az[p].z); x.w *= gelu_grad<TOUT>(az[p].w);
+                }
+                if (!CHECK || (m < M && nok)) {
+                    long orow = m;
+                    if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
+                    store4_out<TOUT>(C + orow * ldc + n, x.x, x.y, x.z, x.w);
+                }
+            }
+        }
+    };
+    // bf16 interior tiles without residual / row remap: 8 columns per lane, so a row is 8 lanes x 16 bytes and one
+    // store instruction writes 8 whole 128-byte lines (half as many store instructions as the 4-column form)
+    auto body8 = [&]() {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const int n8 = nw + c8;
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, g0 = make_float4(1.f, 1.f, 1.f, 1.f), g1 = g0;
+        if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
+        if (ep.gamma) { g0 = *reinterpret_cast<const float4*>(ep.gamma + n8); g1 = *reinterpret_cast<const float4*>(ep.gamma + n8 + 4); }
+        const float* rd8 = scr + r8 * EP_LD + c8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            float4 v0[4], v1[4], z0[4], z1[4];
+            if constexpr (ACT == 3) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const TOUT* zp = static_cast<const TOUT*>(ep.aux) + (long)(mw + i * 32 + p * 8 + r8) * ep.ldaux + n8;
+                    z0[p] = load4_out<TOUT>(zp);
+                    z1[p] = load4_out<TOUT>(zp + 4);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
+                v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 x = v0[p], y = v1[p];
+                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                const long m = mw + i * 32 + p * 8 + r8;
+                if constexpr (ACT == 2)
+                    *reinterpret_cast<uint4*>(static_cast<TOUT*>(ep.aux) + m * ep.ldaux + n8) =
+                        make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+                if (ACT == 1 || ACT == 2) { apply_gelu4<TOUT>(x); apply_gelu4<TOUT>(y); }
+                if (ep.gamma) {
+                    x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
+                    y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
+                }
+                if constexpr (ACT == 3) {
+                    x.x *= gelu_grad<TOUT>(z0[p].x); x.y *= gelu_grad<TOUT>(z0[p].y);
+                    x.z *= gelu_grad<TOUT>(z0[p].z); x.w *= gelu_grad<TOUT>(z0[p].w);
+                    y.x *= gelu_grad<TOUT>(z1[p].x); y.y *= gelu_grad<TOUT>(z1[p].y);
+                    y.z *= gelu_grad<TOUT>(z1[p].z); y.w *= gelu_grad<TOUT>(z1[p].w);
+                }
+                store16(C + m * ldc + n8, ep.stream != 0, pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+            }
+        }
+    };
+    // fused q|k|v projection (M324_AUX_QKV_HEADS): this wave's 64 columns are one head of q (which = 0), k (1) or v (2).
+    // 8 columns per lane: a row's 64 values sit in the 8 lanes that share lane >> 3, so the per-head RMSNorm is three
+    // xor-shuffles inside the group, and a (token, head) row leaves as 8 x 16 bytes = one 128-byte line.
+    auto body_qkv = [&]() {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const int hc = ep.qkv_H * 64, which = nw / hc, head = (nw % hc) >> 6;
+        const int n8 = nw + c8;
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, w0 = make_float4(1.f, 1.f, 1.f, 1.f), w1 = w0;
+        if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
+        const bool norm = which < 2 && ep.qkv_w[which] != nullptr;
+        if (norm) {
+            w0 = *reinterpret_cast<const float4*>(ep.qkv_w[which] + c8);
+            w1 = *reinterpret_cast<const float4*>(ep.qkv_w[which] + c8 + 4);
+        }
+        const float post = which == 0 ? ep.qkv_qscale : 1.0f;
+        bf16_t* const base = ep.qkv_out[which] + (long)head * ep.qkv_L * 64 + c8;
+        const float* rd8 = scr + r8 * EP_LD + c8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            float4 v0[4], v1[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
+                v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
+            }
+            // token of pass p: m = mw + 32 i + r8 + 8 p  ->  (batch, position); one division per block, then steps of 8
+            const int m0r = mw + i * 32 + r8;
+            int bb = m0r / ep.qkv_L, ll = m0r - bb * ep.qkv_L;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 x = v0[p], y = v1[p];
+                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                float rs = post;
+                if (norm) {
+                    float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w + y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+                    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                    rs *= rsqrtf(ss * (1.0f / 64.0f) + ep.qkv_eps);
+                }
+                x.x *= rs * w0.x; x.y *= rs * w0.y; x.z *= rs * w0.z; x.w *= rs * w0.w;
+                y.x *= rs * w1.x; y.y *= rs * w1.y; y.z *= rs * w1.z; y.w *= rs * w1.w;
+                if (m0r + 8 * p < M && n8 < N)
+                    *reinterpret_cast<uint4*>(base + (((long)bb * ep.qkv_H) * ep.qkv_L + ll) * 64) =
+                        make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+                ll += 8;
+                while (ll >= ep.qkv_L) { ll -= ep.qkv_L; ++bb; }
+            }
+        }
+    };
+    const bool interior = mw + MI * 32 <= M && nw + 64 <= N;
+    if constexpr (ACT == 4) {
+        body_qkv();
+        return;
+    }
+    if constexpr (sizeof(TOUT) == 2 && RES == 0 && ACT != 4) {
+        if (interior && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+            (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0) &&
+            (ACT < 2 || ((ep.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0))) {
+            body8();
+            return;
+        }
+    }
+    if (interior) body(std::false_type{});
+    else body(std::true_type{});
+}
+
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef __attribute__((address_space(1))) const void glb_ptr_t;
+
+constexpr int BM5 = 256, BN5 = 256;              // tile of the 256-wide kernels (v5, v7, v10, v11)
+constexpr int CHUNK10 = 256 * ROWB;              // 32 KiB: one operand's 256 rows x 64 k of one K-stage (v10, v11)
+
+#define M324_BARRIER()                             \
+    do {                                           \
+        asm volatile("s_barrier" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+
+}  // namespace

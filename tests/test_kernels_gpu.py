@@ -97,12 +97,13 @@ def test_gemm_inplace_residual(dtype):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
-@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v7"])
+@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v7", "v10", "v11"])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("K", [64, 192, 832])
 def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
     """M324_GEMM=vN (read per call) forces one kernel schedule; each must handle ragged M / N tiles, a K shorter than
-    its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v7 to v5.)"""
+    its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v7 / v10 / v11 to v5;
+    the chunk-ring kernels v10 / v11 need two K-stages of 64 and hand K = 64 to v7.)"""
     ops = _ops()
     from motion324_amd.lib import ACT_GELU
     monkeypatch.setenv("M324_GEMM", variant)
@@ -132,6 +133,35 @@ def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
     x = x0.clone().to(DEV)
     ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), x, residual=x)
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
+
+
+@pytest.mark.parametrize("variant", ["v10", "v11"])
+def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
+    """The chunk-ring kernels on a grid with more tiles than CUs (20 x 16 = 320 tiles of 256 x 256, ragged last row of
+    tiles): the persistent v11 walks 1-2 tiles per workgroup with the next tile's first chunks prefetched under the
+    epilogue; bias + GELU into bf16, then the in-place fp32 residual stream.  The default choice must agree bit for bit
+    with the forced schedule's summation order (same k order in every tile kernel)."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    dtype = torch.bfloat16
+    M, N, K = 20 * 256 - 37, 4096, 192
+    a, w = _q(_rand((M, K), 31), dtype), _q(_rand((N, K), 32, 0.1), dtype)
+    bias = _rand((N,), 33)
+    v = a.double() @ w.double().T + bias.double()
+    g = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+    ad, wd, bd = a.to(dtype).to(DEV), w.to(dtype).to(DEV), bias.to(DEV)
+    monkeypatch.setenv("M324_GEMM", variant)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(ad, wd, out, bias=bd, act=ACT_GELU)
+    assert rel_err(out.float(), g) < TOL[dtype]
+    x0 = _rand((M, N), 34)
+    x = x0.clone().to(DEV)
+    ops.gemm(ad, wd, x, bias=bd, residual=x)
+    assert rel_err(x, x0.double() + v) < 1e-5
+    monkeypatch.setenv("M324_GEMM", "v2")
+    x2 = x0.clone().to(DEV)
+    ops.gemm(ad, wd, x2, bias=bd, residual=x2)
+    assert torch.equal(x, x2)
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 768, 3072), (64, 2304, 768), (37, 200, 64), (5, 36, 448)])

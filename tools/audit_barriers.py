@@ -2,16 +2,16 @@
 """Static check of the compiled kernels: every s_barrier of a kernel that stages tiles by LDS-DMA (global_load_lds) must
 have a vmcnt wait in the 14 instructions before it -- __syncthreads() alone does NOT make the compiler wait for an
 in-flight LDS-DMA (round 1: the attention dQ kernel read a stage that had not landed).
-usage: tools/audit_barriers.py   (compiles motion324_amd/csrc/{gemm,attention}.hip to assembly with hipcc)"""
+usage: tools/audit_barriers.py   (compiles motion324_amd/csrc/{gemm,gemm_ring4,attention}.hip to assembly with hipcc)"""
 import os, re, subprocess, sys, tempfile
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 bad_total = 0
-for src in ("gemm.hip", "attention.hip"):
+for src in ("gemm.hip", "gemm_ring4.hip", "attention.hip"):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                        "--cuda-device-only", "-S", "-o", out, os.path.join(root, "motion324_amd", "csrc", src)],
+        form = [] if src == "gemm_ring4.hip" else ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # as motion324_amd/build.py
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + form + ["--cuda-device-only", "-S", "-o", out, os.path.join(root, "motion324_amd", "csrc", src)],
                        check=True, stderr=subprocess.DEVNULL)
         kernels, name = {}, None
         for line in open(out):
