@@ -936,7 +936,7 @@ static int xcd_remap() {
     return v;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11 forces a variant (A/B measurements, tests).
+// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11|v12 forces a variant (A/B measurements, tests).
 static int forced_variant() {      // read per call: lets one process A/B-toggle the variant
     const char* e = getenv("M324_GEMM");
     return (e && e[0] == 'v') ? atoi(e + 1) : 0;
@@ -949,7 +949,7 @@ static int pick_variant(const m324_gemm_args* a) {
     const bool ring_ok = bf16 && a->K % 64 == 0 && a->K >= 128;      // v10 / v11: K-stages of 64, at least two
     if (f == 1 || f == 2 || f == 5) return f;
     if (f == 7) return bf16 ? 7 : 5;
-    if (f == 10 || f == 11) return ring_ok ? f : (bf16 ? 7 : 5);
+    if (f == 10 || f == 11 || f == 12) return ring_ok ? f : (bf16 ? 7 : 5);
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
@@ -964,13 +964,19 @@ static int pick_variant(const m324_gemm_args* a) {
         if (ring_ok) return a->out_dtype == M324_F32 ? 11 : 10;
         return a->K >= 96 ? 7 : 5;
     }
+    // narrow outputs with a long contraction (the MLP's fc2 at N = 768, K = 3072): 256 x 128 tiles fill the chip in one
+    // round where 256 x 256 tiles cannot, with 3/4 of the 128 x 128 tiles' texture-path traffic (v12: 58 -> 51 us at
+    // M = 10368, 55 -> 45 us at M = 8224); at K = 768 the two tie and v2 stays.
+    const long t12 = (long)ceil_div(a->N, 128) * ceil_div(a->M, 256);
+    const double e12 = (double)t12 / (double)(((t12 + 255) / 256) * 256);
+    if (ring_ok && a->K >= 1024 && t12 >= 180 && e12 >= 0.70) return 12;
     return 2;
 }
 
 template <typename TOUT, int ACT, int RES>
 static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
-    if (variant == 11) {
-        m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap());
+    if (variant == 11 || variant == 12) {
+        m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap(), variant);
         return;
     }
     if (variant == 10) {

@@ -1,4 +1,5 @@
-// m324_gemm, schedule v11: the 4-wave 256 x 256 chunk-ring kernel.  Own translation unit because it must be compiled
+// m324_gemm, schedules v11 (4-wave persistent 256 x 256 chunk ring) and v12 (4-wave 256 x 128, three-stage ring).  Own
+// translation unit because v11 must be compiled
 // WITHOUT -amdgpu-mfma-vgpr-form: a wave owns a 128 x 128 block = 256 accumulator registers, which fill the AGPR half
 // of the unified file while fragments, addresses and the epilogue use the VGPR half (400 registers, no spills); with
 // the flag hipcc keeps the accumulators in VGPRs and shuffles everything else through v_accvgpr_mov.
@@ -155,22 +156,157 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
 #undef M324_SG
 }
 
+// ------------------------------------------------------------------------------------------------
+// v12: 256 x 128 tiles for the outputs that are only 768 columns wide (every attention / MLP output projection of the
+// trunk and of DINO: 28 + 28 launches per clip).  256 x 256 tiles give those 123 workgroups for 256 CUs; the 128 x 128
+// tiles of v2 fill the chip but move 64 KiB through the texture path per 4.2 MFLOP and are bound by it (tools/dma_lab:
+// 29-33 cycles per KiB -> 0.87 us per K-stage against 0.28 us of MFMA).  A 256 x 128 tile moves 48 KiB for the same
+// work, 41 x 6 = 246 tiles cover the chip in one round, and a K-stage is 48 KiB of LDS, so THREE whole stages fit
+// (144 KiB): two stages of look-ahead instead of v10's 1.5.  Four waves (one per SIMD) as 2 (M) x 2 (N), each a
+// 128 x 64 block = 4 x 2 accumulators; a phase (k-step of 16) is 8 MFMAs, 6 fragment reads and 3 LDS-DMA pieces.
+// MFMA work is rotated by one k-step against the LDS stages exactly as in v10:
+//   X_{s-1}: stage s landed, slot of stage s-1 free -> iteration s streams stage s+2 into it
+//   phases: MFMA (s-1,3) | (s,0) | (s,1) | (s,2), each under the fragment reads of the next k-step
+//   lgkmcnt(0) (stage s is in registers), vmcnt(12) (stage s+1 landed; the 12 pieces of s+2 may fly), X_s.
+constexpr int STAGE12 = (256 + 128) * ROWB;       // 48 KiB
+
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                         long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
+                                                         int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * STAGE12];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lid = blockIdx.x;
+    if (xcd_remap & 1) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * 256, n0 = (lid % ntn) * 128;
+
+    // LDS-DMA pieces of 8 rows x 128 B: wave w moves row groups 8w .. 8w+7 of A (32 groups) and 4w .. 4w+3 of W (16 groups)
+    const bf16_t* g[12];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 8 + (lane >> 3);
+        g[i] = A + (long)min(m0 + r, M - 1) * lda + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        g[8 + i] = W + (long)min(n0 + r, N - 1) * ldw + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+    }
+    auto issue3 = [&](int i0, int st, int slot) {           // pieces i0 .. i0+2 of stage st
+        unsigned char* base = smem + slot * STAGE12;
+#pragma unroll
+        for (int i = i0; i < i0 + 3; ++i) {
+            unsigned char* d = i < 8 ? base + wave * 8192 + i * 1024 : base + 32768 + wave * 4096 + (i - 8) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i] + (long)st * 64), (lds_ptr_t*)d, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int NS = K / 64;
+    const int aoff = lds_off(wm * 128 + l31, hi), boff = 32768 + lds_off(wn * 64 + l31, hi);
+    bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[1][i] = (bf16x8)(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[1][j] = (bf16x8)(0);
+    auto load_frags = [&](int set, int slot, int ks) {
+        const unsigned char* base = smem + slot * STAGE12;
+        const int x = ks << 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(base + ((boff + j * 4096) ^ x));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(base + ((aoff + i * 4096) ^ x));
+    };
+    auto mma8 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+    };
+#define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    auto sched_phase = [&]() {                               // M r M r M r M r M r M r M G M G G
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 2);
+    };
+
+    issue3(0, 0, 0); issue3(3, 0, 0); issue3(6, 0, 0); issue3(9, 0, 0);
+    {
+        const int s1 = NS > 1 ? 1 : 0;
+        issue3(0, s1, 1); issue3(3, s1, 1); issue3(6, s1, 1); issue3(9, s1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (stage 1 may fly)
+    M324_BARRIER();
+    int slot = 0;                                           // s % 3
+    for (int s = 0; s < NS; ++s) {
+        const int fslot = slot == 0 ? 2 : slot - 1;         // (s + 2) % 3 == (s - 1) % 3
+        const int sn = s + 2 < NS ? s + 2 : NS - 1;
+        load_frags(0, slot, 0);
+        issue3(0, sn, fslot);
+        mma8(1);                                            // (s-1, k-step 3); zeros in the first iteration
+        sched_phase();
+        load_frags(1, slot, 1);
+        issue3(3, sn, fslot);
+        mma8(0);
+        sched_phase();
+        load_frags(0, slot, 2);
+        issue3(6, sn, fslot);
+        mma8(1);
+        sched_phase();
+        load_frags(1, slot, 3);
+        issue3(9, sn, fslot);
+        mma8(0);
+        sched_phase();
+        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        M324_BARRIER();
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    mma8(1);                                                // (NS-1, k-step 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
+#undef M324_SG
+    M324_BARRIER();
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep);
+}
+
 }  // namespace
 
 namespace m324 {
 
-void launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap) {
-    const int ntn = ceil_div(a->N, BN5), ntiles = ntn * ceil_div(a->M, BM5);
-    static const int n_cu = [] {                            // one persistent workgroup per CU (160 KiB of LDS each)
+void launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap, int variant) {
+    const int ntn = ceil_div(a->N, variant == 12 ? 128 : BN5), ntiles = ntn * ceil_div(a->M, BM5);
+    static const int n_cu = [] {                            // v11: one persistent workgroup per CU (160 KiB of LDS each)
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
         return n;
     }();
-    const dim3 grid(ntiles < n_cu ? ntiles : n_cu);
+    const dim3 grid(variant == 12 ? ntiles : (ntiles < n_cu ? ntiles : n_cu));
 #define M324_R4(TOUT, ACT, RES)                                                                                              \
-    hipLaunchKernelGGL((gemm_ring4_kernel<TOUT, ACT, RES>), grid, dim3(256), 0, s, (const bf16_t*)a->A, a->lda,              \
-                       (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep, ntn, ntiles, xcd_remap)
+    do {                                                                                                                     \
+        if (variant == 12)                                                                                                   \
+            hipLaunchKernelGGL((gemm_ring3_kernel<TOUT, ACT, RES>), grid, dim3(256), 0, s, (const bf16_t*)a->A, a->lda,      \
+                               (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep, ntn, xcd_remap);      \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((gemm_ring4_kernel<TOUT, ACT, RES>), grid, dim3(256), 0, s, (const bf16_t*)a->A, a->lda,      \
+                               (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep, ntn, ntiles,          \
+                               xcd_remap);                                                                                   \
+    } while (0)
 #define M324_R4_OUT(ACT, RES)                                      \
     do {                                                           \
         if (a->out_dtype == M324_BF16) M324_R4(bf16_t, ACT, RES);  \

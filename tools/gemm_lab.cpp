@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
     const Shape shapes[] = {
         {"trunk qkv", 10368, 2304, 768, 0},   {"trunk fc+res", 10368, 768, 768, 2},  {"trunk fc1 gelu", 10368, 3072, 768, 1},
         {"trunk fc2+res", 10368, 768, 3072, 2}, {"dino qkv", 8224, 2304, 768, 3},     {"dino fc1 gelu", 8224, 3072, 768, 1},
-        {"dino fc2+res", 8224, 768, 3072, 2},  {"dec fc+res", 65536, 768, 768, 2},    {"dec fc1 gelu", 65536, 3072, 768, 1},
+        {"dino fc2+res", 8224, 768, 3072, 2},  {"dino fc+res", 8224, 768, 768, 2}, {"dec fc+res", 65536, 768, 768, 2},    {"dec fc1 gelu", 65536, 3072, 768, 1},
         {"dec fc1 plain", 65536, 3072, 768, 0}, {"dec fc2+res", 65536, 768, 3072, 2}, {"square 4096", 4096, 4096, 4096, 0},
         {"square 8192", 8192, 8192, 8192, 0},   {"pcd fc2", 64, 768, 3072, 2},         {"pcd fc1 gelu", 64, 3072, 768, 1},
         {"pcd qkv", 64, 2304, 768, 0},          {"pcd fc", 64, 768, 768, 2},
