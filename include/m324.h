@@ -32,7 +32,8 @@ typedef enum { M324_ACT_NONE = 0, M324_ACT_GELU = 1 } m324_act;
  *                            MLP both gelu(z) (C) and z (aux), which the backward needs (autograd of transformer.py:73-78);
  *   M324_AUX_MUL_GELU_GRAD : the result is multiplied by gelu'(aux[m,n]) = Phi(z) + z phi(z) before it is stored -- the
  *                            dgrad GEMM of the MLP's second Linear then delivers d(pre-activation) directly.           */
-typedef enum { M324_AUX_NONE = 0, M324_AUX_STORE_PREACT = 1, M324_AUX_MUL_GELU_GRAD = 2, M324_AUX_QKV_HEADS = 3 } m324_aux_mode;
+typedef enum { M324_AUX_NONE = 0, M324_AUX_STORE_PREACT = 1, M324_AUX_MUL_GELU_GRAD = 2, M324_AUX_QKV_HEADS = 3,
+               M324_AUX_QKV_HEADS_VT = 4 } m324_aux_mode;
 
 /* ABI version of this header (bumped on any signature change). */
 int m324_abi_version(void);
@@ -72,7 +73,9 @@ typedef struct {
     /* M324_AUX_QKV_HEADS (inference, bf16): the [M, 3*H*64] result of a fused q|k|v projection is not stored token-major
      * in C (C may be NULL) but split into head-major qkv_q / qkv_k / qkv_v [B, H, L, 64] (row m = b * qkv_L + l), with
      * the per-head RMSNorm of q and k (weights qkv_qw / qkv_kw [64], NULL = none, eps qkv_eps) and q * qkv_qscale
-     * applied on the fp32 accumulators -- what m324_qkv_split does in a second pass (transformer.py:36-42,200-207).   */
+     * applied on the fp32 accumulators -- what m324_qkv_split does in a second pass (transformer.py:36-42,200-207).   
+     * M324_AUX_QKV_HEADS_VT: the same, but qkv_v receives the TRANSPOSED, key-permuted Vt [B, H, 64, qkv_L] that
+     * m324_attention reads by default (m324_qkv_split's Vt; needs qkv_L % 128 == 0, so there is no padding).         */
     void* qkv_q; void* qkv_k; void* qkv_v;
     const float* qkv_qw; const float* qkv_kw;
     float qkv_eps, qkv_qscale;

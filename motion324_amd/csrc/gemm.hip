@@ -995,7 +995,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
     Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off,
                 a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode,
                 {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
-                a->qkv_L, a->qkv_H,
+                a->qkv_L, a->qkv_H, a->aux_mode == M324_AUX_QKV_HEADS_VT ? 1 : 0,
                 (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > (128l << 20)) ? 1 : 0};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
@@ -1027,7 +1027,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
                                a->K, ep, (int)grid.x, xcd_remap());                                                      \
     } while (0)
-        if (a->aux_mode == M324_AUX_QKV_HEADS) {
+        if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) {
             if constexpr (sizeof(TOUT) == 2) M324_GLDS(4, 0);
         } else if (a->aux_mode == M324_AUX_STORE_PREACT) {
             M324_GLDS(2, 0);
@@ -1085,7 +1085,8 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
 }
 
 extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
-    M324_REQUIRE(a && a->A && a->W && (a->C || a->aux_mode == M324_AUX_QKV_HEADS), "m324_gemm: null pointer");
+    const bool qkv_mode = a && (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT);
+    M324_REQUIRE(a && a->A && a->W && (a->C || qkv_mode), "m324_gemm: null pointer");
     M324_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "m324_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     const int bk = a->in_dtype == M324_BF16 ? 64 : 32;
     M324_REQUIRE(a->K % bk == 0, "m324_gemm: K=%d must be a multiple of %d", a->K, bk);
@@ -1097,8 +1098,10 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
     M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
                  "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
-    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 3, "m324_gemm: aux_mode %d", a->aux_mode);
-    if (a->aux_mode == M324_AUX_QKV_HEADS) {
+    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 4, "m324_gemm: aux_mode %d", a->aux_mode);
+    if (qkv_mode) {
+        M324_REQUIRE(a->aux_mode != M324_AUX_QKV_HEADS_VT || a->qkv_L % 128 == 0,
+                     "m324_gemm: M324_AUX_QKV_HEADS_VT needs qkv_L %% 128 == 0 (L=%d)", a->qkv_L);
         M324_REQUIRE(a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16 && a->qkv_q && a->qkv_k && a->qkv_v && a->qkv_H > 0 &&
                          a->qkv_L > 0 && a->N == 3 * a->qkv_H * 64 && a->M % a->qkv_L == 0 && !a->residual && !a->gamma &&
                          a->act == M324_ACT_NONE && a->row_gin <= 0 && a->batch <= 1 && a->M > 64 && vec_ok(a),

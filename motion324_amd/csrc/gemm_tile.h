@@ -22,6 +22,7 @@ struct Epilogue {
     const float* qkv_w[2];       // RMSNorm weights of q, k (or null)
     float qkv_eps, qkv_qscale;
     int qkv_L, qkv_H;
+    int qkv_vt;                  // M324_AUX_QKV_HEADS_VT: qkv_out[2] is Vt [B, H, 64, L] (key quarters of every 16 in the order 0,2,1,3)
     int stream;                  // bf16 outputs without residual: store non-temporal (host: output larger than the MALL keeps)
 };
 
@@ -408,6 +409,30 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            if (which == 2 && ep.qkv_vt) {
+                // V of this head, transposed: lane d owns column d of the 32 x 64 block (32 conflict-free b32 reads, the
+                // lanes of a wave hit 64 consecutive banks) and writes its 32 tokens as 64 contiguous bytes of Vt row d,
+                // token quarters of each 16-group in the order 0, 2, 1, 3 (what the attention's P^T fragments contract).
+                // qkv_L % 128 == 0 (host-checked): a 32-token block never straddles a batch and Vt has no padding.
+                const int m0b = mw + i * 32;
+                if (m0b < M && nw + 64 <= N) {
+                    const float bd = ep.bias ? ep.bias[nw + lane] : 0.f;
+                    const int bb = m0b / ep.qkv_L, ll = m0b - bb * ep.qkv_L;
+                    bf16_t* dst = ep.qkv_out[2] + (((long)bb * ep.qkv_H + head) * 64 + lane) * (long)ep.qkv_L + ll;
+                    float t[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) t[k] = scr[k * EP_LD + lane] + bd;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const float* u = t + g * 16;
+                        *reinterpret_cast<uint4*>(dst + g * 16) =
+                            make_uint4(pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[8], u[9]), pack_bf16x2(u[10], u[11]));
+                        *reinterpret_cast<uint4*>(dst + g * 16 + 8) =
+                            make_uint4(pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7]), pack_bf16x2(u[12], u[13]), pack_bf16x2(u[14], u[15]));
+                    }
+                }
+                continue;
+            }
             float4 v0[4], v1[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {

@@ -13,7 +13,7 @@ void m324_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int m324_abi_version(void) { return 8; }
+extern "C" int m324_abi_version(void) { return 9; }
 
 extern "C" int m324_last_error(char* buf, int n) {
     if (!buf || n <= 0) return (int)strlen(g_err);

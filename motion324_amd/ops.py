@@ -112,7 +112,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     preact_out [M, N] (out's dtype) also receives the value the activation is applied to (M324_AUX_STORE_PREACT);
     gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only.
     qkv_heads = (Q, K, V, q_w, k_w, eps, q_scale, L, H): the fused q|k|v projection is written head-major into Q / K / V
-    [B, H, L, 64] with per-head RMSNorm and the q pre-scale (M324_AUX_QKV_HEADS); `out` is ignored (may be None)."""
+    [B, H, L, 64] with per-head RMSNorm and the q pre-scale (M324_AUX_QKV_HEADS); `out` is ignored (may be None).
+    A V of shape [B, H, 64, L] selects M324_AUX_QKV_HEADS_VT: V leaves transposed and key-permuted, the operand
+    attention() reads by default (L % 128 == 0)."""
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K or a.dtype != w.dtype:
@@ -124,13 +126,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     if qkv_heads is not None:
         Qo, Ko, Vo, qw, kw, eps, q_scale, Lh, Hh = qkv_heads
         Bh = M // Lh
+        vt = tuple(Vo.shape) == (Bh, Hh, 64, Lh) and Lh != 64
         for t in (Qo, Ko, Vo):
-            if t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (Bh, Hh, Lh, 64):
-                raise L.M324Error(f"gemm: qkv_heads output {t.dtype}{tuple(t.shape)} (want bf16 {(Bh, Hh, Lh, 64)})")
+            want = (Bh, Hh, 64, Lh) if (vt and t is Vo) else (Bh, Hh, Lh, 64)
+            if t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != want:
+                raise L.M324Error(f"gemm: qkv_heads output {t.dtype}{tuple(t.shape)} (want bf16 {want})")
+        if vt and Lh % 128:
+            raise L.M324Error(f"gemm: a transposed V output needs L % 128 == 0 (L={Lh})")
         args.C, args.ldc = None, N
         args.in_dtype, args.out_dtype = code_of(a.dtype), BF16
         args.bias = _vec(bias, N, "bias")
-        args.aux_mode = 3
+        args.aux_mode = 4 if vt else 3
         args.qkv_q, args.qkv_k, args.qkv_v = _p(Qo), _p(Ko), _p(Vo)
         args.qkv_qw, args.qkv_kw = _vec(qw, 64, "q_w"), _vec(kw, 64, "k_w")
         args.qkv_eps, args.qkv_qscale, args.qkv_L, args.qkv_H = eps, q_scale, Lh, Hh

@@ -111,6 +111,7 @@ def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor) -
 # below 2048 tokens; longer ones keep m324_qkv_split's transposed V, whose 8-wave attention kernel is 9 % faster than
 # its transposing-read variant.  M324_FUSE_QKV=0 disables (A/B measurements).
 FUSE_QKV = os.environ.get("M324_FUSE_QKV", "1") != "0"
+FUSE_QKV_VT = os.environ.get("M324_FUSE_QKV_VT", "1") != "0"     # long sequences: the epilogue writes the transposed V itself
 
 
 _FUSE_OFF = 0
@@ -130,7 +131,9 @@ class fusion_disabled:
 
 
 def fuse_qkv(P: Prepared, rows: int, L: int) -> bool:
-    return (FUSE_QKV and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64 and L < 2048
+    """Per-frame blocks (L < 2048): head-major Q / K / V, attention with the row-major-V kernel.  Long sequences (the
+    global blocks) keep the faster transposed-V attention; the projection epilogue writes Vt itself when L % 128 == 0."""
+    return (FUSE_QKV and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64 and (L < 2048 or (FUSE_QKV_VT and L % 128 == 0))
             and not torch.is_grad_enabled())
 
 
@@ -160,10 +163,12 @@ class QK_Norm_TransformerBlock(nn.Module):
         if fuse_qkv(P, rows, L) and kv_gather is None:
             # short sequences (the per-frame blocks): the projection's epilogue writes head-major Q / K / V itself
             # (RMSNorm + q pre-scale on the fp32 accumulators) and the attention reads V row-major
-            Q, K, V = (torch.empty((B, a.num_heads, L, 64), dtype=P.dtype, device=x.device) for _ in range(3))
+            long_seq = L >= 2048
+            Q, K = (torch.empty((B, a.num_heads, L, 64), dtype=P.dtype, device=x.device) for _ in range(2))
+            V = torch.empty((B, a.num_heads, 64, L) if long_seq else (B, a.num_heads, L, 64), dtype=P.dtype, device=x.device)
             ops.gemm(h, P.mat(a.to_qkv.weight), None, bias=P.vec(a.to_qkv.bias),
                      qkv_heads=(Q, K, V, qw, kw, RMS_EPS, ops.Q_PRESCALE, L, a.num_heads))
-            ops.attention(Q, K, V, h, prescaled=True, v_rowmajor=True)
+            ops.attention(Q, K, V, h, prescaled=True, v_rowmajor=not long_seq)
             ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
             return _mlp_residual(P, self.norm2, self.mlp, x)
         qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)

@@ -282,6 +282,39 @@ def test_gemm_qkv_heads_epilogue(B, L, H, norm, bias):
     assert rel_err(out_f.float(), ref_o) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [None, "v2", "v7", "v10", "v11"])
+def test_gemm_qkv_heads_transposed_v_epilogue(monkeypatch, variant):
+    """M324_AUX_QKV_HEADS_VT: as the head-major epilogue, but V leaves as the transposed, key-permuted Vt the default
+    attention kernel reads.  Vt must equal m324_gemm + m324_qkv_split bit for bit (both round acc + bias to bf16 once);
+    Q / K differ by the one bf16 rounding the two-pass form puts before the RMSNorm.  Every tile kernel's ACT = 4 path."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    B, L, H, K = 2, 384, 4, 192
+    C = H * 64
+    x = _q(_rand((B * L, K), 191), dtype).to(dtype).to(DEV)
+    w = _q(_rand((3 * C, K), 192, 0.1), dtype).to(dtype).to(DEV)
+    b = _rand((3 * C,), 193).to(DEV)
+    qw, kw = (1 + 0.1 * _rand((64,), 194)).to(DEV), (1 + 0.1 * _rand((64,), 195)).to(DEV)
+    qkv = torch.empty((B * L, 3 * C), dtype=dtype, device=DEV)
+    ops.gemm(x, w, qkv, bias=b)
+    Q2, K2, Vt2 = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, 1e-5, B, L, H, dtype, q_scale=ops.Q_PRESCALE)
+    if variant:
+        monkeypatch.setenv("M324_GEMM", variant)
+    Q, Kk = (torch.full((B, H, L, 64), float("nan"), dtype=dtype, device=DEV) for _ in range(2))
+    Vt = torch.full((B, H, 64, L), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(x, w, None, bias=b, qkv_heads=(Q, Kk, Vt, qw, kw, 1e-5, ops.Q_PRESCALE, L, H))
+    assert torch.equal(Vt, Vt2)
+    assert rel_err(Q.float(), Q2.float().double()) < 6e-3 and rel_err(Kk.float(), K2.float().double()) < 6e-3
+    out_f, out_2 = (torch.empty((B * L, C), dtype=dtype, device=DEV) for _ in range(2))
+    ops.attention(Q, Kk, Vt, out_f, prescaled=True)
+    ops.attention(Q2, K2, Vt2, out_2, prescaled=True)
+    assert rel_err(out_f.float(), out_2.float().double()) < 1e-2
+    from motion324_amd.lib import M324Error
+    with pytest.raises(M324Error, match="128"):        # L = 200: a 32-token block would straddle the batches
+        ops.gemm(x[:400], w, None, bias=b, qkv_heads=(Q[:, :, :200].contiguous(), Kk[:, :, :200].contiguous(),
+                                                       torch.empty((2, H, 64, 200), dtype=dtype, device=DEV), qw, kw, 1e-5, 1.0, 200, H))
+
+
 def test_gemm_rejects_bad_k():
     ops = _ops()
     from motion324_amd.lib import M324Error
