@@ -164,6 +164,28 @@ def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
     assert torch.equal(x, x2)
 
 
+@pytest.mark.parametrize("variant,M,N,K", [("v10", 8192, 3072, 768), ("v11", 8192, 3072, 768), ("v12", 10368, 768, 3072),
+                                            ("v7", 8192, 3072, 768)])
+def test_gemm_ring_kernels_are_race_free(monkeypatch, variant, M, N, K):
+    """The LDS-DMA rings state their own vmcnt waits (tests/test_static.py audits them); a missing one shows up as a tile
+    read before it landed -- rarely, and only when the chip is full.  Forty launches at the model's shapes must give
+    forty bit-identical results, and the first must match the 128 x 128 kernel (same k order)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    a = _q(_rand((M, K), 41), dtype).to(dtype).to(DEV)
+    w = _q(_rand((N, K), 42, 0.05), dtype).to(dtype).to(DEV)
+    monkeypatch.setenv("M324_GEMM", "v2")
+    ref = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(a, w, ref)
+    monkeypatch.setenv("M324_GEMM", variant)
+    outs = [torch.empty((M, N), dtype=dtype, device=DEV) for _ in range(4)]
+    for it in range(40):
+        ops.gemm(a, w, outs[it % 4])
+        if it % 4 == 3:
+            for o in outs:
+                assert torch.equal(o, ref), f"launch {it}: result differs"
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 768, 3072), (64, 2304, 768), (37, 200, 64), (5, 36, 448)])
 def test_gemm_skinny_rows(M, N, K):
     """M <= 64 in bf16 takes the split-K-over-waves kernel (the shape encoder's 64 latent tokens): ragged M and N,
