@@ -27,7 +27,8 @@
 struct Shape {
     const char* name;
     int M, N, K;
-    int epi;   // 0 plain bf16 out, 1 bias+gelu bf16 out, 2 fp32 residual (in place) fp32 out, 3 bias bf16 out
+    int epi;   // 0 plain bf16 out, 1 bias+gelu bf16 out, 2 fp32 residual (in place) fp32 out, 3 bias bf16 out,
+               // 4 fused q|k|v heads (RMSNorm, transposed V; L = M, H = N / 192), 5 the same with bias and row-major V, L = 257
 };
 
 static unsigned short f2bf(float f) {
@@ -67,6 +68,7 @@ int main(int argc, char** argv) {
         {"dec fc1 plain", 65536, 3072, 768, 0}, {"dec fc2+res", 65536, 768, 3072, 2}, {"square 4096", 4096, 4096, 4096, 0},
         {"square 8192", 8192, 8192, 8192, 0},   {"pcd fc2", 64, 768, 3072, 2},         {"pcd fc1 gelu", 64, 3072, 768, 1},
         {"pcd qkv", 64, 2304, 768, 0},          {"pcd fc", 64, 768, 768, 2},
+        {"trunk qkv heads", 10368, 2304, 768, 4}, {"dino qkv heads", 8224, 2304, 768, 5},
     };
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
@@ -106,6 +108,21 @@ int main(int argc, char** argv) {
         a.bias = (s.epi == 1 || s.epi == 3) ? db : nullptr;
         a.act = s.epi == 1 ? M324_ACT_GELU : M324_ACT_NONE;
         if (s.epi == 2) { a.residual = (const float*)dC; a.ldr = s.N; }
+        void *dQ = nullptr, *dK = nullptr, *dV = nullptr;
+        float* dnw = nullptr;
+        if (s.epi >= 4) {      // outputs go to Q / K / V; the correctness column then compares nothing (C untouched)
+            const size_t third = (size_t)s.M * (s.N / 3) * 2;
+            HIP_OK(hipMalloc(&dQ, third)); HIP_OK(hipMalloc(&dK, third)); HIP_OK(hipMalloc(&dV, third));
+            std::vector<float> ones(64, 1.0f);
+            HIP_OK(hipMalloc((void**)&dnw, 256));
+            HIP_OK(hipMemcpy(dnw, ones.data(), 256, hipMemcpyHostToDevice));
+            a.bias = s.epi == 5 ? db : nullptr;
+            a.aux_mode = s.epi == 4 ? M324_AUX_QKV_HEADS_VT : M324_AUX_QKV_HEADS;
+            a.qkv_q = dQ; a.qkv_k = dK; a.qkv_v = dV;
+            a.qkv_qw = s.epi == 4 ? dnw : nullptr; a.qkv_kw = s.epi == 4 ? dnw : nullptr;
+            a.qkv_eps = 1e-5f; a.qkv_qscale = 0.18f; a.qkv_H = s.N / 192;
+            a.qkv_L = s.epi == 4 ? s.M : 257;
+        }
         auto run = [&](int variant, void* out) {
             char env[16];
             snprintf(env, sizeof env, "v%d", variant);
@@ -182,6 +199,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
         hipFree(dA); hipFree(dW); hipFree(dC); hipFree(dRef); hipFree(db);
         if (dR0) hipFree(dR0);
+        if (dQ) { hipFree(dQ); hipFree(dK); hipFree(dV); hipFree(dnw); }
     }
     return 0;
 }
