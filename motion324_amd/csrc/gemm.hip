@@ -423,21 +423,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const bf16_t* __restr
 //   phase 1: MFMA (s,0)   | fragments (s,1) | 2 pieces of W_{s+1}      phase 3: MFMA (s,2) | fragments (s,3) | 2 pieces of A_{s+2}
 //   lgkmcnt(0) (stage s is in registers), vmcnt(4) (W_{s+1} landed; the 4 pieces of A_{s+2} may fly), X_s.
 // Past the end of K the last stage is fetched again into free chunks (never read), so the loop is branch-free.
-#ifdef M324_V10_PROF
-__device__ long long g_v10_prof[8];               // lab builds only: loop / vmcnt-wait / barrier ticks, samples, loop time (10 ns), prologue, epilogue ticks
-#define M324_PROF_T() (prof ? clock64() : 0)
-#else
-#define M324_PROF_T() 0
-#endif
 
 template <typename TOUT, int ACT, int RES>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
                                                            long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
                                                            int xcd_remap) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * CHUNK10];
-#ifdef M324_V10_PROF
-    const long long t_entry = clock64();
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -521,78 +512,54 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
 #endif
     };
 
-    // prologue: A_0, W_0, A_1 (chunks 0, 1, 2)
-    issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
-    issue2(gb, 0, 0, 1); issue2(gb, 2, 0, 1);
+    // prologue: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile (12 in all at
+    // K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue and is peeled
     {
-        const int s1 = NS > 1 ? 1 : 0;
+        const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
+        issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
+        issue2(gb, 0, 0, 1); issue2(gb, 2, 0, 1);
         issue2(ga, 0, s1, 2); issue2(ga, 2, s1, 2);
+        issue2(gb, 0, s1, 3); issue2(gb, 2, s1, 3);
+        issue2(ga, 0, s2, 4); issue2(ga, 2, s2, 4);
     }
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // stage 0 landed (A_1 may fly)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (A_1, W_1, A_2 may fly)
     M324_BARRIER();
     int pa = 0, pw = 1;                                     // ring positions of A_s, W_s
-    [[maybe_unused]] long long t_vm = 0, t_bar = 0;
-#ifdef M324_V10_PROF
-    const bool prof = true;
-#else
-    constexpr bool prof = false;
-#endif
-    [[maybe_unused]] const long long t_loop0 = M324_PROF_T();
-#ifdef M324_V10_PROF
-    const long long r_loop0 = wall_clock64();
-#endif
-    for (int s = 0; s < NS; ++s) {
+    auto stage = [&](int s, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
         int pwn = pa + 3, pan = pa + 4;                     // positions of W_{s+1} (chunk 2s+3) and A_{s+2} (chunk 2s+4)
         pwn = pwn >= 5 ? pwn - 5 : pwn;
         pan = pan >= 5 ? pan - 5 : pan;
         const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
         load_frags(0, pa, pw, 0);
-        issue2(gb, 0, sw, pwn);
+        if constexpr (ISSUE) issue2(gb, 0, sw, pwn);
         mma8(1);                                            // (s-1, k-step 3); zeros in the first iteration
         sched_kstep();
         load_frags(1, pa, pw, 1);
-        issue2(gb, 2, sw, pwn);
+        if constexpr (ISSUE) issue2(gb, 2, sw, pwn);
         mma8(0);
         sched_kstep();
         load_frags(0, pa, pw, 2);
-        issue2(ga, 0, sa, pan);
+        if constexpr (ISSUE) issue2(ga, 0, sa, pan);
         mma8(1);
         sched_kstep();
         load_frags(1, pa, pw, 3);
-        issue2(ga, 2, sa, pan);
+        if constexpr (ISSUE) issue2(ga, 2, sa, pan);
         mma8(0);
         sched_kstep();
-        const long long tw0 = M324_PROF_T();
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        const long long tw1 = M324_PROF_T();
         M324_BARRIER();
-        const long long tw2 = M324_PROF_T();
-        t_vm += tw1 - tw0;
-        t_bar += tw2 - tw1;
         pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
         pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
-    }
-#ifdef M324_V10_PROF
-    const long long t_loop1 = clock64();
-    if (lane == 0 && (wave == 0 || wave == 5)) {
-        atomicAdd((unsigned long long*)&g_v10_prof[4], (unsigned long long)(wall_clock64() - r_loop0));
-        atomicAdd((unsigned long long*)&g_v10_prof[5], (unsigned long long)(t_loop0 - t_entry));
-        atomicAdd((unsigned long long*)&g_v10_prof[0], (unsigned long long)(t_loop1 - t_loop0));
-        atomicAdd((unsigned long long*)&g_v10_prof[1], (unsigned long long)t_vm);
-        atomicAdd((unsigned long long*)&g_v10_prof[2], (unsigned long long)t_bar);
-        atomicAdd((unsigned long long*)&g_v10_prof[3], 1ull);
-    }
-#endif
+    };
+    stage(0, std::false_type{});
+    for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
     mma8(1);                                                // (NS-1, k-step 3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
 #undef M324_SG
     M324_BARRIER();
     store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
                                       n0 + wn * 64, lane, ep);
-#ifdef M324_V10_PROF
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0 && (wave == 0 || wave == 5)) atomicAdd((unsigned long long*)&g_v10_prof[6], (unsigned long long)(clock64() - t_loop1));
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1046,16 +1013,6 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
 
 }  // namespace
 
-#ifdef M324_V10_PROF
-extern "C" int m324_debug_v10_prof(long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_v10_prof), 64) != hipSuccess) return -1;
-    if (reset) {
-        long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_v10_prof), z, 64) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, float* C, long ldc, int M, int N, int Kc,
                             int slices, long strideC, void* stream) {

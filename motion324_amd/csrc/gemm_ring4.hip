@@ -97,6 +97,41 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
 
     tile_setup(blockIdx.x);
     issue_prologue();
+    {                                                       // first tile: fill the whole ring (W_1, A_2 -> chunks 3, 4)
+        const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
+        issue4(gb, 0, s1, 3); issue4(gb, 4, s1, 3);
+        issue4(ga, 0, s2, 4); issue4(ga, 4, s2, 4);
+    }
+    int pa = 0, pw = 1;
+    auto stage = [&](int s, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        int pwn = pa + 3, pan = pa + 4;
+        pwn = pwn >= 5 ? pwn - 5 : pwn;
+        pan = pan >= 5 ? pan - 5 : pan;
+        const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
+        load_frags(0, pa, pw, 0);
+        if constexpr (ISSUE) issue4(gb, 0, sw, pwn);
+        mma16(1);                                           // (s-1, k-step 3); zeros in the first iteration
+        sched_phase();
+        load_frags(1, pa, pw, 1);
+        if constexpr (ISSUE) issue4(gb, 4, sw, pwn);
+        mma16(0);
+        sched_phase();
+        load_frags(0, pa, pw, 2);
+        if constexpr (ISSUE) issue4(ga, 0, sa, pan);
+        mma16(1);
+        sched_phase();
+        load_frags(1, pa, pw, 3);
+        if constexpr (ISSUE) issue4(ga, 4, sa, pan);
+        mma16(0);
+        sched_phase();
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        M324_BARRIER();
+        pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
+        pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
+    };
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // first tile: stage 0 landed (A_1, W_1, A_2 may fly)
+    M324_BARRIER();
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int mt = m0, nt = n0;                          // this tile's origin (m0 / n0 move on before the epilogue)
 #pragma unroll
@@ -109,39 +144,12 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
                     for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { fa[1][i] = (bf16x8)(0); fb[1][i] = (bf16x8)(0); }
-        // Everything this wave has in flight must be done: the three prologue chunks and, after the first tile, the
-        // epilogue's stores (loads and stores share vmcnt and may retire out of order with respect to each other).
-        // The builtin, not inline asm: hipcc's own wait-count pass must see the drain, or it protects the epilogue's
-        // bias loads against the first fragment read of every K-stage with a vmcnt(0) of its own.
-        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
-        M324_BARRIER();
-        int pa = 0, pw = 1;
-        for (int s = 0; s < NS; ++s) {
-            int pwn = pa + 3, pan = pa + 4;
-            pwn = pwn >= 5 ? pwn - 5 : pwn;
-            pan = pan >= 5 ? pan - 5 : pan;
-            const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
-            load_frags(0, pa, pw, 0);
-            issue4(gb, 0, sw, pwn);
-            mma16(1);                                       // (s-1, k-step 3); zeros in the first iteration
-            sched_phase();
-            load_frags(1, pa, pw, 1);
-            issue4(gb, 4, sw, pwn);
-            mma16(0);
-            sched_phase();
-            load_frags(0, pa, pw, 2);
-            issue4(ga, 0, sa, pan);
-            mma16(1);
-            sched_phase();
-            load_frags(1, pa, pw, 3);
-            issue4(ga, 4, sa, pan);
-            mma16(0);
-            sched_phase();
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            M324_BARRIER();
-            pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
-            pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
-        }
+        pa = 0, pw = 1;
+        // the first tile found the whole ring issued (stage 0 has nothing to add); later tiles had three chunks
+        // prefetched under the previous epilogue, whose scratch occupied chunks 3-4
+        if (t == (int)blockIdx.x) stage(0, std::false_type{});
+        else stage(0, std::true_type{});
+        for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the re-fetched chunks too: the ring is about to be reused
         M324_BARRIER();
         if (t + (int)gridDim.x < ntiles) {                   // next tile's first chunks land under this tile's epilogue
@@ -152,6 +160,14 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
         float* scr = reinterpret_cast<float*>(smem + 3 * CHUNK10) + wave * EP_WAVE_FLOATS;
         store_tile_lds<TOUT, ACT, RES, 4>(acc[0], scr, C, ldc, M, N, mt + wm * 128, nt + wn * 128, lane, ep);
         store_tile_lds<TOUT, ACT, RES, 4>(acc[1], scr, C, ldc, M, N, mt + wm * 128, nt + wn * 128 + 64, lane, ep);
+        if (t + (int)gridDim.x < ntiles) {
+            // Before the next tile starts, everything this wave has in flight must be done: the three prefetched chunks
+            // and the epilogue's stores (loads and stores share vmcnt and may retire out of order with respect to each
+            // other).  The builtin, not inline asm: hipcc's own wait-count pass must see the drain, or it protects the
+            // epilogue's bias loads against the first fragment read of every K-stage with a vmcnt(0) of its own.
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+            M324_BARRIER();
+        }
     }
 #undef M324_SG
 }
@@ -245,37 +261,42 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
         M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 2);
     };
 
+    // prologue: the whole ring (stages 0, 1, 2); stage 0 then has nothing to issue and is peeled
     issue3(0, 0, 0); issue3(3, 0, 0); issue3(6, 0, 0); issue3(9, 0, 0);
     {
-        const int s1 = NS > 1 ? 1 : 0;
+        const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
         issue3(0, s1, 1); issue3(3, s1, 1); issue3(6, s1, 1); issue3(9, s1, 1);
+        issue3(0, s2, 2); issue3(3, s2, 2); issue3(6, s2, 2); issue3(9, s2, 2);
     }
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (stage 1 may fly)
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // stage 0 landed (stages 1, 2 may fly)
     M324_BARRIER();
     int slot = 0;                                           // s % 3
-    for (int s = 0; s < NS; ++s) {
+    auto stage = [&](int s, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
         const int fslot = slot == 0 ? 2 : slot - 1;         // (s + 2) % 3 == (s - 1) % 3
         const int sn = s + 2 < NS ? s + 2 : NS - 1;
         load_frags(0, slot, 0);
-        issue3(0, sn, fslot);
+        if constexpr (ISSUE) issue3(0, sn, fslot);
         mma8(1);                                            // (s-1, k-step 3); zeros in the first iteration
         sched_phase();
         load_frags(1, slot, 1);
-        issue3(3, sn, fslot);
+        if constexpr (ISSUE) issue3(3, sn, fslot);
         mma8(0);
         sched_phase();
         load_frags(0, slot, 2);
-        issue3(6, sn, fslot);
+        if constexpr (ISSUE) issue3(6, sn, fslot);
         mma8(1);
         sched_phase();
         load_frags(1, slot, 3);
-        issue3(9, sn, fslot);
+        if constexpr (ISSUE) issue3(9, sn, fslot);
         mma8(0);
         sched_phase();
         asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         M324_BARRIER();
         slot = slot == 2 ? 0 : slot + 1;
-    }
+    };
+    stage(0, std::false_type{});
+    for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
     mma8(1);                                                // (NS-1, k-step 3)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
 #undef M324_SG

@@ -58,8 +58,6 @@ int main(int argc, char** argv) {
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", libp.c_str(), dlerror()); return 2; }
     auto gemm = (int (*)(const m324_gemm_args*, void*))dlsym(h, "m324_gemm");
     auto lasterr = (int (*)(char*, int))dlsym(h, "m324_last_error");
-    auto prof = (int (*)(long long*, int))dlsym(h, "m324_debug_v10_prof");   // lab builds of the library only
-    auto prof11 = (int (*)(long long*, int))dlsym(h, "m324_debug_v11_prof");
 
     const Shape shapes[] = {
         {"trunk qkv", 10368, 2304, 768, 0},   {"trunk fc+res", 10368, 768, 768, 2},  {"trunk fc1 gelu", 10368, 3072, 768, 1},
@@ -178,24 +176,6 @@ int main(int argc, char** argv) {
             printf(" v%d %7.1f us %6.0f TF/s (avg %6.1f, err %.3g) |", variants[vi], best[vi],
                    2.0 * s.M * s.N * s.K / best[vi] / 1e6, sum[vi] / 3, err[vi]);
         printf("\n");
-        if (prof) {
-            long long q[8];
-            HIP_OK(hipDeviceSynchronize());
-            if (prof(q, 1) == 0 && q[3] > 0)
-                printf("    v10 per sampled wave: main loop %.0f ticks = %.1f us (%.0f MHz), of which %.1f %% in s_waitcnt vmcnt, %.1f %% in "
-                       "s_barrier; prologue %.0f ticks, epilogue %.0f ticks\n",
-                       (double)q[0] / q[3], (double)q[4] / q[3] / 100.0, (double)q[0] / q[4] * 100.0, 100.0 * q[1] / q[0],
-                       100.0 * q[2] / q[0], (double)q[5] / q[3], (double)q[6] / q[3]);
-        }
-        if (prof11) {
-            long long q[8];
-            HIP_OK(hipDeviceSynchronize());
-            if (prof11(q, 1) == 0 && q[3] > 0)
-                printf("    v11 per sampled wave: main loop %.0f ticks = %.1f us (%.0f MHz; %.0f ticks per K-stage, MFMA needs 2048); "
-                       "prologue %.0f ticks, epilogue %.0f ticks\n",
-                       (double)q[0] / q[3], (double)q[4] / q[3] / 100.0, (double)q[0] / q[4] * 100.0,
-                       (double)q[0] / q[3] / (s.K / 64), (double)q[5] / q[3], (double)q[6] / q[3]);
-        }
         fflush(stdout);
         hipFree(dA); hipFree(dW); hipFree(dC); hipFree(dRef); hipFree(db);
         if (dR0) hipFree(dR0);
