@@ -563,6 +563,132 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// v13: v2's 128 x 128 tile (two workgroups per CU) on v10's pipeline.  v2 double-buffers whole K-tiles behind one
+// vmcnt(0) + barrier per tile: the texture path, which bounds these tiles (64 KiB of LDS-DMA per 4.2 MFLOP), idles while
+// the workgroup drains and starts cold again after every barrier.  Here the 80 KiB a workgroup may use are a ring of
+// FIVE 16-KiB chunks (one operand's 128 rows x 64 k of one K-stage; chunk 2s = A of stage s, 2s+1 = W of stage s), so
+// 2.5 stages are resident, pieces are issued between the MFMAs of every k-step, the wait is a counted vmcnt(4), the
+// MFMA work is rotated one k-step against the LDS stages and the prologue fills the whole ring -- exactly v10 with a
+// 2 x 2 accumulator block per wave (a phase is 4 MFMAs, 4 fragment reads and 2 LDS-DMA pieces).
+constexpr int CHUNK13 = 128 * ROWB;               // 16 KiB
+
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                            long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
+                                                            int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * CHUNK13];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int lid = blockIdx.x;
+    if (xcd_remap & 1) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+
+    // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
+        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
+    }
+    auto issue2 = [&](const bf16_t* const (&g)[4], int i0, int st, int pos) {
+        unsigned char* d = smem + pos * CHUNK13 + wave * 4096 + i0 * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i0 + i] + (long)st * 64), (lds_ptr_t*)(d + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int NS = K / 64;
+    const int aoff = lds_off(wm * 64 + l31, hi), boff = lds_off(wn * 64 + l31, hi);
+    bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { fa[1][i] = (bf16x8)(0); fb[1][i] = (bf16x8)(0); }
+    auto load_frags = [&](int set, int pa, int pw, int ks) {
+        const unsigned char* ba = smem + pa * CHUNK13;
+        const unsigned char* bw = smem + pw * CHUNK13;
+        const int x = ks << 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(bw + ((boff + j * 4096) ^ x));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(ba + ((aoff + i * 4096) ^ x));
+    };
+    auto mma4 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+    };
+#define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    auto sched_phase = [&]() {                               // M r M r M r r M G G
+        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
+        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 2);
+    };
+
+    {
+        const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
+        issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
+        issue2(gb, 0, 0, 1); issue2(gb, 2, 0, 1);
+        issue2(ga, 0, s1, 2); issue2(ga, 2, s1, 2);
+        issue2(gb, 0, s1, 3); issue2(gb, 2, s1, 3);
+        issue2(ga, 0, s2, 4); issue2(ga, 2, s2, 4);
+    }
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (A_1, W_1, A_2 may fly)
+    M324_BARRIER();
+    int pa = 0, pw = 1;
+    auto stage = [&](int s, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        int pwn = pa + 3, pan = pa + 4;
+        pwn = pwn >= 5 ? pwn - 5 : pwn;
+        pan = pan >= 5 ? pan - 5 : pan;
+        const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
+        load_frags(0, pa, pw, 0);
+        if constexpr (ISSUE) issue2(gb, 0, sw, pwn);
+        mma4(1);                                            // (s-1, k-step 3); zeros in the first iteration
+        sched_phase();
+        load_frags(1, pa, pw, 1);
+        if constexpr (ISSUE) issue2(gb, 2, sw, pwn);
+        mma4(0);
+        sched_phase();
+        load_frags(0, pa, pw, 2);
+        if constexpr (ISSUE) issue2(ga, 0, sa, pan);
+        mma4(1);
+        sched_phase();
+        load_frags(1, pa, pw, 3);
+        if constexpr (ISSUE) issue2(ga, 2, sa, pan);
+        mma4(0);
+        sched_phase();
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        M324_BARRIER();
+        pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
+        pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
+    };
+    stage(0, std::false_type{});
+    for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
+    mma4(1);                                                // (NS-1, k-step 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
+#undef M324_SG
+    M324_BARRIER();
+    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 64,
+                                      n0 + wn * 64, lane, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
 // v9: skinny GEMM for M <= 64 (the 64 latent tokens of the shape encoder: every projection of the 4 point-transformer
 // blocks and of the encoder cross-attention at B = 1).  A 128 x 128 tile kernel runs these on N / 128 = 6..24 CUs with the
 // whole K loop serial (17-48 us for 0.1-0.3 GFLOP).  Here a workgroup owns 32 output columns, its 8 waves split K in
@@ -903,7 +1029,7 @@ static int xcd_remap() {
     return v;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11|v12 forces a variant (A/B measurements, tests).
+// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11|v12|v13 forces a variant (A/B measurements, tests).
 static int forced_variant() {      // read per call: lets one process A/B-toggle the variant
     const char* e = getenv("M324_GEMM");
     return (e && e[0] == 'v') ? atoi(e + 1) : 0;
@@ -916,7 +1042,7 @@ static int pick_variant(const m324_gemm_args* a) {
     const bool ring_ok = bf16 && a->K % 64 == 0 && a->K >= 128;      // v10 / v11: K-stages of 64, at least two
     if (f == 1 || f == 2 || f == 5) return f;
     if (f == 7) return bf16 ? 7 : 5;
-    if (f == 10 || f == 11 || f == 12) return ring_ok ? f : (bf16 ? 7 : 5);
+    if (f >= 10 && f <= 13) return ring_ok ? f : (bf16 ? (f == 13 ? 2 : 7) : (f == 13 ? 2 : 5));
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
@@ -937,6 +1063,10 @@ static int pick_variant(const m324_gemm_args* a) {
     const long t12 = (long)ceil_div(a->N, 128) * ceil_div(a->M, 256);
     const double e12 = (double)t12 / (double)(((t12 + 255) / 256) * 256);
     if (ring_ok && a->K >= 1024 && t12 >= 180 && e12 >= 0.70) return 12;
+    // 128 x 128 tiles: the chunk-ring pipeline (v13) for the fp32 residual outputs at K = 768 (22.3 -> 21.4 us,
+    // 20.2 -> 19.1 us; 10.35 -> 10.31 ms per clip).  The fused q|k|v epilogues stay on v2: v13 wins them in isolation
+    // (43.6 -> 42.3 us) but the clip got 0.9 % slower with it.
+    if (ring_ok && a->out_dtype == M324_F32 && !a->aux_mode) return 13;
     return 2;
 }
 
@@ -944,6 +1074,12 @@ template <typename TOUT, int ACT, int RES>
 static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
     if (variant == 11 || variant == 12) {
         m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap(), variant);
+        return;
+    }
+    if (variant == 13) {
+        hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN) * ceil_div(a->M, BM)), dim3(256), 0, s,
+                           (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
+                           ceil_div(a->N, BN), xcd_remap());
         return;
     }
     if (variant == 10) {

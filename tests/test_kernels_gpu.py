@@ -97,13 +97,13 @@ def test_gemm_inplace_residual(dtype):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
-@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v7", "v10", "v11", "v12"])
+@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v7", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("K", [64, 192, 832])
 def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
     """M324_GEMM=vN (read per call) forces one kernel schedule; each must handle ragged M / N tiles, a K shorter than
-    its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v7 / v10 / v11 / v12 to v5;
-    the chunk-ring kernels v10 / v11 / v12 need two K-stages of 64 and hand K = 64 to v7.)"""
+    its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v7 / v10 / v11 / v12 to v5, v13 to v2;
+    the chunk-ring kernels v10 - v13 need two K-stages of 64 and hand K = 64 to v7.)"""
     ops = _ops()
     from motion324_amd.lib import ACT_GELU
     monkeypatch.setenv("M324_GEMM", variant)
@@ -135,7 +135,7 @@ def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
-@pytest.mark.parametrize("variant", ["v10", "v11", "v12"])
+@pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13"])
 def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
     """The chunk-ring kernels on a grid with more tiles than CUs (20 x 16 = 320 tiles of 256 x 256, ragged last row of
     tiles): the persistent v11 walks 1-2 tiles per workgroup with the next tile's first chunks prefetched under the
@@ -165,7 +165,7 @@ def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
 
 
 @pytest.mark.parametrize("variant,M,N,K", [("v10", 8192, 3072, 768), ("v11", 8192, 3072, 768), ("v12", 10368, 768, 3072),
-                                            ("v7", 8192, 3072, 768)])
+                                            ("v7", 8192, 3072, 768), ("v13", 10368, 768, 768)])
 def test_gemm_ring_kernels_are_race_free(monkeypatch, variant, M, N, K):
     """The LDS-DMA rings state their own vmcnt waits (tests/test_static.py audits them); a missing one shows up as a tile
     read before it landed -- rarely, and only when the chip is full.  Forty launches at the model's shapes must give
@@ -304,7 +304,7 @@ def test_gemm_qkv_heads_epilogue(B, L, H, norm, bias):
     assert rel_err(out_f.float(), ref_o) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [None, "v2", "v7", "v10", "v11"])
+@pytest.mark.parametrize("variant", [None, "v2", "v7", "v10", "v11", "v13"])
 def test_gemm_qkv_heads_transposed_v_epilogue(monkeypatch, variant):
     """M324_AUX_QKV_HEADS_VT: as the head-major epilogue, but V leaves as the transposed, key-permuted Vt the default
     attention kernel reads.  Vt must equal m324_gemm + m324_qkv_split bit for bit (both round acc + bias to bf16 once);
