@@ -164,6 +164,27 @@ def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
     assert torch.equal(x, x2)
 
 
+@pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("M,N,K", [(65, 8, 128), (37, 200, 128), (300, 136, 192), (513, 260, 128), (256, 256, 128), (257, 132, 320)])
+def test_gemm_ring_edge_shapes(monkeypatch, variant, M, N, K):
+    """The chunk-ring kernels at their smallest legal depth (K = 128: two K-stages, the peeled stage 0 plus one loop
+    iteration whose look-ahead is clamped back onto the last stage), with fewer rows / columns than one tile, one row or
+    column past a tile edge, and N as small as 8: plain bf16 output and the in-place fp32 residual stream."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    monkeypatch.setenv("M324_GEMM", variant)
+    a, w = _q(_rand((M, K), 51), dtype), _q(_rand((N, K), 52, 0.1), dtype)
+    ref = a.double() @ w.double().T
+    ad, wd = a.to(dtype).to(DEV), w.to(dtype).to(DEV)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(ad, wd, out)
+    assert rel_err(out.float(), ref) < TOL[dtype]
+    x0 = _rand((M, N), 53)
+    x = x0.clone().to(DEV)
+    ops.gemm(ad, wd, x, residual=x)
+    assert rel_err(x, x0.double() + ref) < 1e-5
+
+
 @pytest.mark.parametrize("variant,M,N,K", [("v10", 8192, 3072, 768), ("v11", 8192, 3072, 768), ("v12", 10368, 768, 3072),
                                             ("v7", 8192, 3072, 768), ("v13", 10368, 768, 768)])
 def test_gemm_ring_kernels_are_race_free(monkeypatch, variant, M, N, K):
