@@ -56,13 +56,23 @@ template <bool PRESCALED, int NQ, int NWV, bool VROW = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
-                                                        int Lkp, float scale_log2e, float* __restrict__ lse) {
+                                                        int Lkp, float scale_log2e, float* __restrict__ lse, int nqt) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * ASTAGE];   // [stage][K | Vt]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = (blockIdx.x * NWV + wave) * (QW * NQ);
+    int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    if (nqt > 0) {
+        // flat grid (long sequences): workgroup i runs on XCD i % 8; give every XCD a contiguous range of the
+        // (batch, head, query tile) list, i.e. whole heads, so the ~20 workgroups that walk one head's K / V in step
+        // share its tiles in ONE L2 instead of five workgroups in each of the eight
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = qt & 7, loc = qt >> 3;
+        const int lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+        qt = lid % nqt;
+        h = (lid / nqt) % H;
+        b = lid / (nqt * H);
+    }
+    const int q0 = (qt * NWV + wave) * (QW * NQ);
 
     const bf16_t* Qh = Q + (long)b * q_bstride + (long)h * Lq * 64;
     const bf16_t* Kh = K + ((long)b * H + h) * (long)Lk * 64;
@@ -688,6 +698,15 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         const char* fnw = getenv("M324_ATTN_NW");
         const bool w8 = !nq2 && (fnw ? atoi(fnw) == 8 : (Lq >= 2048 && Lk >= 512));
         dim3 g2(ceil_div(Lq, nq2 ? 2 * QB : (w8 ? 2 * QB : QB)), H, B);
+        // XCD-aware flat grid for the 8-wave kernel (M324_ATTN_FLAT=0 keeps the 3-D grid: A/B runs)
+        int nqt = 0;
+        {
+            const char* ff = getenv("M324_ATTN_FLAT");
+            if (w8 && !(ff && atoi(ff) == 0)) {
+                nqt = (int)g2.x;
+                g2 = dim3(g2.x * H * B, 1, 1);
+            }
+        }
         // Co-residency: the NQ = 1 kernel fits 3 workgroups per CU (168 VGPRs, 32 KiB LDS).  Interleaved A/B on
         // MI355X: 3 per CU beats 2 per CU (422 vs 453 us on the 10 368-token global attention) even though the
         // grid then ends in a partly filled round -- latency hiding wins over round quantisation.
@@ -696,10 +715,10 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         const unsigned pad = (focc && atoi(focc) == 2) ? 24 * 1024 : 0;
 #define M324_ATTN(PS, NQ, NWV)                                                                                          \
     hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ, NWV>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,         \
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse)
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt)
 #define M324_ATTN_VR(PS, NWV)                                                                                            \
     hipLaunchKernelGGL((attn_bf16_kernel<PS, 1, NWV, true>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,    \
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse)
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt)
         if (vrow) {
             if (q_prescaled) { if (w8) M324_ATTN_VR(true, 8); else M324_ATTN_VR(true, 4); }
             else { if (w8) M324_ATTN_VR(false, 8); else M324_ATTN_VR(false, 4); }
