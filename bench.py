@@ -125,7 +125,7 @@ def main():
     fast = None if args.eager else m.GraphedForward(model)
     # --clips-in-flight 2: a second graph with its own static buffers on a second stream; step i runs on stream i % 2
     lanes = [(torch.cuda.current_stream(), fast)]
-    if args.clips_in_flight == 2 and fast is not None:
+    if args.clips_in_flight == 2 and fast is not None and world == 1:     # N > 1: one communicator, one stream of collectives
         lanes = [(torch.cuda.Stream(), fast), (torch.cuda.Stream(), m.GraphedForward(model))]
     step_no = [0]
 
