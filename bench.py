@@ -2,13 +2,21 @@
 """Headline benchmark: frames/sec of Motion_Latent_Model.forward on the BASELINE.json clip
 (32 frames x 2048 mesh points x 512x512 video, 4096 surface samples, batch 1, bf16) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode infer|train|frame-parallel]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One "step" = one forward of the hot path over one 32-frame clip per GPU, inputs resident in HBM.
-Multi-GPU: clips are independent: every rank runs its own clip with no collective
-inside the forward; the per-clip [T,N,3] offsets are all-gathered at the end of each step.  Weak scaling.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run ...`, launched before this process touches the GPU) and returns its exit code.
+
+Modes (BASELINE.json `configs`):
+  infer (default, configs[1], c2): one "step" = one forward of the hot path over one 32-frame clip per GPU, inputs resident
+      in HBM, hipGraph replay.  Clips are independent: no collective inside the forward, the per-clip
+      [T,N,3] offsets are all-gathered at the end of each step.  Weak scaling.  THE headline line.
+  train (configs[2] / [3], c3 / c4): one step = forward + hand-written backward + bucketed gradient all-reduce (overlapped
+      with the backward) + fused AdamW on dyscene.yaml shapes (12 frames, 4096 points, 224x224), --batch per GPU (8 / 32).
+  frame-parallel (configs[4], c5): one 256-frame clip, frames sharded over the ranks with exact single-GPU semantics
+      (K/V all-gather per global block).  Strong scaling; at N = 1 the whole clip runs on one GPU.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 from __future__ import annotations
@@ -16,6 +24,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,13 +37,14 @@ sys.path.insert(0, REPO)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PROFILE_ROUND = "r02"          # profiles/<round>_* hold the rocprofv3 summaries the roofline rows are checked against
 
 WORKLOAD = dict(B=1, T=32, N=2048, S=4096, HW=512, frames=32)   # BASELINE.json configs[1]
 
 
 def algorithmic_flops(B, T, N, S, d=768, K=64, g=16, n_layer=16, pcd_layers=4, dino_depth=12):
     """Forward FLOPs (2*MAC) of the reference's arithmetic, SURVEY.md 8(d) (incl. its per-frame recompute
-    of the decoder point features): 7.527 TFLOP for the c2 clip."""
+    of the decoder point features): 7.527 TFLOP for the c2 clip, 208.0 for the 256-frame clip."""
     lin = lambda m, i, o: 2.0 * m * i * o
     att = lambda b, q, k: 4.0 * b * (d // 64) * q * k * 64
     blk = lambda m: lin(m, d, 3 * d) + lin(m, d, d) + 2 * lin(m, d, 4 * d)
@@ -50,72 +61,236 @@ def algorithmic_flops(B, T, N, S, d=768, K=64, g=16, n_layer=16, pcd_layers=4, d
     return f
 
 
-def build_model(device, frames):
+def build_model(device, frames, train=False):
     import motion324_amd as m
     from motion324_amd import synth
     cfg = synth.make_config(frames=frames)
     model = m.Motion_Latent_Model(cfg)
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.Dims(frames=frames), seed=0).items()}
     model.load_state_dict(sd, strict=False)
-    return model.eval().to(device), sd
+    model = (model.train() if train else model.eval()).to(device)
+    return model, sd
 
 
-def cpu_baseline(sd, sample_np, frames):
-    """The CPU oracle (fp32 restatement of the reference path) timed on this host: ONE forward of the
-    same 32-frame clip, all cores, no warm-up (about 10-30 s of CPU work)."""
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_identity():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(sd, sample_np, frames, budget_s=45.0):
+    """The CPU oracle (fp32 restatement of the reference path, BASELINE.md section 3 protocol) timed on this host's cores:
+    thread count chosen by a measured sweep on a 4-frame sub-clip (torch's CPU kernels stop scaling, then collapse, far
+    below a 256-thread host -- the sweep is reported), then 1 warm-up (the sub-clip) + median of up to 3 forwards of
+    the full 32-frame clip, bounded by `budget_s` of CPU work."""
     from oracle import ref_forward as oracle
-    # torch's CPU kernels stop scaling (and then collapse) far below a 256-thread host: 32 threads is
-    # the measured sweet spot of this workload's GEMM / attention sizes; `cores` reports what was used
-    threads = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(threads)
+    cpu_model, physical, logical = _cpu_identity()
     sample = oracle.to_torch(sample_np)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        out = oracle.forward(sd, sample, frames=frames)["pcd_moved"]
-    dt = time.perf_counter() - t0
     T = sample["rgb_video"].shape[1]
-    return {"value": round(T / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 forward of the full {T}-frame clip (fp32, torch CPU ops, {threads} threads, no warm-up), {dt:.1f} s"}, out
+    sub = dict(sample)
+    sub["rgb_video"] = sample["rgb_video"][:, :4]
+    cands = sorted({c for c in (8, 16, 32, 64, physical) if 1 <= c <= logical})
+    sweep = {}
+    with torch.no_grad():
+        for c in cands:
+            torch.set_num_threads(c)
+            oracle.forward(sd, sub, frames=frames)                        # warm-up at this thread count
+            t0 = time.perf_counter()
+            oracle.forward(sd, sub, frames=frames)
+            sweep[c] = time.perf_counter() - t0
+            if sweep[c] > 3.0 * min(sweep.values()):
+                break                                                       # collapsing: stop climbing
+        threads = min(sweep, key=sweep.get)
+        torch.set_num_threads(threads)
+        times, out = [], None
+        spent = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = oracle.forward(sd, sample, frames=frames)["pcd_moved"]
+            dt = time.perf_counter() - t0
+            times.append(dt)
+            spent += dt
+            if spent + dt > budget_s:
+                break
+    med = sorted(times)[len(times) // 2]
+    sweep_s = ", ".join(f"{c}t {v * 1e3:.0f} ms" for c, v in sweep.items())
+    return {"value": round(T / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model, "physical_cores": physical, "logical_cpus": logical,
+            "sample": f"median of {len(times)} forwards of the full {T}-frame clip after a warm-up (fp32 oracle, torch CPU ops, "
+                      f"{threads} threads of {physical} physical cores; 4-frame thread sweep: {sweep_s}); {med:.1f} s per clip"}, out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="time eager per-kernel launches instead of hipGraph replay")
-    ap.add_argument("--clips-in-flight", type=int, default=1, choices=[1, 2],
-                    help="2: consecutive steps alternate between two HIP streams / graphs, so one clip's kernels fill the "
-                         "partly filled last round of the other's (throughput mode; the default 1 is one clip at a time)")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------- launch plumbing
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # M324_BENCH_BACKEND=gloo runs the N > 1 control flow with several ranks on ONE device (rehearsal of the launch line on a
-    # single-GPU box; the numbers mean nothing): the driver's real runs use RCCL ("nccl"), one rank per GPU
-    backend = os.environ.get("M324_BENCH_BACKEND", "nccl")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to benchmark")
-    if backend != "nccl":
-        local %= torch.cuda.device_count()
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
 
+def maybe_spawn(args) -> None:
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a CHILD process tree (never an exec: this
+    process may not have touched the GPU yet, and stays that way) and exit with the child's code."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+class Dist:
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={self.world} ranks")
+        # M324_BENCH_BACKEND=gloo runs the N > 1 control flow with several ranks on ONE device (rehearsal of the launch
+        # line on a single-GPU box; the numbers mean nothing): the driver's real runs use RCCL ("nccl"), one rank per GPU
+        self.backend = os.environ.get("M324_BENCH_BACKEND", "nccl")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path to benchmark")
+        if self.backend != "nccl":
+            self.local %= torch.cuda.device_count()
+        elif self.world > torch.cuda.device_count():
+            raise SystemExit(f"bench.py: {self.world} ranks but only {torch.cuda.device_count()} GPUs are visible")
+        self.dev = torch.device("cuda", self.local)
+        torch.cuda.set_device(self.dev)
+        self.comm_ranks = 1
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+            # what the communicator itself reports: one all-reduce of ones over RCCL must give N
+            ones = torch.ones(1, device=self.dev)
+            dist.all_reduce(ones)
+            self.comm_ranks = int(ones.item())
+            if self.comm_ranks != args.gpus or dist.get_world_size() != args.gpus:
+                raise SystemExit(f"bench.py: communicator has {self.comm_ranks} ranks, expected {args.gpus}")
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt: float) -> float:
+        if self.world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            torch.distributed.destroy_process_group()
+
+
+def timed(dist_: Dist, step, steps: int):
+    """EXACTLY `steps` calls of step() between two fences; returns (wall seconds max over ranks, host enqueue seconds)."""
+    dist_.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    t_enq = time.perf_counter() - t0
+    dist_.fence()
+    return dist_.max_over_ranks(time.perf_counter() - t0), t_enq
+
+
+def sustained(dist_: Dist, step, seconds: float):
+    """>= `seconds` of back-to-back steps (clock / power throttling shows up here, not in a 0.2 s timed region)."""
+    if seconds <= 0:
+        return None
+    dist_.fence()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(32):
+            step()
+        n += 32
+        torch.cuda.synchronize()              # bound the host's run-ahead so that the loop ends near `seconds`
+        stop = time.perf_counter() - t0 >= seconds
+        if dist_.world > 1:                   # every rank must leave after the same step (the step holds a collective)
+            flag = torch.tensor([1.0 if stop else 0.0], device=dist_.dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            stop = float(flag.item()) > 0
+        if stop:
+            break
+    dist_.fence()
+    dt = dist_.max_over_ranks(time.perf_counter() - t0)
+    return n, dt
+
+
+# ----------------------------------------------------------------------------------------------- roofline rows
+def roofline_rows(rec, steps: int):
+    """Per-symbol rows from the HIP-event recorder: (kernel template + grid) -> launches, avg us, algorithmic FLOP / bytes
+    per launch, fraction of the dense peak.  The same symbols appear in profiles/<round>_*_kernel_stats.md."""
+    rows = {}
+    for (cls, tag), v in rec.by_tag().items():
+        sym = tag.split(" | ")[0] if " | " in tag else cls
+        shape = tag.split(" | ")[1] if " | " in tag else tag
+        r = rows.setdefault((cls, sym), {"class": cls, "symbol": sym, "launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0,
+                                         "shapes": set()})
+        r["launches"] += v["launches"]
+        r["total_ms"] += v["total_ms"]
+        r["flops"] += v["flops"]
+        r["bytes"] += v.get("bytes", 0.0)
+        r["shapes"].add(shape.split(" bias")[0].split(" gelu")[0].split(" res")[0].split(" out=")[0].split(" qkv")[0])
+    out = []
+    for r in rows.values():
+        peak = PEAK_BF16_TFLOPS if r["class"].endswith("bf16") else PEAK_F32_TFLOPS
+        tf = r["flops"] / max(r["total_ms"], 1e-9) / 1e9
+        out.append({"symbol": r["symbol"], "shapes": sorted(r["shapes"]), "launches_per_step": r["launches"] // steps,
+                    "avg_us": round(r["total_ms"] / r["launches"] * 1e3, 2), "ms_per_step": round(r["total_ms"] / steps, 3),
+                    "gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 2),
+                    "mbytes_per_launch": round(r["bytes"] / r["launches"] / 1e6, 2),
+                    "tflops": round(tf, 1), "frac": round(tf / peak, 4)})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def committed_traffic(symbol: str):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes (counters cannot be read in-process):
+    profiles/<round>_traffic.json, written by tools/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE passes."""
+    for rnd in (PROFILE_ROUND, "r01"):
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", f"{rnd}_traffic.json")))
+        except (OSError, ValueError):
+            continue
+        key = symbol.split(" grid=")[0]
+        for k, v in tj.items():
+            if k == symbol or k == key or k.split(" grid=")[0] == key:
+                return v.get("traffic_bytes_per_launch"), f"profiles/{rnd}_traffic.json"
+    return None, None
+
+
+# ----------------------------------------------------------------------------------------------- modes
+def run_infer(args, D: Dist):
     import motion324_amd as m
-    from motion324_amd import synth
+    from motion324_amd import parallel, synth
     from motion324_amd.timing import Recorder
     w = WORKLOAD
+    world, rank, dev = D.world, D.rank, D.dev
     model, sd = build_model(dev, w["frames"])
     # every rank works on its own clip: same shape, different seed
     sample_np = synth.synth_inputs(w["B"], w["T"], w["N"], w["S"], w["HW"], seed=1 + rank)
@@ -128,6 +303,14 @@ def main():
     if args.clips_in_flight == 2 and fast is not None and world == 1:     # N > 1: one communicator, one stream of collectives
         lanes = [(torch.cuda.Stream(), fast), (torch.cuda.Stream(), m.GraphedForward(model))]
     step_no = [0]
+    gathered = [None]
+    last = [None]
+
+    def gather(out):
+        if world > 1:
+            if gathered[0] is None:
+                gathered[0] = torch.empty((world,) + tuple(out.shape), dtype=out.dtype, device=dev)
+            parallel.all_gather_into(gathered[0], out.contiguous())
 
     def step(eager=False):
         stream, fwd = lanes[step_no[0] % len(lanes)]
@@ -135,70 +318,50 @@ def main():
         with torch.no_grad():
             if eager or fast is None:
                 out = model(sample).pcd_moved
+                gather(out)
             else:
                 with torch.cuda.stream(stream):
                     out = fwd(sample).pcd_moved
-                    if world > 1:
-                        gathered = [torch.empty_like(out) for _ in range(world)]
-                        torch.distributed.all_gather(gathered, out)
-                return out
-        if world > 1:
-            gathered = [torch.empty_like(out) for _ in range(world)]
-            torch.distributed.all_gather(gathered, out)
+                    gather(out)
+        last[0] = out
         return out
 
     for _ in range(args.warmup):
         step()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    t_enq = time.perf_counter() - t0          # host time to enqueue all steps (diagnostic)
-    fence()
-    dt = time.perf_counter() - t0
+    dt, t_enq = timed(D, step, args.steps)
+    out = last[0]
+    sus = sustained(D, step, args.sustain)
     # per-kernel HIP-event timing (roofline object): the same K steps again, launched eagerly on the same
     # stream with an event pair around every GEMM / attention launch (events cannot sit inside a graph)
     rec = Recorder()
     with rec:
         for _ in range(args.steps):
             step(eager=True)
-    fence()
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+    D.fence()
 
+    line = None
     if rank == 0:
         frames_per_step = world * w["B"] * w["T"]
         ms = dt / args.steps * 1e3
         value = frames_per_step * args.steps / dt
         summ = rec.summary()
         stages = {k: summ.pop(k) for k in list(summ) if k.startswith("stage:")}
-        dom = max(summ, key=lambda k: summ[k]["total_ms"])
-        d = summ[dom]
-        peak = PEAK_BF16_TFLOPS if dom.endswith("bf16") else PEAK_F32_TFLOPS
-        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel class: PMC counters cannot be read in-process, so the figure comes
-        # from the committed rocprofv3 passes (profiles/r01_traffic.json; see tools/pmc.sh, tools/pmc_traffic.py)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
-            traffic = tj.get(dom, {}).get("traffic_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
-                "launches_per_step": d["launches"] // args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
-                "by_kernel": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 3),
-                                  "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
+        rows = [r for r in roofline_rows(rec, args.steps) if not r["symbol"].startswith("stage:")]
+        dom = rows[0]                                  # dominant SYMBOL (kernel template + grid) by time per step
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        traffic, traffic_src = committed_traffic(dom["symbol"])
+        roof = {"bound": "mfma", "kernel": dom["symbol"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
+                "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
+                "algorithmic_mbytes_per_launch": dom["mbytes_per_launch"],
+                "timing": "HIP events around every launch of an eager pass on the launch stream; the same symbols are in "
+                          f"profiles/{PROFILE_ROUND}_*_kernel_stats.md (rocprofv3 --kernel-trace --stats of this command)",
+                "by_symbol": rows[:14],
+                "class_totals": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 3),
+                                     "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1),
+                                     "frac": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12 / peak, 4)}
+                                 for k, v in summ.items()}}
         flops = algorithmic_flops(w["B"], w["T"], w["N"], w["S"])
         line = {
             "metric": "frames/sec (32-frame clip, 2048 pts, 512x512)", "value": round(value, 2), "unit": "frames/s",
@@ -206,13 +369,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "Motion_Latent_Model.forward inference, B=1 x 32 frames x 2048 points x 512x512 video, "
-                                   "4096 surface samples, training.frames=32, random-init weights (one clip per GPU)",
+                                   "4096 surface samples, training.frames=32, random-init weights (one clip per GPU; BASELINE configs[1])",
                        "parallelism": f"clip-parallel x{world}"},
-            "launch": "eager" if fast is None else "hipGraph replay", "clips_in_flight": len(lanes), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+            "launch": "eager" if fast is None else "hipGraph replay", "clips_in_flight": len(lanes),
+            "comm_ranks": D.comm_ranks, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             "end_to_end_tflops": round(flops * world * args.steps / dt / 1e12, 1),
             "end_to_end_frac_of_bf16_peak": round(flops * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roof,
         }
+        if sus is not None:
+            n, sdt = sus
+            line["sustained"] = {"seconds": round(sdt, 2), "steps": n, "value": round(frames_per_step * n / sdt, 2),
+                                 "unit": "frames/s", "ms_per_step": round(sdt / n * 1e3, 3)}
         blk = stages.get("stage:decoder_cross_attn_block")
         if blk:        # north_star target: >= 40 % of the dense bf16 MFMA peak on this block (reference FLOP count)
             bms = blk["total_ms"] / args.steps
@@ -227,9 +395,125 @@ def main():
             line["rel_err_vs_cpu_oracle"] = round(err, 6)
         else:
             line["cpu_baseline"] = None
+    return line
+
+
+def run_train(args, D: Dist):
+    """BASELINE configs[2] (c3, --batch 8, N = 1) and configs[3] (c4, --batch 32, N = 8): dyscene.yaml shapes."""
+    import motion324_amd as m
+    from motion324_amd import synth, training
+    from motion324_amd.optim import FusedAdamW, backward_completion_order, cosine_with_warmup
+    world, rank, dev = D.world, D.rank, D.dev
+    T, N, HW = 12, 4096, 224                      # configs/dyscene.yaml: frames, num_pcd_samples = num_shape_samples, image size
+    model, _ = build_model(dev, T, train=True)
+    s = synth.synth_inputs(args.batch, T, N, N, HW, seed=1 + rank, with_target=True)
+    sample = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+    opt = FusedAdamW(model.named_parameters(), lr=4e-4, betas=(0.9, 0.95), weight_decay=0.05, grad_clip_norm=1.0,
+                     allowed_gradnorm_factor=5.0, order=backward_completion_order(model))
+    m.set_precision(args.precision)
+    losses, infos = [], []
+    it = [0]
+
+    def step():
+        loss, _, G = training.forward_backward(model, sample, sink=opt)       # buckets leave during the backward
+        opt.finish_reduce()
+        info = opt.step(lr=cosine_with_warmup(it[0], 1000, 30000, 4e-4) or 4e-7)
+        it[0] += 1
+        losses.append(loss)
+        infos.append(info)
+
+    for _ in range(args.warmup):
+        step()
+    dt, _ = timed(D, step, args.steps)
+    line = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        # forward FLOPs of the step (reference count); training ~ 3 x trainable forward + recompute + 1 x DINO forward
+        fwd = algorithmic_flops(args.batch, T, N, N)
+        line = {"metric": f"training samples/sec (dyscene.yaml shapes, batch_size_per_gpu={args.batch})",
+                "value": round(world * args.batch * args.steps / dt, 3), "unit": "samples/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                "config": {"workload": f"train step: forward + backward + gradient all-reduce + fused AdamW, {args.batch} x 12 frames x "
+                                       f"4096 points x 224x224 per GPU (BASELINE configs[{2 if world == 1 else 3}])",
+                           "parallelism": f"dp{world}", "grad_buckets": len(opt.buckets),
+                           "grad_bucket_mb": round(opt.numel * 4 / len(opt.buckets) / 1e6, 1)},
+                "comm_ranks": D.comm_ranks, "forward_tflop_per_step_per_gpu": round(fwd / 1e12, 2),
+                "losses": [round(float(x), 6) for x in losses[-min(6, len(losses)):]],
+                "grad_norm": round(infos[-1]["grad_norm"], 4), "skipped_steps": sum(1 for i in infos if i["skipped"]),
+                "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                "roofline": None, "cpu_baseline": None}
+    return line
+
+
+def run_frame_parallel(args, D: Dist):
+    """BASELINE configs[4] (c5): ONE 256-frame clip (82 944 trunk tokens), frames sharded over the ranks."""
+    import motion324_amd as m
+    from motion324_amd import synth
+    world, rank, dev = D.world, D.rank, D.dev
+    T = args.frames
+    model, _ = build_model(dev, T)
+    s = synth.synth_inputs(1, T, 2048, args.surface, 512, seed=1)             # the SAME clip on every rank
+    sample = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+    m.set_precision(args.precision)
+    fast = m.GraphedForward(model) if (world == 1 and not args.eager) else None
+    last = [None]
+
+    def step():
+        with torch.no_grad():
+            if world > 1:
+                last[0] = model.forward_frame_parallel(sample).pcd_moved
+            elif fast is not None:
+                last[0] = fast(sample).pcd_moved
+            else:
+                last[0] = model(sample).pcd_moved
+
+    for _ in range(args.warmup):
+        step()
+    dt, _ = timed(D, step, args.steps)
+    line = None
+    if rank == 0:
+        flops = algorithmic_flops(1, T, 2048, args.surface)
+        line = {"metric": f"frames/sec ({T}-frame clip, 2048 pts, 512x512, frame-parallel)", "value": round(T * args.steps / dt, 2),
+                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                "config": {"workload": f"one {T}-frame clip x 2048 points x 512x512, {args.surface} surface samples, training.frames={T} "
+                                       "(BASELINE configs[4]); frames sharded over the ranks, K/V all-gather per global block",
+                           "parallelism": f"frame-parallel x{world}"},
+                "comm_ranks": D.comm_ranks, "launch": "hipGraph replay" if fast is not None else "eager",
+                "end_to_end_tflops": round(flops * args.steps / dt / 1e12, 1),
+                "end_to_end_frac_of_bf16_peak": round(flops * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS / world, 4),
+                "finite": bool(torch.isfinite(last[0]).all()), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                "roofline": None, "cpu_baseline": None}
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "frame-parallel"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=8, help="train mode: batch_size_per_gpu (c3: 8, c4: 32)")
+    ap.add_argument("--frames", type=int, default=256, help="frame-parallel mode: clip length (training.frames)")
+    ap.add_argument("--surface", type=int, default=4096, help="frame-parallel mode: surface samples (the shell script uses 16384)")
+    ap.add_argument("--sustain", type=float, default=3.0, help="infer mode: seconds of back-to-back replays for the `sustained` field (0 = off)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="time eager per-kernel launches instead of hipGraph replay")
+    ap.add_argument("--clips-in-flight", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive steps alternate between two HIP streams / graphs, so one clip's kernels fill the "
+                         "partly filled last round of the other's (throughput mode; the default 1 is one clip at a time)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    maybe_spawn(args)                     # N > 1 without a launcher: child ranks, before any GPU call in this process
+    D = Dist(args)
+    line = {"infer": run_infer, "train": run_train, "frame-parallel": run_frame_parallel}[args.mode](args, D)
+    if D.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

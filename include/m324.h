@@ -41,6 +41,11 @@ int m324_abi_version(void);
 int m324_last_error(char* buf, int n);
 /* Fills name with the device's gcnArchName ("gfx950..."), returns CU count or negative status. */
 int m324_device_info(char* name, int n);
+/* Lab / test hook (not used by the product path): the kernel choosers' A/B switches -- "M324_GEMM" (forced schedule
+ * number, 0 = automatic), "M324_GEMM_TN", "M324_XCD", "M324_ATTN_NW", "M324_ATTN_FLAT", "M324_ATTN_OCC", "M324_ATTN_NQ2",
+ * "M324_ATTN_BWD_NW", "M324_ATTN_EXP" -- are read from the environment ONCE, when the library is loaded; this call
+ * overrides one of them afterwards (value INT_MIN restores the default).  No launch path calls getenv(). */
+int m324_set_tunable(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * m324_gemm: C = epilogue(A[M,K] . W[N,K]^T)  -- every nn.Linear / the patch Conv2d on the path.
@@ -82,6 +87,10 @@ typedef struct {
     int qkv_L, qkv_H;
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
+/* Host-only: writes the kernel symbol (as rocprofv3 prints the template) and its grid in threads that m324_gemm would
+ * launch for `a` into buf; returns the schedule number.  bench.py labels its per-launch HIP-event rows with it so that
+ * they can be matched against the committed rocprofv3 summaries (profiles/). */
+int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n);
 
 /* ------------------------------------------------------------------------------------------
  * m324_gemm_tn: C[s][n][j] (fp32) = sum over the tokens m of slice s of X[m, n] * Y[m, j]  -- the weight gradient
@@ -142,6 +151,8 @@ int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, con
 enum { M324_ATTN_Q_PRESCALED = 1, M324_ATTN_V_ROWMAJOR = 2 };
 int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo,
                    int B, int H, int Lq, int Lk, float scale, int q_prescaled, float* lse, int dtype, void* stream);
+/* Host-only twin of m324_gemm_plan for m324_attention (flags = the q_prescaled flag word). */
+int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int dtype, char* buf, int n);
 /*   lse (optional, [B,H,Lq] fp32): log2-domain log-sum-exp of every score row, saved for the backward pass. */
 
 /* ------------------------------------------------------------------------------------------
@@ -214,6 +225,18 @@ int m324_mse(const float* pred, const float* target, long n, float weight, float
  * ------------------------------------------------------------------------------------------ */
 int m324_smooth_trajectories(const float* trajs, float* tmp, float* out, int B, int T, int N,
                              float threshold, float sigma, void* stream);
+/* The two remaining methods of the same caller-side function (utils/inference_utils.py:148-195):
+ *   m324_smooth_savgol : method='savgol' -- scipy.signal.savgol_filter(window, polyorder, mode='nearest') = a symmetric
+ *     FIR along t with clamped borders; `coef` is a DEVICE array of `window` (odd) fp64 Savitzky-Golay coefficients the host
+ *     computes (motion324_amd/postprocess.py); accumulation in fp64, like scipy's convolve1d.  T >= window.
+ *   m324_smooth_oneeuro: method='oneeuro' -- OneEuroFilter (:58-97) per scalar coordinate, sequential in t, fp64 state.
+ * trajs/out [B,T,N,3] fp32, distinct buffers. */
+int m324_smooth_savgol(const float* trajs, float* out, int B, int T, int N, const double* coef, int window, void* stream);
+int m324_smooth_oneeuro(const float* trajs, float* out, int B, int T, int N, float mincutoff, float beta, float dcutoff,
+                        void* stream);
+/* index[i] = argmin_j |query[i] - ref[j]|^2 (lowest j on ties): the vertex-colour assignment of the caller's pre-step
+ * (scripts/inference_with_video_mesh.py:112-115, a scipy cKDTree query in the reference).  query [n_query,3], ref [n_ref,3]. */
+int m324_nearest_point(const float* query, int n_query, const float* ref, int n_ref, int* index, void* stream);
 
 /* ==========================================================================================
  * Training-side entry points (backward of the path; reference: torch autograd over the same modules,
@@ -274,9 +297,35 @@ int m324_mse_bwd(const float* pred, const float* target, const float* grad_scale
  * grad_scale: optional device scalar multiplying the gradient (clipping coefficient, train.py:196). */
 int m324_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, const float* grad_scale, void* stream);
+/* The same update over the optimizer's WHOLE flat parameter buffer in one launch (multi-tensor semantics of
+ * torch.optim.AdamW(fused=True), utils/training_utils.py:52): elements [0, n_decay) take `weight_decay` (parameters with
+ * dim() > 1, training_utils.py:39-47), elements [n_decay, n) take none.  n, n_decay multiples of 4; 16-byte aligned. */
+int m324_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, const float* grad_scale, void* stream);
 /* *out (+)= sum g^2 (gradient-norm pieces); sanitize != 0 first applies nan_to_num(0, 1e-6, -1e-6) in place
  * (train.py:181-183).  partial: >= 1024 floats of scratch. */
 int m324_grad_sumsq(float* g, long n, int sanitize, float* partial, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Collectives of the path over RCCL / xGMI (one process per GPU).
+ *   replaces: the NCCL collectives torch.distributed issues for the reference -- DDP's gradient all-reduce
+ *             (train.py:88-89,159-166; setup.py:134-140 creates the process group) -- and carries the two exchanges of the
+ *             multi-GPU inference modes (k|v all-gather per global block, final [T, N, 3] all-gather).
+ *   The Python host of this repo keeps using torch.distributed ("nccl" IS RCCL on ROCm) because the reference's callers
+ *   own that process group; these entry points give a torch-free host the same collectives.  RCCL is resolved when
+ *   m324_comm_init is first called (symbols already in the process, else librccl.so): libm324.so itself does not link it.
+ *   Bootstrap: rank 0 calls m324_comm_unique_id and hands the 256-character hex string to the other ranks (file, env,
+ *   socket -- the caller's business); every rank then calls m324_comm_init on ITS device (hipSetDevice first).
+ *   All calls only enqueue on `stream`; buffers are device pointers; dtype M324_F32 / M324_BF16.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct m324_comm m324_comm;
+int m324_comm_unique_id(char* hex, int n);                         /* n >= 257 */
+int m324_comm_init(m324_comm** comm, const char* unique_id_hex, int rank, int world);
+/* in place; average != 0 divides by the number of ranks (DDP's gradient mean) */
+int m324_comm_allreduce(m324_comm* comm, void* buf, long count, int dtype, int average, void* stream);
+/* recv[r * count_per_rank ...] = rank r's send (rank order = frame order in the frame-parallel forward) */
+int m324_comm_allgather(m324_comm* comm, const void* send, void* recv, long count_per_rank, int dtype, void* stream);
+int m324_comm_destroy(m324_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, parallel
 from .easydict import EasyDict as edict
 from .image_encoder import DINO_EPS, DinoEncoder
 from .lib import ACT_GELU, M324Error
@@ -86,6 +86,64 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
+class _KVGather:
+    """Frame-parallel global attention (BASELINE config 5): all ranks' token-major k|v projections of one global block.
+
+    ``start(kv_local)`` is called right after the k|v projection GEMM and launches the collective on a side stream
+    (RCCL over xGMI: 2 x 82 944 x 768 bf16 = 255 MB assembled per block at T = 256); the compute stream meanwhile runs
+    the block's own q projection and q split; ``finish()`` joins.  Even shards with B = 1 (the 256 / 8 case) go through
+    ONE all_gather_into_tensor straight into a buffer that every global block reuses -- rank order = frame order, so
+    the gathered rows already are the clip's token order and nothing is copied afterwards.  Uneven shards (or B > 1,
+    where the clip order is batch-major) pad to the largest shard and compact once."""
+
+    def __init__(self, B, T_local, Lt, frames, group, dev):
+        self.B, self.T, self.Lt, self.frames, self.group, self.dev = B, T_local, Lt, list(frames), group, dev
+        self.world = len(self.frames)
+        self.T_full = sum(self.frames)
+        self.even = B == 1 and all(f == self.frames[0] for f in self.frames)
+        self.comm = torch.cuda.Stream(device=dev)
+        self.buf = None
+        self._pending = None
+        self.launch_log = []                     # ids of the streams the collectives were enqueued on (tests)
+
+    def start(self, kv_local: torch.Tensor) -> None:
+        """kv_local: contiguous [B * T_local * Lt, 2C]."""
+        rows, width = kv_local.shape
+        main = torch.cuda.current_stream(self.dev)
+        self.comm.wait_stream(main)              # the projection has been enqueued; earlier readers of `buf` too
+        with torch.cuda.stream(self.comm):
+            self.launch_log.append(self.comm.cuda_stream)
+            if self.even:
+                if self.buf is None or self.buf.dtype != kv_local.dtype or self.buf.shape[1] != width:
+                    self.buf = torch.empty((self.world * rows, width), dtype=kv_local.dtype, device=self.dev)
+                work = parallel.all_gather_into(self.buf, kv_local, group=self.group, async_op=True)
+                self._pending = (work, None, kv_local)
+            else:
+                mx = max(self.frames) * self.Lt
+                send = torch.zeros((self.B, mx, width), dtype=kv_local.dtype, device=self.dev)
+                send[:, :self.T * self.Lt] = kv_local.reshape(self.B, self.T * self.Lt, width)
+                parts = torch.empty((self.world,) + tuple(send.shape), dtype=kv_local.dtype, device=self.dev)
+                work = parallel.all_gather_into(parts, send, group=self.group, async_op=True)
+                self._pending = (work, parts, kv_local)
+
+    def finish(self):
+        """-> ([B * T_full * Lt, 2C] in clip order, T_full * Lt)."""
+        work, parts, kv_local = self._pending
+        self._pending = None
+        with torch.cuda.stream(self.comm):
+            work.wait()
+            if parts is None:
+                full = self.buf
+            else:
+                full = torch.cat([parts[r, :, :f * self.Lt] for r, f in enumerate(self.frames)], dim=1)
+                full = full.reshape(self.B * self.T_full * self.Lt, -1)
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_stream(self.comm)
+        kv_local.record_stream(self.comm)
+        full.record_stream(main)
+        return full, self.T_full * self.Lt
+
+
 class _TrainStepFunction(torch.autograd.Function):
     """loss, pcd_moved = f(params): forward AND backward are computed in forward() by libm324 kernels; backward()
     only scales the stored gradients by d(loss)."""
@@ -94,7 +152,9 @@ class _TrainStepFunction(torch.autograd.Function):
     def forward(ctx, model, sample, *params):
         from . import training
         loss, out, G = training.forward_backward(model, sample)
-        ctx.grads = [G.get(p) for p in params]
+        # a trainable parameter the step never touched (special_token_rest at T == 1) gets zeros, as from autograd:
+        # DDP's reducer (find_unused_parameters=False, train.py:89) must see every bucket marked ready
+        ctx.grads = [G.get(p) if G.get(p) is not None else torch.zeros_like(p) for p in params]
         ctx.mark_non_differentiable(out)
         return loss, out
 
@@ -308,18 +368,7 @@ class Motion_Latent_Model(nn.Module):
         # D. alternating global / local trunk (reference :394-409)
         if shard is not None and shard[1] > 1:
             rank, world, group = shard
-            frames = parallel.counts(T_full, world)
-
-            def kv_gather(kv_local):
-                """[B*T_local*Lt, 2C] (strided view) -> ([B*T_full*Lt, 2C], T_full*Lt), batch-major, rank order =
-                frame order (the order of keys does not matter to softmax, but it keeps V and K aligned)."""
-                mx = max(frames) * Lt
-                buf = torch.zeros((B, mx, kv_local.shape[1]), dtype=kv_local.dtype, device=dev)
-                buf[:, :T * Lt] = kv_local.reshape(B, T * Lt, -1)
-                parts = [torch.empty_like(buf) for _ in range(world)]
-                torch.distributed.all_gather(parts, buf, group=group)
-                full = torch.cat([p[:, :f * Lt] for p, f in zip(parts, frames)], dim=1)
-                return full.reshape(B * T_full * Lt, -1), T_full * Lt
+            kv_gather = _KVGather(B, T, Lt, parallel.counts(T_full, world), group, dev)
 
         for gblk, lblk in zip(self.global_transformer_blocks, self.local_transformer_blocks):
             gblk.run(P, tok, B, T * Lt, kv_gather=kv_gather)
@@ -370,9 +419,12 @@ class Motion_Latent_Model(nn.Module):
             frames = parallel.counts(T_full, world)
             buf = torch.zeros((max(frames), B, N, 3), dtype=torch.float32, device=dev)
             buf[:T] = out.transpose(0, 1)
-            parts = [torch.empty_like(buf) for _ in range(world)]
-            torch.distributed.all_gather(parts, buf, group=group)
-            out = torch.cat([p[:f] for p, f in zip(parts, frames)], dim=0).transpose(0, 1).contiguous()
+            parts = torch.empty((world,) + tuple(buf.shape), dtype=torch.float32, device=dev)
+            parallel.all_gather_into(parts, buf, group=group)
+            if all(f == frames[0] for f in frames):
+                out = parts.reshape(T_full, B, N, 3).transpose(0, 1).contiguous()
+            else:
+                out = torch.cat([parts[r, :f] for r, f in enumerate(frames)], dim=0).transpose(0, 1).contiguous()
         result = edict(input_data=sample, pcd_moved=out)
         if "point_clouds" in sample:                                           # reference :582-592
             m = self.loss_computer(out, sample["point_clouds"].to(dev))

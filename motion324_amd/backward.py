@@ -22,11 +22,19 @@ RMS_EPS = 1e-5
 
 
 class GradStore:
-    """fp32 gradient accumulator keyed by parameter (what autograd's .grad would hold)."""
+    """fp32 gradient accumulator keyed by parameter (what autograd's .grad would hold).
 
-    def __init__(self):
+    With a ``sink`` (motion324_amd.optim.FusedAdamW) the gradients of the parameters it owns are written straight into
+    its flat gradient buffer, and ``done(params)`` tells it that the backward will not touch those parameters again --
+    the moment the optimizer may launch the bucket's all-reduce on its side stream (the reference's DDP reducer hooks,
+    train.py:88-89,159-166)."""
+
+    def __init__(self, sink=None):
         self.grads: Dict[int, torch.Tensor] = {}
         self.params: Dict[int, torch.nn.Parameter] = {}
+        self.sink = sink
+        if sink is not None:
+            sink.begin_step()
 
     def add(self, param: Optional[torch.nn.Parameter], g: torch.Tensor) -> None:
         if param is None or not param.requires_grad:
@@ -35,12 +43,31 @@ class GradStore:
         k = id(param)
         if k in self.grads:
             self.grads[k] += g          # accumulation of a few small tensors (shared weights): torch add on fp32
+            return
+        if self.sink is not None and self.sink.owns(param):
+            view = self.sink.grad_of(param)
+            view.copy_(g)
+            self.grads[k] = view
         else:
             self.grads[k] = g.float().clone() if g.dtype != torch.float32 or not g.is_contiguous() else g.clone()
-            self.params[k] = param
+        self.params[k] = param
 
     def get(self, param) -> Optional[torch.Tensor]:
         return self.grads.get(id(param))
+
+    def done(self, params) -> None:
+        """No further add() will touch these parameters in this step (parameters that received no gradient get zeros,
+        what autograd would deliver)."""
+        if self.sink is None:
+            return
+        params = [p for p in params if p is not None and p.requires_grad]
+        for p in params:
+            if id(p) not in self.grads and self.sink.owns(p):
+                view = self.sink.grad_of(p)
+                view.zero_()
+                self.grads[id(p)] = view
+                self.params[id(p)] = p
+        self.sink.ready(params)
 
 
 def _attention_bwd(P: Prepared, spq: dict, spk: dict, do: torch.Tensor, lse, D, B: int, Lq: int, H: int, shared_q: bool):

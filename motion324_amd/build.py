@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libm324.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "attention.hip", "elementwise.hip", "backward.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "attention.hip", "elementwise.hip", "backward.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(HERE, "..", "include", "m324.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified 512-entry file), which removes the
 # v_accvgpr_read/write shuffling around every softmax / epilogue access of an accumulator
@@ -61,7 +61,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

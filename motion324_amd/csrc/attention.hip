@@ -20,6 +20,7 @@
 // staged by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the source address) into a 3-stage ring:
 // two tiles in flight, counted vmcnt + raw s_barrier, no ds_write pass and no staging registers.
 // The fp32 parity variant uses v_mfma_f32_32x32x2_f32 on padded fp32 tiles (single buffered).
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 
@@ -693,26 +694,22 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         M324_REQUIRE((ldo * 2) % 8 == 0, "m324_attention: ldo misaligned");
         // NQ = 2 (two query blocks per wave) measured slower than NQ = 1 on MI355X (254 VGPRs -> one wave per
         // SIMD); it stays selectable for experiments only.
-        const bool nq2 = getenv("M324_ATTN_NQ2") != nullptr && Lq >= 1024 && !vrow;
-        // eight waves per workgroup for long query sets (M324_ATTN_NW=4|8 forces; read per call for A/B runs)
-        const char* fnw = getenv("M324_ATTN_NW");
-        const bool w8 = !nq2 && (fnw ? atoi(fnw) == 8 : (Lq >= 2048 && Lk >= 512));
+        const bool nq2 = m324::tunable(m324::TUN_ATTN_NQ2) != 0 && Lq >= 1024 && !vrow;
+        // eight waves per workgroup for long query sets (M324_ATTN_NW=4|8 forces: A/B runs, tests)
+        const int fnw = m324::tunable(m324::TUN_ATTN_NW);
+        const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
         dim3 g2(ceil_div(Lq, nq2 ? 2 * QB : (w8 ? 2 * QB : QB)), H, B);
         // XCD-aware flat grid for the 8-wave kernel (M324_ATTN_FLAT=0 keeps the 3-D grid: A/B runs)
         int nqt = 0;
-        {
-            const char* ff = getenv("M324_ATTN_FLAT");
-            if (w8 && !(ff && atoi(ff) == 0)) {
-                nqt = (int)g2.x;
-                g2 = dim3(g2.x * H * B, 1, 1);
-            }
+        if (w8 && m324::tunable(m324::TUN_ATTN_FLAT) != 0) {
+            nqt = (int)g2.x;
+            g2 = dim3(g2.x * H * B, 1, 1);
         }
         // Co-residency: the NQ = 1 kernel fits 3 workgroups per CU (168 VGPRs, 32 KiB LDS).  Interleaved A/B on
         // MI355X: 3 per CU beats 2 per CU (422 vs 453 us on the 10 368-token global attention) even though the
         // grid then ends in a partly filled round -- latency hiding wins over round quantisation.
         // M324_ATTN_OCC=2 pads the LDS allocation to force two per CU (experiments only).
-        const char* focc = getenv("M324_ATTN_OCC");
-        const unsigned pad = (focc && atoi(focc) == 2) ? 24 * 1024 : 0;
+        const unsigned pad = m324::tunable(m324::TUN_ATTN_OCC) == 2 ? 24 * 1024 : 0;
 #define M324_ATTN(PS, NQ, NWV)                                                                                          \
     hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ, NWV>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,         \
                        (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt)
@@ -737,6 +734,28 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
     return M324_OK;
 }
 
+// Name and grid (threads) of the kernel m324_attention would launch: see m324_gemm_plan.
+extern "C" int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int dtype, char* buf, int n) {
+    M324_REQUIRE(buf && n > 0 && B > 0 && H > 0 && Lq > 0 && Lk > 0, "m324_attention_plan: bad arguments");
+    if (dtype != M324_BF16) {
+        snprintf(buf, (size_t)n, "attn_f32_kernel grid=%ldx%dx%d", (long)ceil_div(Lq, QB) * 256, H, B);
+        return 0;
+    }
+    const bool vrow = (flags & M324_ATTN_V_ROWMAJOR) != 0, ps = (flags & M324_ATTN_Q_PRESCALED) != 0;
+    const bool nq2 = m324::tunable(m324::TUN_ATTN_NQ2) != 0 && Lq >= 1024 && !vrow;
+    const int fnw = m324::tunable(m324::TUN_ATTN_NW);
+    const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
+    const long gx = ceil_div(Lq, (nq2 || w8) ? 2 * QB : QB);
+    const int nwv = w8 ? 8 : 4;
+    if (w8 && m324::tunable(m324::TUN_ATTN_FLAT) != 0)
+        snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s> grid=%ldx1x1", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
+                 vrow ? "true" : "false", gx * H * B * nwv * 64);
+    else
+        snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s> grid=%ldx%dx%d", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
+                 vrow ? "true" : "false", gx * nwv * 64, H, B);
+    return nwv;
+}
+
 extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_bstride, long qt_bstride, const void* K,
                                        const void* Kt, const void* V, const void* dO, const void* dOt, const float* lse,
                                        const float* D, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, float scale,
@@ -748,8 +767,7 @@ extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_b
     // M324_ATTN_BWD_NW=8 (read per call) selects eight waves per workgroup: every staged tile then feeds 256 instead of
     // 128 rows (half the LDS-DMA pieces per FLOP).  Unlike the forward it measured 0.7 % SLOWER on the training step
     // (B = 8, L = 3888), so four waves stay the default.
-    const char* fnw = getenv("M324_ATTN_BWD_NW");
-    const bool w8 = fnw && atoi(fnw) == 8;
+    const bool w8 = m324::tunable(m324::TUN_ATTN_BWD_NW) == 8;
     if (w8) {
         hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<8>, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
                            q_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D,

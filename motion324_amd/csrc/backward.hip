@@ -180,6 +180,33 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// One launch over the optimizer's whole flat parameter buffer (fused multi-tensor AdamW): elements [0, n_decay) carry
+// weight decay (the parameters with dim() > 1), the rest do not; n and n_decay are multiples of 4 (16-byte segments).
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                         float4* __restrict__ v, long n4, long n4_decay, float lr, float b1, float b2,
+                                                         float eps, float wd, float bc1, float bc2_sqrt,
+                                                         const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.0f;
+    const float step = lr / bc1, inv_bc2 = 1.0f / bc2_sqrt;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float keep = i < n4_decay ? 1.0f - lr * wd : 1.0f;
+        const float4 gi = g[i], mo = m[i], vo = v[i];
+        float4 pi = p[i], mi, vi;
+#define M324_ADAM1(c)                                                     \
+        {                                                                 \
+            const float gc = gi.c * gs;                                   \
+            mi.c = b1 * mo.c + (1.0f - b1) * gc;                          \
+            vi.c = b2 * vo.c + (1.0f - b2) * gc * gc;                     \
+            pi.c = pi.c * keep - step * mi.c / (sqrtf(vi.c) * inv_bc2 + eps); \
+        }
+        M324_ADAM1(x) M324_ADAM1(y) M324_ADAM1(z) M324_ADAM1(w)
+#undef M324_ADAM1
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi;
+    }
+}
+
 __global__ __launch_bounds__(256) void grad_sanitize_sumsq_kernel(float* __restrict__ g, long n, int sanitize,
                                                                   float* __restrict__ partial) {
     __shared__ float red[4];
@@ -305,6 +332,19 @@ extern "C" int m324_adamw(float* p, const float* g, float* m, float* v, long n, 
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2s, grad_scale);
     M324_CHECK_LAUNCH("m324_adamw");
+    return M324_OK;
+}
+
+extern "C" int m324_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, const float* grad_scale, void* stream) {
+    M324_REQUIRE(p && g && m && v && n > 0 && step >= 1 && n_decay >= 0 && n_decay <= n, "m324_adamw_flat: bad arguments");
+    M324_REQUIRE(n % 4 == 0 && n_decay % 4 == 0 && ((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                     ((uintptr_t)v % 16) == 0,
+                 "m324_adamw_flat: the flat buffers must be 16-byte aligned with n and n_decay multiples of 4");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
+                       (float4*)m, (float4*)v, n / 4, n_decay / 4, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    M324_CHECK_LAUNCH("m324_adamw_flat");
     return M324_OK;
 }
 

@@ -29,6 +29,15 @@ void m324_set_error(const char* fmt, ...);
         if (e_ != hipSuccess) M324_FAIL(M324_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// ---- tunables: A/B switches of the kernel choosers.  Read from the environment ONCE, when the library is loaded
+// (M324_GEMM=v10, M324_ATTN_NW=8, ...); afterwards only m324_set_tunable() changes them (labs / tests).  No launch
+// path calls getenv().
+namespace m324 {
+enum Tunable { TUN_GEMM = 0, TUN_GEMM_TN, TUN_XCD, TUN_ATTN_NW, TUN_ATTN_FLAT, TUN_ATTN_OCC, TUN_ATTN_NQ2, TUN_ATTN_BWD_NW,
+               TUN_ATTN_EXP, TUN_COUNT };
+int tunable(int which);          // 0 = "not set" for every switch except TUN_XCD / TUN_ATTN_FLAT (default 1)
+}  // namespace m324
+
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ---------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // native conversions: one v_cvt_pk_bf16_f32 (RNE, NaN-preserving) per pair

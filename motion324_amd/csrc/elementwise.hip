@@ -383,6 +383,79 @@ __global__ __launch_bounds__(256) void smooth_gauss_kernel(const float* __restri
     q[0] = ax; q[1] = ay; q[2] = az;
 }
 
+// FIR along t with clamped ('nearest') borders: scipy.signal.savgol_filter(mode='nearest') = convolve1d with the
+// Savitzky-Golay coefficients (host-computed, symmetric for deriv = 0), accumulated in fp64 like scipy does.
+__global__ __launch_bounds__(256) void smooth_fir_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int T, int N,
+                                                         const double* __restrict__ coef, int window) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // one thread per (b, t, n)
+    if (idx >= (long)B * T * N) return;
+    const int n = (int)(idx % N), t = (int)((idx / N) % T), b = (int)(idx / ((long)N * T));
+    const int h = window / 2;
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    for (int j = 0; j < window; ++j) {
+        const int tt = min(max(t + h - j, 0), T - 1);           // convolution: y[t] = sum_j c[j] x[t + h - j]
+        const double w = coef[j];
+        const float* p = in + (((long)b * T + tt) * N + n) * 3;
+        ax += w * (double)p[0]; ay += w * (double)p[1]; az += w * (double)p[2];
+    }
+    float* q = out + idx * 3;
+    q[0] = (float)ax; q[1] = (float)ay; q[2] = (float)az;
+}
+
+// One Euro filter (utils/inference_utils.py:58-97,186-195): a causal adaptive low-pass per scalar coordinate, sequential in
+// t.  One thread per (batch, point, xyz).  Arithmetic in fp64: under the reference's pinned numpy 1.26 the filter state
+// (python floats x np.float32 scalars) is float64 from the second sample on, only the stored result is rounded to fp32.
+__global__ __launch_bounds__(256) void smooth_oneeuro_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int T,
+                                                             int N, double mincutoff, double beta, double dcutoff) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // (b, n, c)
+    if (idx >= (long)B * N * 3) return;
+    const int b = (int)(idx / ((long)N * 3));
+    const long nc = idx % ((long)N * 3);
+    const float* p = in + (long)b * T * N * 3 + nc;
+    float* q = out + (long)b * T * N * 3 + nc;
+    const double two_pi = 6.283185307179586;
+    const double rd = two_pi * dcutoff, alpha_d = rd / (rd + 1.0);
+    double x_prev = (double)p[0], dx_prev = 0.0;
+    q[0] = p[0];
+    for (int t = 1; t < T; ++t) {
+        const long o = (long)t * N * 3;
+        const double x = (double)p[o];
+        const double dx = t == 1 ? (double)(p[o] - p[0]) : x - x_prev;     // the first difference is float32 - float32
+        const double dx_hat = alpha_d * dx + (1.0 - alpha_d) * dx_prev;
+        const double r = two_pi * (mincutoff + beta * fabs(dx_hat));
+        const double alpha = r / (r + 1.0);
+        const double x_hat = alpha * x + (1.0 - alpha) * x_prev;
+        x_prev = x_hat;
+        dx_prev = dx_hat;
+        q[o] = (float)x_hat;
+    }
+}
+
+// Nearest reference point of every query point (brute force, squared distances in fp32 from fp32 differences; the lowest
+// index wins ties): the vertex-colour assignment of the caller's pre-step (scripts/inference_with_video_mesh.py:112-115,
+// a cKDTree query there).  Reference points are staged through LDS in tiles of 1024.
+__global__ __launch_bounds__(256) void nearest_point_kernel(const float* __restrict__ query, int nq, const float* __restrict__ ref,
+                                                            int nr, int* __restrict__ idx_out) {
+    __shared__ float tile[1024 * 3];
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const bool live = qi < nq;
+    const float qx = live ? query[qi * 3] : 0.f, qy = live ? query[qi * 3 + 1] : 0.f, qz = live ? query[qi * 3 + 2] : 0.f;
+    float best = INFINITY;
+    int besti = 0;
+    for (int r0 = 0; r0 < nr; r0 += 1024) {
+        const int cnt = min(1024, nr - r0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 3; e += 256) tile[e] = ref[(long)r0 * 3 + e];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const float dx = tile[j * 3] - qx, dy = tile[j * 3 + 1] - qy, dz = tile[j * 3 + 2] - qz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; besti = r0 + j; }
+        }
+    }
+    if (live) idx_out[qi] = besti;
+}
+
 // =====================================================================================================
 // Training-side kernels (backward of the HBM-bound ops + layout helpers for the backward GEMMs)
 // =====================================================================================================
@@ -658,6 +731,34 @@ extern "C" int m324_smooth_trajectories(const float* trajs, float* tmp, float* o
                            sigma, radius);
     }
     M324_CHECK_LAUNCH("m324_smooth_trajectories");
+    return M324_OK;
+}
+
+extern "C" int m324_smooth_savgol(const float* trajs, float* out, int B, int T, int N, const double* coef, int window,
+                                  void* stream) {
+    M324_REQUIRE(trajs && out && coef && B > 0 && T > 0 && N > 0 && window >= 1 && (window & 1) && trajs != out,
+                 "m324_smooth_savgol: bad arguments (odd window, distinct buffers)");
+    M324_REQUIRE(T >= window, "m324_smooth_savgol: T=%d is shorter than the window %d (the reference leaves such clips unfiltered)", T, window);
+    hipLaunchKernelGGL(smooth_fir_kernel, dim3(ceil_div((long)B * T * N, 256)), dim3(256), 0, (hipStream_t)stream, trajs, out, B, T,
+                       N, coef, window);
+    M324_CHECK_LAUNCH("m324_smooth_savgol");
+    return M324_OK;
+}
+
+extern "C" int m324_smooth_oneeuro(const float* trajs, float* out, int B, int T, int N, float mincutoff, float beta, float dcutoff,
+                                   void* stream) {
+    M324_REQUIRE(trajs && out && B > 0 && T > 0 && N > 0 && trajs != out, "m324_smooth_oneeuro: bad arguments");
+    hipLaunchKernelGGL(smooth_oneeuro_kernel, dim3(ceil_div((long)B * N * 3, 256)), dim3(256), 0, (hipStream_t)stream, trajs, out, B,
+                       T, N, (double)mincutoff, (double)beta, (double)dcutoff);
+    M324_CHECK_LAUNCH("m324_smooth_oneeuro");
+    return M324_OK;
+}
+
+extern "C" int m324_nearest_point(const float* query, int n_query, const float* ref, int n_ref, int* index, void* stream) {
+    M324_REQUIRE(query && ref && index && n_query > 0 && n_ref > 0, "m324_nearest_point: bad arguments");
+    hipLaunchKernelGGL(nearest_point_kernel, dim3(ceil_div(n_query, 256)), dim3(256), 0, (hipStream_t)stream, query, n_query, ref,
+                       n_ref, index);
+    M324_CHECK_LAUNCH("m324_nearest_point");
     return M324_OK;
 }
 

@@ -13,6 +13,7 @@
 // Pipeline: global -> registers (issued before the MFMAs of the current tile) -> LDS (after them),
 // double-buffered LDS, one barrier per K-tile.
 
+#include <stdio.h>
 #include "gemm_tile.h"
 
 namespace {
@@ -1024,16 +1025,10 @@ static bool vec_ok(const m324_gemm_args* a) {
 }
 
 // XCD-aware tile order (default on; M324_XCD=0 disables)
-static int xcd_remap() {
-    static const int v = [] { const char* e = getenv("M324_XCD"); return e ? (atoi(e) & 1) : 1; }();
-    return v;
-}
+static int xcd_remap() { return m324::tunable(m324::TUN_XCD) & 1; }
 
 // Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11|v12|v13 forces a variant (A/B measurements, tests).
-static int forced_variant() {      // read per call: lets one process A/B-toggle the variant
-    const char* e = getenv("M324_GEMM");
-    return (e && e[0] == 'v') ? atoi(e + 1) : 0;
-}
+static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_GEMM at load / m324_set_tunable
 
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
@@ -1043,6 +1038,12 @@ static int pick_variant(const m324_gemm_args* a) {
     if (f == 1 || f == 2 || f == 5) return f;
     if (f == 7) return bf16 ? 7 : 5;
     if (f >= 10 && f <= 13) return ring_ok ? f : (bf16 ? (f == 13 ? 2 : 7) : (f == 13 ? 2 : 5));
+    // v14 (deferred epilogue): at least five K-stages carry the four epilogue steps; whole 128-column tiles; no aux operand
+    const bool dfe_ok = ring_ok && a->K >= 576 && a->N % 128 == 0 && a->M % 16 == 0 && a->aux_mode == 0 &&
+                        a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M || (a->res_rows % 16 == 0 && a->res_rows >= 256)) &&
+                        (long)a->M * a->lda * 2 < 0x7FFFFFFFl && (long)a->N * a->ldw * 2 < 0x7FFFFFFFl &&
+                        (long)a->M * a->ldc * 4 < 0x7FFFFFFFl && (!a->residual || (long)a->M * a->ldr * 4 < 0x7FFFFFFFl);
+    if (f == 14) return dfe_ok ? 14 : (ring_ok ? 12 : 2);
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
@@ -1071,26 +1072,24 @@ static int pick_variant(const m324_gemm_args* a) {
 }
 
 template <typename TOUT, int ACT, int RES>
-static void launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
-    if (variant == 11 || variant == 12) {
-        m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap(), variant);
-        return;
-    }
+static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
+    if (variant == 11 || variant == 12 || variant == 14) return m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap(), variant);
     if (variant == 13) {
         hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN) * ceil_div(a->M, BM)), dim3(256), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
                            ceil_div(a->N, BN), xcd_remap());
-        return;
+        return M324_OK;
     }
     if (variant == 10) {
         hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
                            ceil_div(a->N, BN5), xcd_remap());
-        return;
+        return M324_OK;
     }
     hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
                        (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
                        ceil_div(a->N, BN5), xcd_remap());
+    return M324_OK;
 }
 
 template <typename TIN, typename TOUT>
@@ -1118,8 +1117,10 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                         : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
 #define M324_GLDS(ACT, RES)                                                                                              \
     do {                                                                                                                 \
-        if (variant == 7 || variant >= 10)                                                                               \
-            launch_pipe<TOUT, ACT, RES>(a, s, ep, variant);                                                              \
+        if (variant == 7 || variant >= 10) {                                                                             \
+            const int rc_ = launch_pipe<TOUT, ACT, RES>(a, s, ep, variant);                                              \
+            if (rc_ != M324_OK) return rc_;                                                                              \
+        }                                                                                                                \
         else if (variant == 5)                                                                                           \
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
                                dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
@@ -1150,6 +1151,43 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
 }  // namespace
 
 
+// Name (as rocprofv3's kernel trace prints the template, element types abbreviated) and grid in threads of the kernel
+// m324_gemm would launch for `a`: lets bench.py label its HIP-event rows with the same symbols the committed rocprof
+// summaries use.  Host-only; mirrors launch() above.
+extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
+    M324_REQUIRE(a && buf && n > 0, "m324_gemm_plan: bad arguments");
+    const int nbatch = a->batch > 1 ? a->batch : 1;
+    const int variant = nbatch > 1 ? 2 : pick_variant(a);
+    const char* tout = a->out_dtype == M324_BF16 ? "unsigned short" : "float";
+    const char* tin = a->in_dtype == M324_BF16 ? "unsigned short" : "float";
+    const int res = !a->residual && a->row_gin <= 0 ? 0
+                    : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
+    int act = a->act == M324_ACT_GELU ? 1 : 0, rs = act ? (res ? 2 : 0) : res;
+    if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) act = 4, rs = 0;
+    else if (a->aux_mode == M324_AUX_STORE_PREACT) act = 2, rs = 0;
+    else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD) act = 3, rs = 0;
+    long wg = 0, threads = 256;
+    const char* name = "gemm_kernel";
+    switch (variant) {
+        case 1: wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
+        case 2: name = "gemm_glds_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) * nbatch; break;
+        case 5: name = "gemm_glds5_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
+        case 7: name = "gemm_pipe_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
+        case 9: name = "gemm_skinny_kernel"; wg = ceil_div(a->N, 32); threads = 512; break;
+        case 10: name = "gemm_ring_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
+        case 11: name = "gemm_ring4_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;
+        case 12: name = "gemm_ring3_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); break;
+        case 13: name = "gemm_ring2_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
+        case 14: name = "gemm_dfe_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;
+        default: break;
+    }
+    if (variant == 1) snprintf(buf, (size_t)n, "%s<%s, %s> grid=%ld", name, tin, tout, wg * threads);
+    else if (variant == 9) snprintf(buf, (size_t)n, "%s<%s, %d> grid=%ld", name, tout, act ? 1 : 0, wg * threads);
+    else if (variant == 2 || variant == 5) snprintf(buf, (size_t)n, "%s<%s, %s, %d, %d> grid=%ld", name, tin, tout, act, rs, wg * threads);
+    else snprintf(buf, (size_t)n, "%s<%s, %d, %d> grid=%ld", name, tout, act, rs, wg * threads);
+    return variant;
+}
+
 extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, float* C, long ldc, int M, int N, int Kc,
                             int slices, long strideC, void* stream) {
     M324_REQUIRE(X && Y && C, "m324_gemm_tn: null pointer");
@@ -1161,9 +1199,8 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
     const int ks = ((M + slices - 1) / slices + 63) / 64 * 64;          // tokens per slice, whole 64-row tiles
     M324_REQUIRE((long)ks * (slices - 1) < M, "m324_gemm_tn: %d slices leave an empty slice for M=%d", slices, M);
     // 256 x 256 tiles on the pipelined kernel when every slice is whole 32-token half-tiles and the output fills the tiles
-    // (M324_GEMM_TN=128 forces the small kernel, read per call)
-    const char* ftn = getenv("M324_GEMM_TN");
-    const bool big = !(ftn && atoi(ftn) == 128) && M % 32 == 0 && N % 256 == 0 && Kc % 256 == 0 && M / slices >= 256;
+    // (M324_GEMM_TN=128 forces the small kernel)
+    const bool big = m324::tunable(m324::TUN_GEMM_TN) != 128 && M % 32 == 0 && N % 256 == 0 && Kc % 256 == 0 && M / slices >= 256;
     if (big) {
         const int ntj = Kc / 256;
         hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3((N / 256) * ntj, slices), dim3(512), 0, (hipStream_t)stream,

@@ -28,7 +28,7 @@ struct Epilogue {
 
 // gemm_ring4.hip (own translation unit: built WITHOUT -amdgpu-mfma-vgpr-form, its 256 accumulators live in AGPRs).
 // act_code: the ACT template value (0 none, 1 GELU, 2 GELU + pre-activation, 3 x gelu', 4 q|k|v heads); res_code: RES.
-void launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap, int variant);
+int launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap, int variant);
 }  // namespace m324
 
 namespace {
@@ -263,6 +263,11 @@ constexpr int EP_WAVE_FLOATS = 32 * EP_LD;     // 8704 bytes per wave
 template <typename TOUT, int ACT, int RES, int MI>
 __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float* scr, TOUT* C, long ldc, int M, int N, int mw,
                                                int nw, int lane, const Epilogue& ep) {
+#if defined(M324_LAB_NOSTORE) && defined(__HIP_DEVICE_COMPILE__)          // tools/ lab builds only: main loop without its epilogue (accumulators kept alive)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { asm volatile("" ::"v"(acc[i][0])); asm volatile("" ::"v"(acc[i][1])); }
+    return;
+#endif
     const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
     const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
     const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;

@@ -1,5 +1,8 @@
 // Error plumbing and device query for libm324.
+#include <limits.h>
 #include <stdarg.h>
+#include <stdlib.h>
+#include <atomic>
 #include <stdio.h>
 #include <string.h>
 #include "common.h"
@@ -13,7 +16,37 @@ void m324_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int m324_abi_version(void) { return 9; }
+extern "C" int m324_abi_version(void) { return 10; }
+
+// ---- tunables (see common.h): environment read once at load, then m324_set_tunable only
+namespace {
+struct TunDef { const char* env; int dflt; };
+const TunDef kTun[m324::TUN_COUNT] = {
+    {"M324_GEMM", 0}, {"M324_GEMM_TN", 0}, {"M324_XCD", 1}, {"M324_ATTN_NW", 0}, {"M324_ATTN_FLAT", 1},
+    {"M324_ATTN_OCC", 0}, {"M324_ATTN_NQ2", 0}, {"M324_ATTN_BWD_NW", 0}, {"M324_ATTN_EXP", 0}};
+std::atomic<int> g_tun[m324::TUN_COUNT];
+int parse_tun(const char* e) { return (e[0] == 'v' || e[0] == 'V') ? atoi(e + 1) : atoi(e); }
+struct TunInit {
+    TunInit() {
+        for (int i = 0; i < m324::TUN_COUNT; ++i) {
+            const char* e = getenv(kTun[i].env);
+            g_tun[i].store(e && e[0] ? parse_tun(e) : kTun[i].dflt, std::memory_order_relaxed);
+        }
+    }
+} g_tun_init;
+}  // namespace
+
+int m324::tunable(int which) { return g_tun[which].load(std::memory_order_relaxed); }
+
+extern "C" int m324_set_tunable(const char* name, int value) {
+    M324_REQUIRE(name, "m324_set_tunable: null name");
+    for (int i = 0; i < m324::TUN_COUNT; ++i)
+        if (!strcmp(name, kTun[i].env)) {
+            g_tun[i].store(value == INT_MIN ? kTun[i].dflt : value, std::memory_order_relaxed);
+            return M324_OK;
+        }
+    M324_FAIL(M324_ERR_INVALID, "m324_set_tunable: unknown switch %s", name);
+}
 
 extern "C" int m324_last_error(char* buf, int n) {
     if (!buf || n <= 0) return (int)strlen(g_err);

@@ -9,10 +9,10 @@ hipStreamBeginCapture on the stream libm324 launches on) and replayed: one host 
     out = fast(sample)                    # first call per (shapes, precision): warm-up + capture
     out.pcd_moved                         # static output buffer, overwritten by the next replay
 
-Weights are read through the Prepared cache at capture time: a graph is keyed by the cache generation, so
-``model.train()/eval()`` toggles, the native optimizer step and ``prepared.bump_generation()`` force a re-capture;
-after any other in-place weight update call ``fast.reset()`` (inference-only helper: the reference's callers
-never update weights between forwards).
+Weights are read through the Prepared cache at capture time: a graph is keyed by the cache generation AND by a stamp
+of every parameter's storage pointer and in-place version counter, so ``model.train()/eval()`` toggles, the native
+optimizer step, ``load_state_dict`` / ``load_checkpoint`` on a live model and ``model.to(...)`` all force a re-capture.
+Only an update through raw pointers that bypasses torch's version counters needs ``prepared.bump_generation()``.
 """
 from __future__ import annotations
 
@@ -38,7 +38,8 @@ class GraphedForward:
         self._graphs.clear()
 
     def _key(self, sample) -> Tuple:
-        return (prepared.generation(), compute_dtype()) + tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
+        return (prepared.generation(), prepared.weight_stamp(self.model), compute_dtype()) + \
+            tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
 
     def __call__(self, sample: Dict[str, torch.Tensor]):
         if self.model.training:
@@ -46,7 +47,7 @@ class GraphedForward:
         key = self._key(sample)
         entry = self._graphs.get(key)
         if entry is None:
-            for stale in [k for k in self._graphs if k[0] != key[0]]:     # graphs that point at dropped weight copies
+            for stale in [k for k in self._graphs if k[:2] != key[:2]]:   # graphs that point at dropped weight copies
                 del self._graphs[stale]
             static_in = {k: sample[k].detach().to(torch.float32).contiguous().clone() for k in _KEYS if k in sample}
             side = torch.cuda.Stream()

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libm324.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class M324Error(RuntimeError):
@@ -49,7 +49,10 @@ SIGNATURES = {
     "m324_abi_version": [],
     "m324_last_error": [C.c_char_p, _I],
     "m324_device_info": [C.c_char_p, _I],
+    "m324_set_tunable": [C.c_char_p, _I],
     "m324_gemm": [C.POINTER(GemmArgs), _P],
+    "m324_gemm_plan": [C.POINTER(GemmArgs), C.c_char_p, _I],
+    "m324_attention_plan": [_I, _I, _I, _I, _I, _I, C.c_char_p, _I],
     "m324_gemm_tn": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _L, _P],
     "m324_layernorm": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -62,6 +65,9 @@ SIGNATURES = {
     "m324_linear_n3": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
     "m324_mse": [_P, _P, _L, _F, _P, _P, _P],
     "m324_smooth_trajectories": [_P, _P, _P, _I, _I, _I, _F, _F, _P],
+    "m324_smooth_savgol": [_P, _P, _I, _I, _I, _P, _I, _P],
+    "m324_smooth_oneeuro": [_P, _P, _I, _I, _I, _F, _F, _F, _P],
+    "m324_nearest_point": [_P, _I, _P, _I, _P, _P],
     "m324_transpose": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     "m324_colsum": [_P, _L, _P, _I, _I, _I, _I, _P, _I, _P],
     "m324_gelu": [_P, _P, _L, _I, _P],
@@ -74,7 +80,13 @@ SIGNATURES = {
     "m324_linear_n3_bwd": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P],
     "m324_mse_bwd": [_P, _P, _P, _F, _P, _L, _P],
     "m324_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
+    "m324_adamw_flat": [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "m324_grad_sumsq": [_P, _L, _I, _P, _P, _I, _P],
+    "m324_comm_unique_id": [C.c_char_p, _I],
+    "m324_comm_init": [C.POINTER(C.c_void_p), C.c_char_p, _I, _I],
+    "m324_comm_allreduce": [_P, _P, _L, _I, _I, _P],
+    "m324_comm_allgather": [_P, _P, _P, _L, _I, _P],
+    "m324_comm_destroy": [_P],
     "m324_layernorm_bwd": [_P, _L, _P, _F, _P, _L, _I, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 
@@ -114,6 +126,30 @@ def last_error() -> str:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise M324Error(f"{what} failed ({rc}): {last_error()}")
+
+
+TUNABLE_DEFAULT = -2 ** 31      # m324_set_tunable(name, INT_MIN) restores the load-time default
+
+
+def set_tunable(name: str, value: int = TUNABLE_DEFAULT) -> None:
+    """Lab / test hook: overrides one of the kernel-chooser switches that libm324 otherwise reads from the
+    environment once, at load (M324_GEMM, M324_ATTN_NW, ...).  `value` omitted = back to the default."""
+    check(load().m324_set_tunable(name.encode(), int(value)), "m324_set_tunable")
+
+
+class tunable:
+    """with tunable("M324_GEMM", 10): ...   (restores the default afterwards)"""
+
+    def __init__(self, name: str, value):
+        self.name = name
+        self.value = int(str(value).lstrip("vV")) if value is not None else TUNABLE_DEFAULT
+
+    def __enter__(self):
+        set_tunable(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_tunable(self.name)
 
 
 def device_info():

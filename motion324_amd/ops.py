@@ -57,6 +57,18 @@ def _rows(t: torch.Tensor, name: str):
     return _p(t), t.stride(0)
 
 
+def _gemm_plan(args) -> str:
+    buf = C.create_string_buffer(192)
+    L.load().m324_gemm_plan(C.byref(args), buf, 192)
+    return buf.value.decode()
+
+
+def _attn_plan(B, H, Lq, Lk, flags, dtype_code) -> str:
+    buf = C.create_string_buffer(192)
+    L.load().m324_attention_plan(B, H, Lq, Lk, flags, dtype_code, buf, 192)
+    return buf.value.decode()
+
+
 def gemm_splitk(a: torch.Tensor, w: torch.Tensor, slices: int) -> torch.Tensor:
     """out[M,N] fp32 = a[M,K] @ w[N,K]^T with the contraction cut into `slices` independent GEMMs launched together
     (grid.y) and summed by m324_colsum: for weight gradients, where M x N is small and K (tokens) is huge."""
@@ -140,7 +152,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
         args.qkv_q, args.qkv_k, args.qkv_v = _p(Qo), _p(Ko), _p(Vo)
         args.qkv_qw, args.qkv_kw = _vec(qw, 64, "q_w"), _vec(kw, 64, "k_w")
         args.qkv_eps, args.qkv_qscale, args.qkv_L, args.qkv_H = eps, q_scale, Lh, Hh
-        with span("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), f"M={M} N={N} K={K} qkv-heads" if _timing() else ""):
+        with span("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N),
+                  f"{_gemm_plan(args)} | M={M} N={N} K={K} qkv-heads" if _timing() else ""):
             L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
         return Qo
     args.C, args.ldc = _rows(out, "out")
@@ -168,9 +181,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
         args.aux_mode = 1 if preact_out is not None else 2
     esz = a.element_size()
     tag = "" if not _timing() else (
-        f"M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}{' gamma' if gamma is not None else ''}"
-        f"{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}")
-    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, esz * (M * K + N * K) + out.element_size() * M * N, tag):
+        f"{_gemm_plan(args)} | M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}"
+        f"{' gamma' if gamma is not None else ''}{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}")
+    # algorithmic bytes: both operands once, the output once, the fp32 residual rows once
+    nbytes = esz * (M * K + N * K) + out.element_size() * M * N
+    if residual is not None:
+        nbytes += 4 * N * (res_rows if 0 < res_rows < M else M)
+    with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, nbytes, tag):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     return out
 
@@ -259,7 +276,8 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     esz = Q.element_size()
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
               esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq),
-              f"B={B} H={H} Lq={Lq} Lk={Lk}" if _timing() else ""):
+              f"{_attn_plan(B, H, Lq, Lk, int(prescaled) | (2 if v_rowmajor else 0), code_of(Q.dtype))} | B={B} H={H} Lq={Lq} Lk={Lk}"
+              if _timing() else ""):
         L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale,
                                         int(prescaled) | (2 if v_rowmajor else 0), _p(lse), code_of(Q.dtype), _stream()),
                 "m324_attention")
@@ -354,6 +372,36 @@ def smooth_trajectories(trajs: torch.Tensor, threshold: float, sigma: float) -> 
     L.check(L.load().m324_smooth_trajectories(_p(x), _p(tmp), _p(out), B, T, N, threshold, sigma, _stream()),
             "m324_smooth_trajectories")
     return out
+
+
+def smooth_savgol(trajs: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    """[B,T,N,3] fp32 filtered along T with the odd-length fp64 coefficient vector `coef` (clamped borders)."""
+    x = trajs.detach().to(torch.float32).contiguous()
+    B, T, N, _ = x.shape
+    if coef.dtype != torch.float64 or not coef.is_cuda or not coef.is_contiguous():
+        raise L.M324Error("smooth_savgol: coef must be a contiguous fp64 HIP tensor")
+    out = torch.empty_like(x)
+    L.check(L.load().m324_smooth_savgol(_p(x), _p(out), B, T, N, _p(coef), coef.numel(), _stream()), "m324_smooth_savgol")
+    return out
+
+
+def smooth_oneeuro(trajs: torch.Tensor, mincutoff: float, beta: float, dcutoff: float = 1.0) -> torch.Tensor:
+    x = trajs.detach().to(torch.float32).contiguous()
+    B, T, N, _ = x.shape
+    out = torch.empty_like(x)
+    L.check(L.load().m324_smooth_oneeuro(_p(x), _p(out), B, T, N, mincutoff, beta, dcutoff, _stream()), "m324_smooth_oneeuro")
+    return out
+
+
+def nearest_point(query: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """query [Nq,3], ref [Nr,3] fp32 -> int64 [Nq] index of the nearest reference point."""
+    q = query.detach().to(torch.float32).contiguous()
+    r = ref.detach().to(torch.float32).contiguous()
+    if q.dim() != 2 or q.shape[1] != 3 or r.dim() != 2 or r.shape[1] != 3:
+        raise L.M324Error(f"nearest_point: expected [n,3] point sets, got {tuple(q.shape)} / {tuple(r.shape)}")
+    idx = torch.empty((q.shape[0],), dtype=torch.int32, device=q.device)
+    L.check(L.load().m324_nearest_point(_p(q), q.shape[0], _p(r), r.shape[0], _p(idx), _stream()), "m324_nearest_point")
+    return idx.long()
 
 
 # ------------------------------------------------------------------------------------------------ training side
@@ -520,6 +568,16 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
             raise L.M324Error("adamw_step: tensors must be contiguous fp32 of equal size")
     L.check(L.load().m324_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                 _p(grad_scale), _stream()), "m324_adamw")
+
+
+def adamw_flat(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, n_decay: int, lr: float, beta1: float,
+               beta2: float, eps: float, weight_decay: float, step: int, grad_scale: Optional[torch.Tensor] = None) -> None:
+    """One launch over the optimizer's flat buffers: elements [0, n_decay) decay, the rest do not (m324_adamw_flat)."""
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+            raise L.M324Error("adamw_flat: tensors must be contiguous fp32 of equal size")
+    L.check(L.load().m324_adamw_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), int(n_decay), lr, beta1, beta2, eps, weight_decay,
+                                     step, _p(grad_scale), _stream()), "m324_adamw_flat")
 
 
 def grad_sumsq(g: torch.Tensor, out: torch.Tensor, partial: torch.Tensor, sanitize: bool, accumulate: bool) -> None:

@@ -33,6 +33,18 @@ def counts(n_items: int, world: int) -> List[int]:
     return [len(partition(n_items, world, r)) for r in range(world)]
 
 
+def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """out[r * n : (r + 1) * n] = rank r's `inp` (n = inp.numel(); both contiguous): one all_gather_into_tensor straight
+    into `out`, whatever its shape ([world, ...] stacked or concatenated along dim 0).  `out` is handed over in the
+    concatenated form, the only one every backend accepts (RCCL takes both; gloo -- the transport of the single-device
+    rehearsals and tests -- only this one)."""
+    world = dist.get_world_size(group)
+    if out.numel() != world * inp.numel() or not (out.is_contiguous() and inp.is_contiguous()):
+        raise ValueError(f"all_gather_into: out {tuple(out.shape)} must be contiguous with world x {tuple(inp.shape)} elements")
+    shape = (world * inp.shape[0],) + tuple(inp.shape[1:]) if inp.dim() > 0 else (world,)
+    return dist.all_gather_into_tensor(out.view(shape), inp, group=group, async_op=async_op)
+
+
 def all_gather_items(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
     """local: [n_local, ...] outputs of this rank's shard (partition order).  Returns [n_items, ...] on every
     rank.  Shards may be uneven: each rank pads to the largest shard, one all_gather moves everything."""

@@ -53,6 +53,16 @@ def generation() -> int:
     return _GENERATION
 
 
+def weight_stamp(module: torch.nn.Module) -> int:
+    """Cheap fingerprint of a module's parameter / buffer storage and in-place version counters: changes on
+    load_state_dict, .to(device), an eager optimizer step or any other tracked in-place update (a hipGraph captured
+    from the old weights must not be replayed after that)."""
+    h = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        h = (h * 1000003 + t.data_ptr() * 31 + t._version) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
 def pad_k(k: int) -> int:
     return (k + K_ALIGN - 1) // K_ALIGN * K_ALIGN
 
@@ -76,7 +86,10 @@ class Prepared:
 
     @staticmethod
     def _stamp(ps: Sequence[torch.Tensor]) -> tuple:
-        return (_GENERATION,) + tuple((p.data_ptr(), p._version) for p in ps)
+        # the generation counter guards against raw-pointer updates by an optimizer: frozen tensors (the 86 M DINOv2
+        # weights, buffers) are never updated that way, so their copies survive a bump (no re-conversion per step)
+        gen = _GENERATION if any(getattr(p, "requires_grad", False) for p in ps) else 0
+        return (gen,) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def _get(self, kind: str, ps: Sequence[torch.Tensor], make):
         key = (kind,) + tuple(id(p) for p in ps)

@@ -43,12 +43,13 @@ class Recorder:
 
     def by_tag(self) -> Dict[Tuple[str, str], dict]:
         """(kernel class, tag) -> {launches, total_ms, flops}: per-shape breakdown for tuning."""
-        acc = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0.0})
-        for name, flops, _nbytes, e0, e1, tag in self.items:
+        acc = defaultdict(lambda: {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for name, flops, nbytes, e0, e1, tag in self.items:
             a = acc[(name, tag)]
             a["launches"] += 1
             a["total_ms"] += e0.elapsed_time(e1)
             a["flops"] += flops
+            a["bytes"] += nbytes
         return dict(acc)
 
 

@@ -45,16 +45,18 @@ def _point_features_bwd(model, P: Prepared, G: bw.GradStore, enc, feat, d_pf: to
     bw.linear_bwd(P, G, model.point_embed.mlp.weight, model.point_embed.mlp.bias, enc, demb, need_da=False)
 
 
-def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None
-                     ) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
-    """One training step's forward + hand-written backward (see _forward_backward); inference-only fusions are off."""
+def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None,
+                     sink=None) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
+    """One training step's forward + hand-written backward (see _forward_backward); inference-only fusions are off.
+    sink: a motion324_amd.optim.FusedAdamW -- gradients are then written into its flat buffer and each bucket's
+    all-reduce leaves on the optimizer's side stream as soon as the backward has finished the bucket's tensors."""
     from .transformer import fusion_disabled
     with fusion_disabled():
-        return _forward_backward(model, sample, grad_scale, drop_seed)
+        return _forward_backward(model, sample, grad_scale, drop_seed, sink)
 
 
-def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None
-                      ) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
+def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None,
+                      sink=None) -> Tuple[torch.Tensor, torch.Tensor, bw.GradStore]:
     """Returns (loss [0-dim fp32], pcd_moved [B,T,N,3] fp32, GradStore with d(grad_scale * loss)/d param).
     pos_drop (reference :369-370,490; p = transformer.drop_rate, default 0.1) is applied to the video tokens when
     model.training; its mask is a function of ``drop_seed`` (default: drawn from torch's CPU generator, so
@@ -70,7 +72,7 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     if dev.type != "cuda":
         raise M324Error("the training step runs only on a HIP device")
     P = Prepared.for_module(model, dev, compute_dtype())
-    G = bw.GradStore()
+    G = bw.GradStore(sink)
     B, N, _ = ref_pcd.shape
     C, K = model.embed_dim, model.num_learnable_tokens
     S = sample["ref_shape_pcd"].shape[1]
@@ -152,11 +154,14 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
                                        d_kv=d_tok[b * T * Lt:(b + 1) * T * Lt])
         _point_features_bwd(model, P, G, enc_p, feat_p, d_pf)
         dec_saved[b] = None
+    G.done(list(model.shared_mlp_output.parameters()) + list(dec.parameters()))
 
     n_pairs = len(model.global_transformer_blocks)
     for i in reversed(range(n_pairs)):
         bw.self_attn_block_bwd(model.local_transformer_blocks[i], P, G, trunk_in[2 * i + 1], d_tok, B * T, Lt)
+        G.done(model.local_transformer_blocks[i].parameters())
         bw.self_attn_block_bwd(model.global_transformer_blocks[i], P, G, trunk_in[2 * i], d_tok, B, T * Lt)
+        G.done(model.global_transformer_blocks[i].parameters())
         trunk_in[2 * i + 1] = trunk_in[2 * i] = None
 
     # token assembly + input LayerNorm: recompute the un-normalised concatenation, LN backward over every row (the LN
@@ -171,14 +176,18 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     if T > 1:
         G.add(model.special_token_rest,
               ops.colsum(d4[:, 1:, :4].reshape(B * (T - 1), 4 * C).contiguous()).reshape(1, 4, C))
+    G.done([ln_in.weight, model.special_token_0, model.special_token_rest])
     d_mesh = torch.empty((B * K, C), dtype=torch.float32, device=dev)
     for b in range(B):
         d_mesh[b * K:(b + 1) * K] = ops.colsum(d4[b, :, 4:4 + K].reshape(T, K * C).contiguous()).reshape(K, C)
 
     for i in reversed(range(len(model.points_transformer_blocks))):
         bw.self_attn_block_bwd(model.points_transformer_blocks[i], P, G, mesh_in[i], d_mesh, B, K)
+        G.done(model.points_transformer_blocks[i].parameters())
     d_pts = torch.zeros((B * S, C), dtype=torch.float32, device=dev)
     d_query = bw.cross_attn_block_bwd(model.encoder_cross_attn, P, G, query, pts, d_mesh, B, K, S, d_kv=d_pts)
     G.add(model.learnable_tokens, ops.colsum(d_query.reshape(B, K * C)).reshape(1, K, C))
+    G.done(list(model.encoder_cross_attn.parameters()) + [model.learnable_tokens])
     _point_features_bwd(model, P, G, enc_s, feat_s, d_pts)
+    G.done(p for p in model.parameters() if p.requires_grad)           # everything else (point embedding, stragglers)
     return loss, out, G

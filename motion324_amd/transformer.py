@@ -152,8 +152,9 @@ class QK_Norm_TransformerBlock(nn.Module):
     def run(self, P: Prepared, x: torch.Tensor, B: int, L: int, kv_gather=None) -> torch.Tensor:
         """x: fp32 [B*L, C] residual stream, updated in place (x + attn(LN x); x + mlp(LN x)).
 
-        kv_gather (frame-parallel global attention): callable mapping this rank's token-major k|v projection
-        [B*L, 2C] to (all ranks' [B*L_full, 2C], L_full); queries stay local, keys/values cover the whole clip."""
+        kv_gather (frame-parallel global attention): object with start(kv_local [B*L, 2C]) / finish() -> (all ranks'
+        [B*L_full, 2C], L_full) -- Pcd_motion._KVGather; queries stay local, keys/values cover the whole clip.  The k|v
+        projection runs first so that its all-gather travels while the q projection and the q split execute."""
         rows, C = x.shape
         assert rows == B * L
         a = self.attn
@@ -171,15 +172,22 @@ class QK_Norm_TransformerBlock(nn.Module):
             ops.attention(Q, K, V, h, prescaled=True, v_rowmajor=not long_seq)
             ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
             return _mlp_residual(P, self.norm2, self.mlp, x)
-        qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)
-        ops.gemm(h, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
         if kv_gather is None:
+            qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)
+            ops.gemm(h, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
             Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads,
                                      P.dtype, q_scale=ops.Q_PRESCALE)
         else:
-            kv_full, L_full = kv_gather(qkv[:, C:])
-            Q, _, _ = ops.qkv_split(qkv[:, :C], None, None, qw, None, RMS_EPS, B, L, a.num_heads, P.dtype,
-                                    q_scale=ops.Q_PRESCALE)
+            # to_qkv.weight rows [C, 3C) are the k|v projection, rows [0, C) the q projection (contiguous row slices)
+            w = P.mat(a.to_qkv.weight)
+            bias = P.vec(a.to_qkv.bias)
+            kv = torch.empty((rows, 2 * C), dtype=P.dtype, device=x.device)
+            ops.gemm(h, w[C:], kv, bias=None if bias is None else bias[C:])
+            kv_gather.start(kv)                                                       # collective on the side stream ...
+            q = torch.empty((rows, C), dtype=P.dtype, device=x.device)
+            ops.gemm(h, w[:C], q, bias=None if bias is None else bias[:C])            # ... under the q projection + split
+            Q, _, _ = ops.qkv_split(q, None, None, qw, None, RMS_EPS, B, L, a.num_heads, P.dtype, q_scale=ops.Q_PRESCALE)
+            kv_full, L_full = kv_gather.finish()
             _, K, Vt = ops.qkv_split(None, kv_full[:, :C], kv_full[:, C:], None, kw, RMS_EPS, B, L_full, a.num_heads,
                                      P.dtype)
         ops.attention(Q, K, Vt, h, prescaled=True)                                       # h reused as the attention output

@@ -37,6 +37,7 @@ CASES = {
                         shape=(1, 2, 33, 70, 96)),
     "c1": dict(dims=dict(frames=12), shape=(1, 4, 512, 4096, 256)),
     "c2": dict(dims=dict(frames=32), shape=(1, 32, 2048, 4096, 512)),
+    "c5": dict(dims=dict(frames=256), shape=(1, 256, 2048, 4096, 512)),      # golden keeps a sample of the mesh points
 }
 
 
@@ -70,3 +71,18 @@ def vt_layout(v: torch.Tensor) -> torch.Tensor:
     vt[..., :Lk] = v.transpose(2, 3)
     vt = vt.reshape(B, H, D, Lp // 16, 4, 4)[..., [0, 2, 1, 3], :]
     return vt.reshape(B, H, D, Lp).contiguous()
+
+
+@pytest.fixture
+def tune():
+    """tune("M324_GEMM", "v10"): overrides a kernel-chooser switch of libm324 through m324_set_tunable (the library reads
+    the environment only once, at load) and restores every touched switch after the test."""
+    from motion324_amd import lib
+    touched = []
+
+    def _set(name, value):
+        touched.append(name)
+        lib.set_tunable(name, int(str(value).lstrip("vV")))
+    yield _set
+    for name in touched:
+        lib.set_tunable(name)

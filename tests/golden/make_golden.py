@@ -154,6 +154,9 @@ CASES = {
                         shape=(1, 2, 33, 70, 96)),
     "c1": dict(dims=dict(frames=12), shape=(1, 4, 512, 4096, 256)),
     "c2": dict(dims=dict(frames=32), shape=(1, 32, 2048, 4096, 512)),
+    # BASELINE configs[4]: the 256-frame clip (82 944 trunk tokens; ~10 min per forward on 8 cores).  Only a sample of the
+    # mesh points is stored (all frames), so that the fixture stays small.
+    "c5": dict(dims=dict(frames=256), shape=(1, 256, 2048, 4096, 512), pcd_points=96),
 }
 STAGE_ROWS = 16  # rows kept per stage tensor (first dims flattened) for the full-size cases
 
@@ -243,9 +246,16 @@ def run_case(name):
     worst = max(report.values())
     assert worst < 2e-5, f"oracle disagrees with the reference: {report}"
 
-    save = {"pcd_moved": ref_out.numpy(), "loss": np.float32(ref_loss),
+    if spec.get("pcd_points"):
+        pts = np.unique(np.linspace(0, N - 1, spec["pcd_points"]).astype(np.int64))
+        ref_keep = ref_out[:, :, torch.from_numpy(pts)]
+    else:
+        pts, ref_keep = None, ref_out
+    save = {"pcd_moved": ref_keep.numpy(), "loss": np.float32(ref_loss),
             "meta_shape": np.array([B, T, N, S, HW], dtype=np.int64),
             "oracle_vs_reference_max_rel": np.float64(worst)}
+    if pts is not None:
+        save["pcd_points"] = pts
     nrows = 64 if name.startswith("tiny") else STAGE_ROWS
     for k, v in stages.items():
         v2 = v.reshape(-1, v.shape[-1])

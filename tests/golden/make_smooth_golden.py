@@ -15,9 +15,10 @@ SRC = "/root/reference/utils/inference_utils.py"
 HERE = os.path.dirname(os.path.abspath(__file__))
 tree = ast.parse(open(SRC).read())
 fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "smooth_trajectories")
+euro = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "OneEuroFilter")
 ns = {"torch": torch, "np": np, "gaussian_filter1d": gaussian_filter1d, "savgol_filter": savgol_filter,
       "print": lambda *a, **k: None}
-exec(compile(ast.Module(body=[fn], type_ignores=[]), SRC, "exec"), ns)
+exec(compile(ast.Module(body=[euro, fn], type_ignores=[]), SRC, "exec"), ns)
 smooth = ns["smooth_trajectories"]
 
 g = torch.Generator().manual_seed(7)
@@ -35,5 +36,14 @@ out["gaussian_1.5"] = smooth(trajs, method="gaussian", sigma=1.5).numpy()
 short = trajs[:, :3].contiguous()                               # T shorter than the filter radius
 out["trajs_short"] = short.numpy()
 out["short_combined_0.002_1.0"] = smooth(short, method="combined", motion_threshold=0.002, sigma=1.0).numpy()
+# the two remaining methods (utils/inference_utils.py:148-195).  NOTE: this container runs numpy 2.x, whose scalar
+# promotion keeps the One Euro state in float32; the reference pins numpy 1.26 (float64 state).  The two differ by
+# ~1e-7 relative, far inside the 2e-6 the tests allow.
+out["savgol_5_2"] = smooth(trajs, method="savgol", window_size=5, savgol_polyorder=2).numpy()
+out["savgol_8_3"] = smooth(trajs, method="savgol", window_size=8, savgol_polyorder=3).numpy()      # even window -> 9
+out["savgol_3_2"] = smooth(trajs, method="savgol").numpy()                                          # defaults: identity fit
+out["short_savgol_5_2"] = smooth(short, method="savgol", window_size=5, savgol_polyorder=2).numpy()   # T < window: untouched
+out["oneeuro_1.0_0.007"] = smooth(trajs, method="oneeuro").numpy()
+out["oneeuro_0.3_0.5"] = smooth(trajs, method="oneeuro", oneeuro_mincutoff=0.3, oneeuro_beta=0.5).numpy()
 np.savez_compressed(os.path.join(HERE, "smooth.npz"), **out)
 print({k: v.shape for k, v in out.items()})

@@ -279,11 +279,11 @@ def test_cross_attn_block_backward_vs_oracle_autograd(dtype, shared):
 @pytest.mark.parametrize("nw", ["4", "8"])
 @pytest.mark.parametrize("B,H,Lq,Lk,shared", [(2, 3, 70, 70, False), (1, 2, 33, 200, False), (3, 2, 50, 64, True),
                                                (1, 12, 324, 324, False), (1, 2, 700, 129, False)])
-def test_attention_backward_mfma_against_autograd(monkeypatch, nw, B, H, Lq, Lk, shared):
+def test_attention_backward_mfma_against_autograd(tune, nw, B, H, Lq, Lk, shared):
     """bf16 MFMA backward kernels (through qkv_split's train outputs) vs fp64 autograd and vs the reference kernels;
-    both workgroup sizes (M324_ATTN_BWD_NW, read per call; 4 waves is the default)."""
+    both workgroup sizes (M324_ATTN_BWD_NW; 4 waves is the default)."""
     from motion324_amd import ops
-    monkeypatch.setenv("M324_ATTN_BWD_NW", nw)
+    tune("M324_ATTN_BWD_NW", nw)
     dtype = torch.bfloat16
     Bq = 1 if shared else B
     C = H * 64
@@ -335,13 +335,13 @@ def test_colsum_wide_few_rows():
 
 
 @pytest.mark.parametrize("nw", ["4", "8"])
-def test_attention_backward_mfma_many_workgroups_is_race_free(monkeypatch, nw):
+def test_attention_backward_mfma_many_workgroups_is_race_free(tune, nw):
     """Regression: the dQ kernel once relied on __syncthreads() to wait for its LDS-DMA tiles; the compiler emitted no
     vmcnt wait there, so under load a workgroup could read a stage still in flight (one NaN block in ~1 of 20 launches at
     the training shapes B*T = 96, L = 324).  Many co-resident workgroups, LDS poisoned with NaN patterns between launches,
     every launch compared with the first and with the fp32-arithmetic reference kernels."""
     from motion324_amd import ops
-    monkeypatch.setenv("M324_ATTN_BWD_NW", nw)
+    tune("M324_ATTN_BWD_NW", nw)
     dtype = torch.bfloat16
     B, H, L = 24, 12, 324
     C = H * 64

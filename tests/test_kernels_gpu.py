@@ -100,13 +100,13 @@ def test_gemm_inplace_residual(dtype):
 @pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v7", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("K", [64, 192, 832])
-def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
-    """M324_GEMM=vN (read per call) forces one kernel schedule; each must handle ragged M / N tiles, a K shorter than
+def test_gemm_every_schedule_forced(tune, variant, dtype, K):
+    """M324_GEMM=vN (set through m324_set_tunable here) forces one kernel schedule; each must handle ragged M / N tiles, a K shorter than
     its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v7 / v10 / v11 / v12 to v5, v13 to v2;
     the chunk-ring kernels v10 - v13 need two K-stages of 64 and hand K = 64 to v7.)"""
     ops = _ops()
     from motion324_amd.lib import ACT_GELU
-    monkeypatch.setenv("M324_GEMM", variant)
+    tune("M324_GEMM", variant)
     M, N = 3 * 230, 328
     a, w = _q(_rand((M, K), 11), dtype), _q(_rand((N, K), 12, 0.1), dtype)
     bias, gamma, res = _rand((N,), 13), 1 + 0.1 * _rand((N,), 14), _rand((230, N), 15)
@@ -136,7 +136,7 @@ def test_gemm_every_schedule_forced(monkeypatch, variant, dtype, K):
 
 
 @pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13"])
-def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
+def test_gemm_chunk_ring_many_tiles(tune, variant):
     """The chunk-ring kernels on a grid with more tiles than CUs (20 x 16 = 320 tiles of 256 x 256, ragged last row of
     tiles): the persistent v11 walks 1-2 tiles per workgroup with the next tile's first chunks prefetched under the
     epilogue; bias + GELU into bf16, then the in-place fp32 residual stream.  The default choice must agree bit for bit
@@ -150,7 +150,7 @@ def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
     v = a.double() @ w.double().T + bias.double()
     g = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
     ad, wd, bd = a.to(dtype).to(DEV), w.to(dtype).to(DEV), bias.to(DEV)
-    monkeypatch.setenv("M324_GEMM", variant)
+    tune("M324_GEMM", variant)
     out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
     ops.gemm(ad, wd, out, bias=bd, act=ACT_GELU)
     assert rel_err(out.float(), g) < TOL[dtype]
@@ -158,7 +158,7 @@ def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
     x = x0.clone().to(DEV)
     ops.gemm(ad, wd, x, bias=bd, residual=x)
     assert rel_err(x, x0.double() + v) < 1e-5
-    monkeypatch.setenv("M324_GEMM", "v2")
+    tune("M324_GEMM", "v2")
     x2 = x0.clone().to(DEV)
     ops.gemm(ad, wd, x2, bias=bd, residual=x2)
     assert torch.equal(x, x2)
@@ -166,13 +166,13 @@ def test_gemm_chunk_ring_many_tiles(monkeypatch, variant):
 
 @pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("M,N,K", [(65, 8, 128), (37, 200, 128), (300, 136, 192), (513, 260, 128), (256, 256, 128), (257, 132, 320)])
-def test_gemm_ring_edge_shapes(monkeypatch, variant, M, N, K):
+def test_gemm_ring_edge_shapes(tune, variant, M, N, K):
     """The chunk-ring kernels at their smallest legal depth (K = 128: two K-stages, the peeled stage 0 plus one loop
     iteration whose look-ahead is clamped back onto the last stage), with fewer rows / columns than one tile, one row or
     column past a tile edge, and N as small as 8: plain bf16 output and the in-place fp32 residual stream."""
     ops = _ops()
     dtype = torch.bfloat16
-    monkeypatch.setenv("M324_GEMM", variant)
+    tune("M324_GEMM", variant)
     a, w = _q(_rand((M, K), 51), dtype), _q(_rand((N, K), 52, 0.1), dtype)
     ref = a.double() @ w.double().T
     ad, wd = a.to(dtype).to(DEV), w.to(dtype).to(DEV)
@@ -187,7 +187,7 @@ def test_gemm_ring_edge_shapes(monkeypatch, variant, M, N, K):
 
 @pytest.mark.parametrize("variant,M,N,K", [("v10", 8192, 3072, 768), ("v11", 8192, 3072, 768), ("v12", 10368, 768, 3072),
                                             ("v7", 8192, 3072, 768), ("v13", 10368, 768, 768)])
-def test_gemm_ring_kernels_are_race_free(monkeypatch, variant, M, N, K):
+def test_gemm_ring_kernels_are_race_free(tune, variant, M, N, K):
     """The LDS-DMA rings state their own vmcnt waits (tests/test_static.py audits them); a missing one shows up as a tile
     read before it landed -- rarely, and only when the chip is full.  Forty launches at the model's shapes must give
     forty bit-identical results, and the first must match the 128 x 128 kernel (same k order)."""
@@ -195,10 +195,10 @@ def test_gemm_ring_kernels_are_race_free(monkeypatch, variant, M, N, K):
     dtype = torch.bfloat16
     a = _q(_rand((M, K), 41), dtype).to(dtype).to(DEV)
     w = _q(_rand((N, K), 42, 0.05), dtype).to(dtype).to(DEV)
-    monkeypatch.setenv("M324_GEMM", "v2")
+    tune("M324_GEMM", "v2")
     ref = torch.empty((M, N), dtype=dtype, device=DEV)
     ops.gemm(a, w, ref)
-    monkeypatch.setenv("M324_GEMM", variant)
+    tune("M324_GEMM", variant)
     outs = [torch.empty((M, N), dtype=dtype, device=DEV) for _ in range(4)]
     for it in range(40):
         ops.gemm(a, w, outs[it % 4])
@@ -278,7 +278,7 @@ def test_gemm_tn_weight_gradient(M, N, Kc, slices):
     assert rel_err(out2, wide[:, 64:].float().cpu().double().T @ y.double()) < 2e-5
 
 
-def test_gemm_tn_tile_kernels_agree(monkeypatch):
+def test_gemm_tn_tile_kernels_agree(tune):
     """The 256 x 256 pipelined TN kernel (default where it applies) and the 128 x 128 kernel (M324_GEMM_TN=128) compute
     the same sums over the same slices: only the order inside a slice differs."""
     ops = _ops()
@@ -286,7 +286,7 @@ def test_gemm_tn_tile_kernels_agree(monkeypatch):
     M, N, Kc = 12288, 768, 3072
     x, y = _q(_rand((M, N), 74), dtype).to(dtype).to(DEV), _q(_rand((M, Kc), 75, 0.3), dtype).to(dtype).to(DEV)
     big = ops.gemm_tn(x, y, 4)
-    monkeypatch.setenv("M324_GEMM_TN", "128")
+    tune("M324_GEMM_TN", "128")
     small = ops.gemm_tn(x, y, 4)
     assert rel_err(big, small) < 1e-6
     assert rel_err(big, x.float().cpu().double().T @ y.float().cpu().double()) < 2e-5
@@ -326,7 +326,7 @@ def test_gemm_qkv_heads_epilogue(B, L, H, norm, bias):
 
 
 @pytest.mark.parametrize("variant", [None, "v2", "v7", "v10", "v11", "v13"])
-def test_gemm_qkv_heads_transposed_v_epilogue(monkeypatch, variant):
+def test_gemm_qkv_heads_transposed_v_epilogue(tune, variant):
     """M324_AUX_QKV_HEADS_VT: as the head-major epilogue, but V leaves as the transposed, key-permuted Vt the default
     attention kernel reads.  Vt must equal m324_gemm + m324_qkv_split bit for bit (both round acc + bias to bf16 once);
     Q / K differ by the one bf16 rounding the two-pass form puts before the RMSNorm.  Every tile kernel's ACT = 4 path."""
@@ -342,7 +342,7 @@ def test_gemm_qkv_heads_transposed_v_epilogue(monkeypatch, variant):
     ops.gemm(x, w, qkv, bias=b)
     Q2, K2, Vt2 = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, 1e-5, B, L, H, dtype, q_scale=ops.Q_PRESCALE)
     if variant:
-        monkeypatch.setenv("M324_GEMM", variant)
+        tune("M324_GEMM", variant)
     Q, Kk = (torch.full((B, H, L, 64), float("nan"), dtype=dtype, device=DEV) for _ in range(2))
     Vt = torch.full((B, H, 64, L), float("nan"), dtype=dtype, device=DEV)
     ops.gemm(x, w, None, bias=b, qkv_heads=(Q, Kk, Vt, qw, kw, 1e-5, ops.Q_PRESCALE, L, H))
@@ -503,12 +503,12 @@ def test_attention_online_softmax_rescale(dtype):
 
 @pytest.mark.parametrize("sched", ["nw4", "nw8"])
 @pytest.mark.parametrize("Lq,Lk,odd", [(2100, 2100, False), (2304, 1088, True), (2048, 640, False)])
-def test_attention_long_sequence_schedules(monkeypatch, sched, Lq, Lk, odd):
-    """The long-sequence forward schedules (4- and 8-wave workgroups: M324_ATTN_NW, read per call) on ragged lengths, odd
+def test_attention_long_sequence_schedules(tune, sched, Lq, Lk, odd):
+    """The long-sequence forward schedules (4- and 8-wave workgroups: M324_ATTN_NW) on ragged lengths, odd
     and even tile counts, prescaled Q, late / early dominant keys that force the lazy reference to move, and the LSE."""
     ops = _ops()
     dtype = torch.bfloat16
-    monkeypatch.setenv("M324_ATTN_NW", "4" if sched == "nw4" else "8")
+    tune("M324_ATTN_NW", "4" if sched == "nw4" else "8")
     B, H = 1, 2
     q, k, v = (_rand((B, H, L, 64), s_, 1.5) for L, s_ in ((Lq, 61), (Lk, 62), (Lk, 63)))
     k[0, 0, Lk - 70] = q[0, 0, 9] * 3.0                       # q9 . k >> everything, second-to-last tile
@@ -658,3 +658,76 @@ def test_mse():
     a, b = _rand((2, 3, 1000, 3), 47), _rand((2, 3, 1000, 3), 48)
     out = ops.mse(a.to(DEV), b.to(DEV), 0.5)
     assert abs(float(out) - 0.5 * float(((a.double() - b.double()) ** 2).mean())) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ v14: deferred epilogue
+@pytest.mark.parametrize("M,N,K", [(4096 + 48, 768, 768),      # 17 x 6 = 102 tiles (< CUs): every workgroup drains its only tile
+                                    (10368, 2304, 768),         # 41 x 18 = 738 tiles: 2-3 per workgroup, ragged last row of tiles
+                                    (8224, 768, 3072),          # K = 3072: 48 K-stages, 39 of them without a slot
+                                    (2048 * 5, 3072, 640)])     # ten K-stages (the shortest the nine slots + 1 allow)
+def test_gemm_deferred_epilogue_schedule(tune, M, N, K):
+    """v14 (persistent 256 x 128 tiles, the previous tile's epilogue drained under the next tile's MFMAs): bf16 outputs with
+    bias + GELU and plain, the in-place fp32 residual stream with bias + LayerScale, and a residual that repeats every 2048
+    rows (the decoder's out-projection) -- vs fp64, and bit for bit vs the 128 x 128 kernel (same k order) where no GELU
+    polynomial is involved."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    dtype = torch.bfloat16
+    a, w = _q(_rand((M, K), 61), dtype), _q(_rand((N, K), 62, 0.1), dtype)
+    bias, gamma = _rand((N,), 63), 1 + 0.1 * _rand((N,), 64)
+    ad, wd, bd, gd = a.to(dtype).to(DEV), w.to(dtype).to(DEV), bias.to(DEV), gamma.to(DEV)
+    v = a.double() @ w.double().T
+    g = 0.5 * (v + bias.double()) * (1 + torch.erf((v + bias.double()) / math.sqrt(2.0)))
+    x0 = _rand((M, N), 65)
+    bres = _rand((2048, N), 66)
+
+    def run_all():
+        o1 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+        ops.gemm(ad, wd, o1, bias=bd, act=ACT_GELU)
+        o2 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+        ops.gemm(ad, wd, o2)
+        x = x0.clone().to(DEV)
+        ops.gemm(ad, wd, x, bias=bd, gamma=gd, residual=x)
+        y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        if M % 2048 == 0:
+            ops.gemm(ad, wd, y, residual=bres.to(DEV), res_rows=2048)
+        return o1, o2, x, y
+    tune("M324_GEMM", "v14")
+    o1, o2, x, y = run_all()
+    assert rel_err(o1.float(), g) < TOL[dtype]
+    assert rel_err(o2.float(), v) < TOL[dtype]
+    assert rel_err(x, x0.double() + (v + bias.double()) * gamma.double()) < 1e-5
+    if M % 2048 == 0:
+        assert rel_err(y, v + bres.double().repeat(M // 2048, 1)) < 1e-5
+    tune("M324_GEMM", "v2")
+    r1, r2, rx, ry = run_all()
+    assert torch.equal(o2, r2) and torch.equal(x, rx)
+    if M % 2048 == 0:
+        assert torch.equal(y, ry)
+    assert rel_err(o1.float(), r1.float()) < 1e-6 or torch.equal(o1, r1)
+
+
+def test_gemm_deferred_epilogue_is_race_free(tune):
+    """Forty launches at the trunk's q|k|v shape: bit-identical results, equal to the 128 x 128 kernel's."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    M, N, K = 10368, 2304, 768
+    a = _q(_rand((M, K), 41), dtype).to(dtype).to(DEV)
+    w = _q(_rand((N, K), 42, 0.05), dtype).to(dtype).to(DEV)
+    tune("M324_GEMM", "v2")
+    ref = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(a, w, ref)
+    x0 = _rand((M, N), 43).to(DEV)
+    xr = x0.clone()
+    ops.gemm(a, w, xr, residual=xr)
+    tune("M324_GEMM", "v14")
+    outs = [torch.empty((M, N), dtype=dtype, device=DEV) for _ in range(4)]
+    for it in range(40):
+        ops.gemm(a, w, outs[it % 4])
+        if it % 4 == 3:
+            for o in outs:
+                assert torch.equal(o, ref), f"launch {it}: result differs"
+    for it in range(10):
+        x = x0.clone()
+        ops.gemm(a, w, x, residual=x)
+        assert torch.equal(x, xr), f"residual launch {it}: result differs"

@@ -14,7 +14,10 @@ from conftest import CASES, load_golden, rel_err, synth_sd
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
-BF16_TOL = 3e-2
+# bf16 speed mode vs the fp32 reference goldens.  Measured on MI355X (round 1): pcd_moved 4.3-4.6e-3, every captured
+# stage <= 5.2e-3; a regression to 1 % must fail.
+BF16_TOL = 8e-3            # pcd_moved and the non-trunk stages
+BF16_STAGE_TOL = {"trunk_block0": 1e-2, "trunk_out": 1e-2}
 
 
 def build(case, device="cuda"):
@@ -91,7 +94,8 @@ def test_forward_bf16_band(case):
     errs["pcd_moved"] = rel_err(out.pcd_moved, torch.from_numpy(gold["pcd_moved"]))
     print(f"[{case} bf16] " + "  ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     assert torch.isfinite(out.pcd_moved).all()
-    assert errs["pcd_moved"] < BF16_TOL, errs
+    for k, v in errs.items():
+        assert v < BF16_STAGE_TOL.get(k, BF16_TOL), (k, errs)
     assert "loss_metrics" not in out
 
 

@@ -1,4 +1,4 @@
-// Standalone GEMM lab: times m324_gemm variants (M324_GEMM=vN is read per call) on the shapes of the c2 clip without
+// Standalone GEMM lab: times m324_gemm variants (forced through m324_set_tunable) on the shapes of the c2 clip without
 // paying a Python / torch start-up on the GPU box.  Build (in the container, cross-compiles):
 //     hipcc -O2 -std=c++17 tools/gemm_lab.cpp -o tools/gemm_lab -ldl
 // Run (GPU box):  tools/gemm_lab [--variants 0,2,6,7] [--iters 20] [--only substr]
@@ -29,6 +29,7 @@ struct Shape {
     int M, N, K;
     int epi;   // 0 plain bf16 out, 1 bias+gelu bf16 out, 2 fp32 residual (in place) fp32 out, 3 bias bf16 out,
                // 4 fused q|k|v heads (RMSNorm, transposed V; L = M, H = N / 192), 5 the same with bias and row-major V, L = 257
+               // 6 fp32 out + residual broadcast over 2048 rows (the decoder's out-projection), 7 fp32 out, no residual
 };
 
 static unsigned short f2bf(float f) {
@@ -58,11 +59,12 @@ int main(int argc, char** argv) {
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", libp.c_str(), dlerror()); return 2; }
     auto gemm = (int (*)(const m324_gemm_args*, void*))dlsym(h, "m324_gemm");
     auto lasterr = (int (*)(char*, int))dlsym(h, "m324_last_error");
+    auto settun = (int (*)(const char*, int))dlsym(h, "m324_set_tunable");
 
     const Shape shapes[] = {
         {"trunk qkv", 10368, 2304, 768, 0},   {"trunk fc+res", 10368, 768, 768, 2},  {"trunk fc1 gelu", 10368, 3072, 768, 1},
         {"trunk fc2+res", 10368, 768, 3072, 2}, {"dino qkv", 8224, 2304, 768, 3},     {"dino fc1 gelu", 8224, 3072, 768, 1},
-        {"dino fc2+res", 8224, 768, 3072, 2},  {"dino fc+res", 8224, 768, 768, 2}, {"dec fc+res", 65536, 768, 768, 2},    {"dec fc1 gelu", 65536, 3072, 768, 1},
+        {"dino fc2+res", 8224, 768, 3072, 2},  {"dino fc+res", 8224, 768, 768, 2}, {"dec fc+res", 65536, 768, 768, 2}, {"dec fc+bres", 65536, 768, 768, 6}, {"dec fc f32", 65536, 768, 768, 7}, {"dec fc bf16", 65536, 768, 768, 0},    {"dec fc1 gelu", 65536, 3072, 768, 1},
         {"dec fc1 plain", 65536, 3072, 768, 0}, {"dec fc2+res", 65536, 768, 3072, 2}, {"square 4096", 4096, 4096, 4096, 0},
         {"square 8192", 8192, 8192, 8192, 0},   {"pcd fc2", 64, 768, 3072, 2},         {"pcd fc1 gelu", 64, 3072, 768, 1},
         {"pcd qkv", 64, 2304, 768, 0},          {"pcd fc", 64, 768, 768, 2},
@@ -84,7 +86,8 @@ int main(int argc, char** argv) {
         for (auto& v : hb) v = (rand() / (float)RAND_MAX - 0.5f);
         void *dA, *dW, *dC, *dRef, *dR0 = nullptr;
         float* db;
-        const size_t osz = s.epi == 2 ? 4 : 2;
+        const bool f32out = s.epi == 2 || s.epi == 6 || s.epi == 7;
+        const size_t osz = f32out ? 4 : 2;
         HIP_OK(hipMalloc(&dA, nA * 2));
         HIP_OK(hipMalloc(&dW, nW * 2));
         HIP_OK(hipMalloc(&dC, nC * osz));
@@ -102,13 +105,21 @@ int main(int argc, char** argv) {
         m324_gemm_args a;
         memset(&a, 0, sizeof a);
         a.A = dA; a.lda = s.K; a.W = dW; a.ldw = s.K; a.C = dC; a.ldc = s.N;
-        a.M = s.M; a.N = s.N; a.K = s.K; a.in_dtype = M324_BF16; a.out_dtype = s.epi == 2 ? M324_F32 : M324_BF16;
+        a.M = s.M; a.N = s.N; a.K = s.K; a.in_dtype = M324_BF16; a.out_dtype = f32out ? M324_F32 : M324_BF16;
         a.bias = (s.epi == 1 || s.epi == 3) ? db : nullptr;
         a.act = s.epi == 1 ? M324_ACT_GELU : M324_ACT_NONE;
         if (s.epi == 2) { a.residual = (const float*)dC; a.ldr = s.N; }
+        void* dBR = nullptr;
+        if (s.epi == 6) {
+            std::vector<float> hbr((size_t)2048 * s.N);
+            for (auto& v : hbr) v = (rand() / (float)RAND_MAX - 0.5f);
+            HIP_OK(hipMalloc(&dBR, hbr.size() * 4));
+            HIP_OK(hipMemcpy(dBR, hbr.data(), hbr.size() * 4, hipMemcpyHostToDevice));
+            a.residual = (const float*)dBR; a.ldr = s.N; a.res_rows = 2048;
+        }
         void *dQ = nullptr, *dK = nullptr, *dV = nullptr;
         float* dnw = nullptr;
-        if (s.epi >= 4) {      // outputs go to Q / K / V; the correctness column then compares nothing (C untouched)
+        if (s.epi == 4 || s.epi == 5) {      // outputs go to Q / K / V; the correctness column then compares nothing (C untouched)
             const size_t third = (size_t)s.M * (s.N / 3) * 2;
             HIP_OK(hipMalloc(&dQ, third)); HIP_OK(hipMalloc(&dK, third)); HIP_OK(hipMalloc(&dV, third));
             std::vector<float> ones(64, 1.0f);
@@ -122,9 +133,7 @@ int main(int argc, char** argv) {
             a.qkv_L = s.epi == 4 ? s.M : 257;
         }
         auto run = [&](int variant, void* out) {
-            char env[16];
-            snprintf(env, sizeof env, "v%d", variant);
-            if (variant) setenv("M324_GEMM", env, 1); else unsetenv("M324_GEMM");
+            settun("M324_GEMM", variant);
             m324_gemm_args b = a;
             b.C = out;
             if (s.epi == 2) b.residual = (const float*)out;
@@ -179,6 +188,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
         hipFree(dA); hipFree(dW); hipFree(dC); hipFree(dRef); hipFree(db);
         if (dR0) hipFree(dR0);
+        if (dBR) hipFree(dBR);
         if (dQ) { hipFree(dQ); hipFree(dK); hipFree(dV); hipFree(dnw); }
     }
     return 0;
