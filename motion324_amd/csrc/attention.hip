@@ -57,7 +57,7 @@ template <bool PRESCALED, int NQ, int NWV, bool VROW = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
-                                                        int Lkp, float scale_log2e, float* __restrict__ lse, int nqt) {
+                                                        int Lkp, float scale_log2e, float* __restrict__ lse, int nqt, int xflags) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * ASTAGE];   // [stage][K | Vt]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,6 +143,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_
     const int nt = (Lk + KV - 1) / KV;
     issue_tile(0);
     if (nt > 1) issue_tile(1);
+    // Static priority for the second-dispatched half of an 8-wave workgroup (experiment switch M324_ATTN_EXP bit 0): the
+    // younger wave of a SIMD loses every VALU arbitration against its older partner (microarch guide, "two waves per SIMD",
+    // item 4); one s_setprio for the whole loop, no per-segment flips.
+    if (NWV == 8 && (xflags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // lane part of a K / Vt fragment address: row l31 of a 32-row block, chunk hi swizzled by the row.  k-step ks toggles
+    // chunk bits 1-2, i.e. XORs the byte offset with ks << 5, and the stage base (a multiple of 16 KiB) can be added
+    // before that XOR: one v_add per tile + one v_xor per read replace the full swizzle arithmetic per read (35 of the
+    // ~150 VALU instructions of a tile, in a kernel whose VALU time equals its MFMA time).
+    const int ko0 = k_off(l31, hi);
 
     for (int t = 0; t < nt; ++t) {
         // tile t landed (this wave's 4 pieces; tile t+1's may still fly), then the barrier publishes every
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_
         if (t + 2 < nt) issue_tile(t + 2);
         const unsigned char* sk = smem + (t % 3) * ASTAGE;
         const unsigned char* sv = sk + 8192;
+        const int kos = ko0 + (t % 3) * ASTAGE;
 
         // ---- S'^T = K Q^T - m_ref : two 32-key blocks per query block
         f32x16 s[NQ][2];
@@ -169,7 +179,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+#ifdef M324_ATTN_OLDADDR      // tools/ A/B builds only
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
+#else
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kb * 4096 + (kos ^ (ks << 5)));
+#endif
 #pragma unroll
                 for (int n = 0; n < NQ; ++n)
                     s[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[n][ks], s[n][kb], 0, 0, 0);
@@ -264,7 +278,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_
                     const a_s16x8_t v8 = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
                     vf = __builtin_bit_cast(bf16x8, v8);
                 } else {
+#ifdef M324_ATTN_OLDADDR
                     vf = *reinterpret_cast<const bf16x8*>(sv + k_off(db * 32 + l31, 2 * j + hi));
+#else
+                    vf = *reinterpret_cast<const bf16x8*>(smem + 8192 + db * 4096 + (kos ^ (j << 5)));
+#endif
                 }
 #pragma unroll
                 for (int n = 0; n < NQ; ++n)
@@ -710,12 +728,13 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         // grid then ends in a partly filled round -- latency hiding wins over round quantisation.
         // M324_ATTN_OCC=2 pads the LDS allocation to force two per CU (experiments only).
         const unsigned pad = m324::tunable(m324::TUN_ATTN_OCC) == 2 ? 24 * 1024 : 0;
+        const int xfl = m324::tunable(m324::TUN_ATTN_EXP);
 #define M324_ATTN(PS, NQ, NWV)                                                                                          \
     hipLaunchKernelGGL((attn_bf16_kernel<PS, NQ, NWV>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,         \
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt)
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt, xfl)
 #define M324_ATTN_VR(PS, NWV)                                                                                            \
     hipLaunchKernelGGL((attn_bf16_kernel<PS, 1, NWV, true>), g2, dim3(NWV * 64), pad, s, (const bf16_t*)Q, q_bstride,    \
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt)
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt, xfl)
         if (vrow) {
             if (q_prescaled) { if (w8) M324_ATTN_VR(true, 8); else M324_ATTN_VR(true, 4); }
             else { if (w8) M324_ATTN_VR(false, 8); else M324_ATTN_VR(false, 4); }

@@ -1038,12 +1038,6 @@ static int pick_variant(const m324_gemm_args* a) {
     if (f == 1 || f == 2 || f == 5) return f;
     if (f == 7) return bf16 ? 7 : 5;
     if (f >= 10 && f <= 13) return ring_ok ? f : (bf16 ? (f == 13 ? 2 : 7) : (f == 13 ? 2 : 5));
-    // v14 (deferred epilogue): at least five K-stages carry the four epilogue steps; whole 128-column tiles; no aux operand
-    const bool dfe_ok = ring_ok && a->K >= 576 && a->N % 128 == 0 && a->M % 16 == 0 && a->aux_mode == 0 &&
-                        a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M || (a->res_rows % 16 == 0 && a->res_rows >= 256)) &&
-                        (long)a->M * a->lda * 2 < 0x7FFFFFFFl && (long)a->N * a->ldw * 2 < 0x7FFFFFFFl &&
-                        (long)a->M * a->ldc * 4 < 0x7FFFFFFFl && (!a->residual || (long)a->M * a->ldr * 4 < 0x7FFFFFFFl);
-    if (f == 14) return dfe_ok ? 14 : (ring_ok ? 12 : 2);
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
@@ -1073,7 +1067,7 @@ static int pick_variant(const m324_gemm_args* a) {
 
 template <typename TOUT, int ACT, int RES>
 static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
-    if (variant == 11 || variant == 12 || variant == 14) return m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap(), variant);
+    if (variant == 11 || variant == 12) return m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap(), variant);
     if (variant == 13) {
         hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN) * ceil_div(a->M, BM)), dim3(256), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
@@ -1178,7 +1172,6 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
         case 11: name = "gemm_ring4_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;
         case 12: name = "gemm_ring3_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); break;
         case 13: name = "gemm_ring2_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
-        case 14: name = "gemm_dfe_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;
         default: break;
     }
     if (variant == 1) snprintf(buf, (size_t)n, "%s<%s, %s> grid=%ld", name, tin, tout, wg * threads);

@@ -289,10 +289,21 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             const int mb = mw + i * 32 + rr;       // row of pass p: mb + 4 p
             float4 res[8], az[8];
             if (has_res) {
+                // broadcast residual (the decoder's out-projection: the same 2048 point rows under every frame): ONE
+                // division per 32-row block, then a compare-subtract per pass (an integer modulo per row cost this
+                // epilogue 25 us of the 115 us GEMM); periods shorter than a block keep the per-row form
+                const bool wrap = res_mod && ep.res_rows >= 32;
+                const int mb0 = wrap ? mb % ep.res_rows : mb;
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
-                    int mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
-                    if (res_mod) mr %= ep.res_rows;
+                    int mr;
+                    if (wrap) {
+                        mr = mb0 + 4 * p;
+                        mr = mr >= ep.res_rows ? mr - ep.res_rows : mr;
+                    } else {
+                        mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
+                        if (res_mod) mr %= ep.res_rows;
+                    }
                     res[p] = *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
                 }
             }

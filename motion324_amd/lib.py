@@ -10,7 +10,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libm324.so")
+LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      # M324_LIB: lab builds (tools/lablibs)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1

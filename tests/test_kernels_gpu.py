@@ -659,75 +659,3 @@ def test_mse():
     out = ops.mse(a.to(DEV), b.to(DEV), 0.5)
     assert abs(float(out) - 0.5 * float(((a.double() - b.double()) ** 2).mean())) < 1e-6
 
-
-# ------------------------------------------------------------------------------------------------ v14: deferred epilogue
-@pytest.mark.parametrize("M,N,K", [(4096 + 48, 768, 768),      # 17 x 6 = 102 tiles (< CUs): every workgroup drains its only tile
-                                    (10368, 2304, 768),         # 41 x 18 = 738 tiles: 2-3 per workgroup, ragged last row of tiles
-                                    (8224, 768, 3072),          # K = 3072: 48 K-stages, 39 of them without a slot
-                                    (2048 * 5, 3072, 640)])     # ten K-stages (the shortest the nine slots + 1 allow)
-def test_gemm_deferred_epilogue_schedule(tune, M, N, K):
-    """v14 (persistent 256 x 128 tiles, the previous tile's epilogue drained under the next tile's MFMAs): bf16 outputs with
-    bias + GELU and plain, the in-place fp32 residual stream with bias + LayerScale, and a residual that repeats every 2048
-    rows (the decoder's out-projection) -- vs fp64, and bit for bit vs the 128 x 128 kernel (same k order) where no GELU
-    polynomial is involved."""
-    ops = _ops()
-    from motion324_amd.lib import ACT_GELU
-    dtype = torch.bfloat16
-    a, w = _q(_rand((M, K), 61), dtype), _q(_rand((N, K), 62, 0.1), dtype)
-    bias, gamma = _rand((N,), 63), 1 + 0.1 * _rand((N,), 64)
-    ad, wd, bd, gd = a.to(dtype).to(DEV), w.to(dtype).to(DEV), bias.to(DEV), gamma.to(DEV)
-    v = a.double() @ w.double().T
-    g = 0.5 * (v + bias.double()) * (1 + torch.erf((v + bias.double()) / math.sqrt(2.0)))
-    x0 = _rand((M, N), 65)
-    bres = _rand((2048, N), 66)
-
-    def run_all():
-        o1 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
-        ops.gemm(ad, wd, o1, bias=bd, act=ACT_GELU)
-        o2 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
-        ops.gemm(ad, wd, o2)
-        x = x0.clone().to(DEV)
-        ops.gemm(ad, wd, x, bias=bd, gamma=gd, residual=x)
-        y = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
-        if M % 2048 == 0:
-            ops.gemm(ad, wd, y, residual=bres.to(DEV), res_rows=2048)
-        return o1, o2, x, y
-    tune("M324_GEMM", "v14")
-    o1, o2, x, y = run_all()
-    assert rel_err(o1.float(), g) < TOL[dtype]
-    assert rel_err(o2.float(), v) < TOL[dtype]
-    assert rel_err(x, x0.double() + (v + bias.double()) * gamma.double()) < 1e-5
-    if M % 2048 == 0:
-        assert rel_err(y, v + bres.double().repeat(M // 2048, 1)) < 1e-5
-    tune("M324_GEMM", "v2")
-    r1, r2, rx, ry = run_all()
-    assert torch.equal(o2, r2) and torch.equal(x, rx)
-    if M % 2048 == 0:
-        assert torch.equal(y, ry)
-    assert rel_err(o1.float(), r1.float()) < 1e-6 or torch.equal(o1, r1)
-
-
-def test_gemm_deferred_epilogue_is_race_free(tune):
-    """Forty launches at the trunk's q|k|v shape: bit-identical results, equal to the 128 x 128 kernel's."""
-    ops = _ops()
-    dtype = torch.bfloat16
-    M, N, K = 10368, 2304, 768
-    a = _q(_rand((M, K), 41), dtype).to(dtype).to(DEV)
-    w = _q(_rand((N, K), 42, 0.05), dtype).to(dtype).to(DEV)
-    tune("M324_GEMM", "v2")
-    ref = torch.empty((M, N), dtype=dtype, device=DEV)
-    ops.gemm(a, w, ref)
-    x0 = _rand((M, N), 43).to(DEV)
-    xr = x0.clone()
-    ops.gemm(a, w, xr, residual=xr)
-    tune("M324_GEMM", "v14")
-    outs = [torch.empty((M, N), dtype=dtype, device=DEV) for _ in range(4)]
-    for it in range(40):
-        ops.gemm(a, w, outs[it % 4])
-        if it % 4 == 3:
-            for o in outs:
-                assert torch.equal(o, ref), f"launch {it}: result differs"
-    for it in range(10):
-        x = x0.clone()
-        ops.gemm(a, w, x, residual=x)
-        assert torch.equal(x, xr), f"residual launch {it}: result differs"

@@ -4,7 +4,7 @@ usage: tools/microbench.py [gemm|attn|all] [--iters N] [--only SUBSTR]"""
 import argparse, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from motion324_amd import ops
+from motion324_amd import lib, ops
 from motion324_amd.lib import ACT_GELU
 
 ap = argparse.ArgumentParser()
@@ -25,9 +25,9 @@ def timeit(fn, iters):
         res = {v: [] for v in vals}
         for rnd in range(6):
             for v in vals:
-                os.environ[var] = v
+                lib.set_tunable(var, int(v.lstrip("vV")))           # the library reads its environment once, at load
                 res[v].append(_timeit(fn, max(3, iters // 4)))
-        os.environ.pop(var, None)
+        lib.set_tunable(var)
         med = {v: sorted(t)[len(t) // 2] for v, t in res.items()}
         print("   A/B " + "  ".join(f"{var}={v}: {m * 1e3:.1f} us" for v, m in med.items()))
         return min(med.values())
