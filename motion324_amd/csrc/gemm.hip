@@ -1164,7 +1164,7 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
     const char* name = "gemm_kernel";
     switch (variant) {
         case 1: wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
-        case 2: name = "gemm_glds_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) * nbatch; break;
+        case 2: name = "gemm_glds_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
         case 5: name = "gemm_glds5_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
         case 7: name = "gemm_pipe_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
         case 9: name = "gemm_skinny_kernel"; wg = ceil_div(a->N, 32); threads = 512; break;
@@ -1174,10 +1174,13 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
         case 13: name = "gemm_ring2_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
         default: break;
     }
-    if (variant == 1) snprintf(buf, (size_t)n, "%s<%s, %s> grid=%ld", name, tin, tout, wg * threads);
-    else if (variant == 9) snprintf(buf, (size_t)n, "%s<%s, %d> grid=%ld", name, tout, act ? 1 : 0, wg * threads);
-    else if (variant == 2 || variant == 5) snprintf(buf, (size_t)n, "%s<%s, %s, %d, %d> grid=%ld", name, tin, tout, act, rs, wg * threads);
-    else snprintf(buf, (size_t)n, "%s<%s, %d, %d> grid=%ld", name, tout, act, rs, wg * threads);
+    // grid in threads, as rocprofv3's kernel trace prints it (x, y, z)
+    if (variant == 1)
+        snprintf(buf, (size_t)n, "%s<%s, %s> grid=%dx%dx1", name, tin, tout, ceil_div(a->N, BN) * 256, ceil_div(a->M, BM));
+    else if (variant == 9) snprintf(buf, (size_t)n, "%s<%s, %d> grid=%ldx1x1", name, tout, act ? 1 : 0, wg * threads);
+    else if (variant == 2) snprintf(buf, (size_t)n, "%s<%s, %s, %d, %d> grid=%ldx%dx1", name, tin, tout, act, rs, wg * threads, nbatch);
+    else if (variant == 5) snprintf(buf, (size_t)n, "%s<%s, %s, %d, %d> grid=%ldx1x1", name, tin, tout, act, rs, wg * threads);
+    else snprintf(buf, (size_t)n, "%s<%s, %d, %d> grid=%ldx1x1", name, tout, act, rs, wg * threads);
     return variant;
 }
 

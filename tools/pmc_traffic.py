@@ -20,8 +20,33 @@ def load(path, name):
 
 
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-if "--json" in sys.argv:        # per kernel class (the names bench.py's roofline object uses) -> profiles/rNN_traffic.json
+def symbol(raw):
+    """'void (anonymous namespace)::attn_bf16_kernel<true, 1, 8, false>(unsigned short const*, ...' -> the template id"""
+    k = raw
+    if "::" in k and "anonymous" in k:
+        k = k[k.find("::") + 2:]
+    depth = 0
+    for i, ch in enumerate(k):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return k[:i]
+    return k
+
+
+def load_full(path, name):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name:
+            continue
+        acc[symbol(r["Kernel_Name"])][0] += 1
+        acc[symbol(r["Kernel_Name"])][1] += float(r["Counter_Value"])
+    return acc
+
+
+if "--json" in sys.argv:        # per kernel SYMBOL (what bench.py's roofline rows are keyed by) + the two classes -> profiles/rNN_traffic.json
     import json
+    ff, wf = load_full(sys.argv[1], "FETCH_SIZE"), load_full(sys.argv[2], "WRITE_SIZE")
     out = {"note": "HBM bytes per launch from rocprofv3 PMC (separate FETCH_SIZE and WRITE_SIZE passes over `bench.py --eager "
                    "--steps 2 --warmup 1`); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); "
                    "KB -> bytes x1024"}
@@ -33,6 +58,11 @@ if "--json" in sys.argv:        # per kernel class (the names bench.py's rooflin
         if nf and nw:
             out[cls] = {"launches": nf, "fetch_bytes_per_launch": round(fb / nf), "write_bytes_per_launch": round(wb / nw),
                         "traffic_bytes_per_launch": round(fb / nf + wb / nw)}
+    for k in ff:
+        if k in wf and (k.startswith("gemm_") or k.startswith("attn_")):
+            fb, wb = ff[k][1] * 2.0 * 1024 / ff[k][0], wf[k][1] * 1024 / wf[k][0]
+            out[k] = {"launches": ff[k][0], "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+                      "traffic_bytes_per_launch": round(fb + wb)}
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 print("| kernel | launches | fetch MB/launch (x2 corrected) | write MB/launch | total MB/launch |")
 print("|---|---|---|---|---|")
