@@ -123,12 +123,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
     // 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): give every
     // XCD a contiguous range of logical tiles = whole A row-panels with all their column tiles, so a panel
     // is pulled into ONE XCD's L2 and re-used by its ntn column tiles instead of being fetched by all eight.
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, (M + BM - 1) / BM, ntn, xcd_remap, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
     A += (long)blockIdx.y * ep.strideA;      // batched launch (split-K weight gradients): blockIdx.y = problem index
     W += (long)blockIdx.y * ep.strideW;
     C += (long)blockIdx.y * ep.strideC;
@@ -197,12 +194,9 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * BM5, n0 = (lid % ntn) * BN5;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, (M + BM5 - 1) / BM5, ntn, xcd_remap, tm, tn);
+    const int m0 = tm * BM5, n0 = tn * BN5;
 
     // staging: 32 row groups of 8 rows per operand; wave w takes groups w*4 .. w*4+3 of A and of W
     const TIN* ga[4];
@@ -310,12 +304,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const bf16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * BM5, n0 = (lid % ntn) * BN5;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, (M + BM5 - 1) / BM5, ntn, xcd_remap, tm, tn);
+    const int m0 = tm * BM5, n0 = tn * BN5;
 
     // LDS-DMA: a wave-instruction fills 16 rows x 64 B; wave w moves row groups 2w, 2w+1 of A and of W
     const bf16_t* ga[2];
@@ -434,12 +425,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * BM5, n0 = (lid % ntn) * BN5;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, (M + BM5 - 1) / BM5, ntn, xcd_remap, tm, tn);
+    const int m0 = tm * BM5, n0 = tn * BN5;
 
     // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
     const bf16_t* ga[4];
@@ -582,12 +570,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, (M + BM - 1) / BM, ntn, xcd_remap, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
 
     // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
     const bf16_t* ga[4];
@@ -1024,8 +1009,17 @@ static bool vec_ok(const m324_gemm_args* a) {
            (!a->gamma || al(a->gamma, 16));
 }
 
-// XCD-aware tile order (default on; M324_XCD=0 disables)
-static int xcd_remap() { return m324::tunable(m324::TUN_XCD) & 1; }
+// Tile-order mode of tile_of(): M324_XCD bit 0 = contiguous range per XCD, bit 1 = the 4 x 2 group order for weights that
+// do not fit an XCD's L2 beside the streaming A panels AND are wider than deep (q|k|v, fc1: measured HBM fetch -28 % / -13 %
+// at equal time; fc2's K = 3072 A panels dominate its traffic and the group order re-fetches them: +35 %), bit 2 = force
+// it (tests, lab).  Default 3.
+static int xcd_mode(const m324_gemm_args* a) {
+    const int t = m324::tunable(m324::TUN_XCD);
+    if (!(t & 1)) return 0;
+    const long wbytes = (long)a->N * a->K * (a->in_dtype == M324_BF16 ? 2 : 4);
+    if ((t & 4) || ((t & 2) && wbytes > (5l << 19) && a->N >= 2 * a->K)) return 3;
+    return 1;
+}
 
 // Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11|v12|v13 forces a variant (A/B measurements, tests).
 static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_GEMM at load / m324_set_tunable
@@ -1067,22 +1061,22 @@ static int pick_variant(const m324_gemm_args* a) {
 
 template <typename TOUT, int ACT, int RES>
 static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
-    if (variant == 11 || variant == 12) return m324::launch_ring4(a, s, ep, ACT, RES, xcd_remap(), variant);
+    if (variant == 11 || variant == 12) return m324::launch_ring4(a, s, ep, ACT, RES, xcd_mode(a), variant);
     if (variant == 13) {
         hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN) * ceil_div(a->M, BM)), dim3(256), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
-                           ceil_div(a->N, BN), xcd_remap());
+                           ceil_div(a->N, BN), xcd_mode(a));
         return M324_OK;
     }
     if (variant == 10) {
         hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
-                           ceil_div(a->N, BN5), xcd_remap());
+                           ceil_div(a->N, BN5), xcd_mode(a));
         return M324_OK;
     }
     hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
                        (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
-                       ceil_div(a->N, BN5), xcd_remap());
+                       ceil_div(a->N, BN5), xcd_mode(a));
     return M324_OK;
 }
 
@@ -1119,11 +1113,11 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
                                dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
                                a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,              \
-                               ceil_div(a->N, BN5), xcd_remap());                                                        \
+                               ceil_div(a->N, BN5), xcd_mode(a));                                                        \
         else                                                                                                             \
             hipLaunchKernelGGL((gemm_glds_kernel<TIN, TOUT, ACT, RES>), dim3(grid.x * grid.y, nbatch), dim3(256), 0, s,  \
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
-                               a->K, ep, (int)grid.x, xcd_remap());                                                      \
+                               a->K, ep, (int)grid.x, xcd_mode(a));                                                      \
     } while (0)
         if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) {
             if constexpr (sizeof(TOUT) == 2) M324_GLDS(4, 0);

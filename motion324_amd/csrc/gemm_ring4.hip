@@ -37,13 +37,10 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
     const bf16_t* gb[8];
     int m0 = 0, n0 = 0;
     auto tile_setup = [&](int t) {
-        int lid = t;
-        if (xcd_remap & 1) {
-            const int q = ntiles >> 3, r = ntiles & 7, x = lid & 7, loc = lid >> 3;
-            lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-        }
-        m0 = (lid / ntn) * BM5;
-        n0 = (lid % ntn) * BN5;
+        int tm, tn;
+        tile_of(t, ntiles, (M + BM5 - 1) / BM5, ntn, xcd_remap, tm, tn);
+        m0 = tm * BM5;
+        n0 = tn * BN5;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = (wave * 8 + i) * 8 + (lane >> 3);
@@ -195,12 +192,9 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    int lid = blockIdx.x;
-    if (xcd_remap & 1) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = lid & 7, loc = lid >> 3;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
-    const int m0 = (lid / ntn) * 256, n0 = (lid % ntn) * 128;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, (M + 256 - 1) / 256, ntn, xcd_remap, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 128;
 
     // LDS-DMA pieces of 8 rows x 128 B: wave w moves row groups 8w .. 8w+7 of A (32 groups) and 4w .. 4w+3 of W (16 groups)
     const bf16_t* g[12];

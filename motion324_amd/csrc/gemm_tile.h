@@ -126,6 +126,42 @@ __device__ __forceinline__ float apply_gelu(float v) {
     else return gelu_erf(v);
 }
 
+// Workgroup -> output tile.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (id & 7), each with
+// its own 4 MiB L2.  mode bit 0: XCD x works a CONTIGUOUS range of the tile order, so an A row panel is pulled into one
+// L2 and shared by its ntn column tiles instead of being fetched by all eight.  mode bit 1 (weights larger than an L2):
+// the tile order itself becomes 4 row groups x 2 column groups, one group per XCD -- every XCD then keeps HALF of W
+// resident and streams a quarter of A, instead of cycling all of W through its L2 once per row panel.
+__device__ __forceinline__ void tile_of(int bid, int nblocks, int ntm, int ntn, int mode, int& tm, int& tn) {
+    int p = bid;
+    tm = tn = 0;
+    if (mode & 1) {
+        const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, loc = bid >> 3;
+        p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    if (!(mode & 2)) {
+        tm = p / ntn;
+        tn = p - tm * ntn;
+        return;
+    }
+    const int rq = ntm >> 2, rr = ntm & 3, c0 = (ntn + 1) >> 1;
+    int rs = 0;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int rows = rq + (rg < rr);
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const int cols = cg ? ntn - c0 : c0, size = rows * cols;
+            if (p >= 0 && p < size) {
+                const int rl = p / cols;
+                tm = rs + rl;
+                tn = (cg ? c0 : 0) + (p - rl * cols);
+            }
+            p -= size;                                   // p goes negative once its group is found
+        }
+        rs += rows;
+    }
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 

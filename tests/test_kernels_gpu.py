@@ -164,6 +164,33 @@ def test_gemm_chunk_ring_many_tiles(tune, variant):
     assert torch.equal(x, x2)
 
 
+@pytest.mark.parametrize("variant", ["v2", "v5", "v7", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("M,N", [(20 * 256 - 37, 1300), (129, 128), (3 * 256, 7 * 256), (1100, 260)])
+def test_gemm_grouped_tile_order_covers_every_tile_once(tune, variant, M, N):
+    """M324_XCD=7 forces the 4 x 2 group tile order (gemm_tile.h tile_of; chosen by default only for weights larger than
+    an XCD's L2): every output tile must be produced exactly once whatever the tile counts (fewer row tiles than row
+    groups, odd column counts, ragged edges), and bit-identical to the row-major order."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    K = 192
+    a, w = _q(_rand((M, K), 61), dtype).to(dtype).to(DEV), _q(_rand((N, K), 62, 0.1), dtype).to(dtype).to(DEV)
+    tune("M324_GEMM", variant)
+    tune("M324_XCD", 1)
+    ref = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a, w, ref)
+    assert not bool(torch.isnan(ref.float()).any())
+    x0 = _rand((M, N), 63).to(DEV)
+    xr = x0.clone()
+    ops.gemm(a, w, xr, residual=xr)
+    tune("M324_XCD", 7)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a, w, out)
+    assert torch.equal(out, ref)
+    x = x0.clone()
+    ops.gemm(a, w, x, residual=x)                      # in place: a tile produced twice would add its product twice
+    assert torch.equal(x, xr)
+
+
 @pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("M,N,K", [(65, 8, 128), (37, 200, 128), (300, 136, 192), (513, 260, 128), (256, 256, 128), (257, 132, 320)])
 def test_gemm_ring_edge_shapes(tune, variant, M, N, K):

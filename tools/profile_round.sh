@@ -17,7 +17,7 @@ python3 tools/pmc_traffic.py "$f" "$w" --json $out/traffic.json > $out/traffic.m
 # matrix-pipe / VALU utilisation of every kernel (one more PMC pass: SQ + GRBM counters only)
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/pmc_sq -o pmc --output-format csv -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --sustain 0 > /dev/null 2> $out/pmc_sq.err
 q=$(find $out/pmc_sq -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_util.py "$q" > $out/utilisation.md
+python3 tools/pmc_util.py "$q" > $out/utilisation.md 2> $out/utilisation.err
 rm -rf $out/pmc_sq
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
 ls -la $out
