@@ -296,6 +296,8 @@ def run_infer(args, D: Dist):
     sample_np = synth.synth_inputs(w["B"], w["T"], w["N"], w["S"], w["HW"], seed=1 + rank)
     sample = {k: torch.from_numpy(v).to(dev) for k, v in sample_np.items()}
     m.set_precision(args.precision)
+    from motion324_amd import image_encoder
+    image_encoder.TWO_STREAMS = args.dino_streams == 2
 
     fast = None if args.eager else m.GraphedForward(model)
     # --clips-in-flight 2: a second graph with its own static buffers on a second stream; step i runs on stream i % 2
@@ -518,6 +520,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-in-flight", action="store_true", help="infer mode: skip the extra two-clips-in-flight measurement")
     ap.add_argument("--eager", action="store_true", help="time eager per-kernel launches instead of hipGraph replay")
+    ap.add_argument("--dino-streams", type=int, default=2, choices=[1, 2],
+                    help="image encoder inside the hipGraph: 2 = two half-batches of frames as two branches (default), 1 = one chain (A/B)")
     ap.add_argument("--clips-in-flight", type=int, default=1, choices=[1, 2],
                     help="2: consecutive steps alternate between two HIP streams / graphs, so one clip's kernels fill the "
                          "partly filled last round of the other's (throughput mode; the default 1 is one clip at a time)")

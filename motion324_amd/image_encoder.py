@@ -24,6 +24,15 @@ from .prepared import Prepared, pad_k
 from .transformer import fuse_qkv
 
 DINO_EPS = 1e-6
+TWO_STREAMS = True       # run(): under graph capture, two half-batches of frames as two branches (see the comment there)
+_STREAMS = {}
+
+
+def _second_stream(dev: torch.device) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _STREAMS:
+        _STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return _STREAMS[idx]
 
 
 class _Attention(nn.Module):
@@ -122,7 +131,7 @@ class DinoEncoder(nn.Module):
         self.model.eval()
         return self
 
-    def run(self, P: Prepared, video: torch.Tensor) -> torch.Tensor:
+    def run(self, P: Prepared, video: torch.Tensor, two_streams: bool = True) -> torch.Tensor:
         """video [F, Hin, Win, 3] fp32 in [0,1] (channel-last, any size) -> pre-final-norm tokens
         [F * (1 + g*g), C] fp32.  Resize to 224^2 + ImageNet normalisation + im2col happen in one kernel
         (Pcd_motion.py:470-472, dinov2.py:78-80)."""
@@ -144,23 +153,51 @@ class DinoEncoder(nn.Module):
         else:
             qkv = torch.empty((Fr * Lt, 3 * C), dtype=P.dtype, device=video.device)
         h1 = torch.empty((Fr * Lt, m.blocks[0].mlp.fc1.out_features), dtype=P.dtype, device=video.device)
-        for blk in m.blocks:
-            ops.layernorm(x, P.vec(blk.norm1.weight), P.vec(blk.norm1.bias), DINO_EPS, h)
+        # every weight in its compute form BEFORE the fork below (a cold cache converts on the current stream)
+        W = [dict(n1=(P.vec(b.norm1.weight), P.vec(b.norm1.bias)), qkv=(P.mat(b.attn.qkv.weight), P.vec(b.attn.qkv.bias)),
+                  proj=(P.mat(b.attn.proj.weight), P.vec(b.attn.proj.bias), P.vec(b.ls1.gamma)),
+                  n2=(P.vec(b.norm2.weight), P.vec(b.norm2.bias)), fc1=(P.mat(b.mlp.fc1.weight), P.vec(b.mlp.fc1.bias)),
+                  fc2=(P.mat(b.mlp.fc2.weight), P.vec(b.mlp.fc2.bias), P.vec(b.ls2.gamma))) for b in m.blocks]
+
+        def block(w, f0, f1):
+            """One ViT block on frames f0 .. f1 (rows f0*Lt .. f1*Lt of every buffer), on the current stream."""
+            r = slice(f0 * Lt, f1 * Lt)
+            ops.layernorm(x[r], *w["n1"], DINO_EPS, h[r])
             if fused:
-                ops.gemm(h, P.mat(blk.attn.qkv.weight), None, bias=P.vec(blk.attn.qkv.bias),
-                         qkv_heads=(Qh, Kh, Vh, None, None, 0.0, ops.Q_PRESCALE, Lt, H))
-                ops.attention(Qh, Kh, Vh, h, prescaled=True, v_rowmajor=True)
+                ops.gemm(h[r], w["qkv"][0], None, bias=w["qkv"][1],
+                         qkv_heads=(Qh[f0:f1], Kh[f0:f1], Vh[f0:f1], None, None, 0.0, ops.Q_PRESCALE, Lt, H))
+                ops.attention(Qh[f0:f1], Kh[f0:f1], Vh[f0:f1], h[r], prescaled=True, v_rowmajor=True)
             else:
-                ops.gemm(h, P.mat(blk.attn.qkv.weight), qkv, bias=P.vec(blk.attn.qkv.bias))
-                Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, None, 0.0, Fr, Lt, H, P.dtype,
+                ops.gemm(h[r], w["qkv"][0], qkv[r], bias=w["qkv"][1])
+                Q, K, Vt = ops.qkv_split(qkv[r, :C], qkv[r, C:2 * C], qkv[r, 2 * C:], None, None, 0.0, f1 - f0, Lt, H, P.dtype,
                                          q_scale=ops.Q_PRESCALE)
-                ops.attention(Q, K, Vt, h, prescaled=True)
-            ops.gemm(h, P.mat(blk.attn.proj.weight), x, bias=P.vec(blk.attn.proj.bias), gamma=P.vec(blk.ls1.gamma),
-                     residual=x)
-            ops.layernorm(x, P.vec(blk.norm2.weight), P.vec(blk.norm2.bias), DINO_EPS, h)
-            ops.gemm(h, P.mat(blk.mlp.fc1.weight), h1, bias=P.vec(blk.mlp.fc1.bias), act=ACT_GELU)
-            ops.gemm(h1, P.mat(blk.mlp.fc2.weight), x, bias=P.vec(blk.mlp.fc2.bias), gamma=P.vec(blk.ls2.gamma),
-                     residual=x)
+                ops.attention(Q, K, Vt, h[r], prescaled=True)
+            ops.gemm(h[r], w["proj"][0], x[r], bias=w["proj"][1], gamma=w["proj"][2], residual=x[r])
+            ops.layernorm(x[r], *w["n2"], DINO_EPS, h[r])
+            ops.gemm(h[r], w["fc1"][0], h1[r], bias=w["fc1"][1], act=ACT_GELU)
+            ops.gemm(h1[r], w["fc2"][0], x[r], bias=w["fc2"][1], gamma=w["fc2"][2], residual=x[r])
+
+        # Frames are independent through the whole ViT.  At the BASELINE clip (32 x 257 = 8224 rows) every GEMM of a
+        # block fills only ~76 % of its last round of workgroups (33 x 12 tiles of 256 x 256 on 256 CUs = 1.55 rounds);
+        # two half-batches as two branches of the hipGraph let one half's workgroups take the CUs the other half's last
+        # round leaves idle (tools/overlap_lab: q|k|v and fc1 -13 % per pair of half launches, out-projection and fc2
+        # unchanged; the whole encoder 2.46 -> 2.38 ms, the clip -1 %).  Only while a graph is being captured: an eager
+        # pass would pay twice the host launches for it (Python enqueues ~14 us per launch, a half GEMM runs 9 - 20 us),
+        # and results are bit-identical either way (rows are independent, every tile kernel sums k in the same order).
+        side = None
+        if TWO_STREAMS and two_streams and Fr >= 8 and torch.cuda.is_current_stream_capturing():
+            side = _second_stream(video.device)
+        if side is None:
+            for w in W:
+                block(w, 0, Fr)
+            return x
+        main, Fh = torch.cuda.current_stream(video.device), (Fr + 1) // 2
+        side.wait_stream(main)
+        for w in W:
+            block(w, 0, Fh)
+            with torch.cuda.stream(side):
+                block(w, Fh, Fr)
+        main.wait_stream(side)
         return x
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:

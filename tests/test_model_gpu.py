@@ -192,6 +192,43 @@ def test_graph_replay_matches_eager():
     assert not torch.equal(a, b)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_image_encoder_two_graph_branches_match_one_chain(precision):
+    """Under graph capture the image encoder runs its frames as two half-batches on two streams (two branches of the
+    hipGraph, image_encoder.py run()); rows are independent, so the replayed result must equal the eager single-chain
+    pass bit for bit -- 9 frames: uneven halves of 5 and 4."""
+    import motion324_amd as m
+    from motion324_amd import image_encoder
+    from motion324_amd.prepared import Prepared, compute_dtype
+    torch.manual_seed(5)
+    enc = image_encoder.DinoEncoder(depth=2).cuda()
+    video = torch.rand(9, 112, 96, 3, device="cuda")
+    m.set_precision(precision)
+    try:
+        P = Prepared.for_module(enc, video.device, compute_dtype())
+        with torch.no_grad():
+            eager = enc.run(P, video).clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                enc.run(P, video)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            outs = {}
+            for two in (True, False):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = enc.run(P, video, two_streams=two)
+                out.zero_()
+                g.replay()
+                torch.cuda.synchronize()
+                outs[two] = out.clone()
+    finally:
+        m.set_precision(None)
+    assert bool(torch.isfinite(eager).all())
+    assert torch.equal(outs[True], eager) and torch.equal(outs[False], eager)
+
+
 def _fp_worker(rank, world, port, case, precision, ret):
     """One process per rank, all on cuda:0 (single-GPU box): the collective goes through gloo, which carries
     CUDA tensors through host memory -- the code path of forward_frame_parallel is the one RCCL would run."""
