@@ -55,38 +55,76 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * phi;
 }
 
-// Two GELUs per instruction stream for the bf16 epilogue: erf(z) = z P(z^2) on |z| <= 3 (odd minimax polynomial, 9
-// coefficients, |erf error| <= 1.7e-5; beyond the clamp erf(3) = 0.99998 stands in for 1), evaluated with packed fp32
-// FMAs (v_pk_fma_f32) and no transcendental.  |GELU error| <= 7e-5 absolute -- below the bf16 rounding step of every
-// output larger than 0.02 -- at about a third of the issue slots of the rcp/exp form above.
+// Two GELUs per instruction stream for the bf16 epilogue: GELU(x) = x (1/2 + u Q(u^2)), u = clamp(x, +-3 sqrt 2), with
+// u Q(u^2) = erf(u / sqrt 2) / 2 as an odd minimax polynomial (9 coefficients, |erf error| <= 1.7e-5; beyond the clamp
+// erf(3) = 0.99998 stands in for 1), evaluated with packed fp32 FMAs (v_pk_fma_f32) and no transcendental: 13 VALU
+// instructions per pair.  |GELU error| <= 6e-5 absolute -- below the bf16 rounding step of every output larger than 0.02.
 typedef float f32x2v __attribute__((ext_vector_type(2)));
+#define M324_GELU_Q8 5.626603458e-11f
+#define M324_GELU_Q7 -5.371752709e-09f
+#define M324_GELU_Q6 2.268262506e-07f
+#define M324_GELU_Q5 -5.646163474e-06f
+#define M324_GELU_Q4 9.359017959e-05f
+#define M324_GELU_Q3 -1.109398132e-03f
+#define M324_GELU_Q2 9.818113584e-03f
+#define M324_GELU_Q1 -6.634691738e-02f
+#define M324_GELU_Q0 3.989031257e-01f
+#define M324_GELU_CLAMP 4.2426405f
+// N independent pairs, one Horner step of every pair before the next step of any: a dependent v_pk_fma_f32 needs a wait
+// state, and the compiler otherwise emits the pairs one after another with an s_nop between all 11 dependent steps.
+template <int N>
+__device__ __forceinline__ void gelu_poly2n(f32x2v (&x)[N]) {
+    f32x2v u[N], t[N], p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        u[i].x = __builtin_amdgcn_fmed3f(x[i].x, -M324_GELU_CLAMP, M324_GELU_CLAMP);
+        u[i].y = __builtin_amdgcn_fmed3f(x[i].y, -M324_GELU_CLAMP, M324_GELU_CLAMP);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = u[i] * u[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = __builtin_elementwise_fma((f32x2v)(M324_GELU_Q8), t[i], (f32x2v)(M324_GELU_Q7));
+#define M324_GELU_STEP(C)          \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], (f32x2v)(C));
+    M324_GELU_STEP(M324_GELU_Q6)
+    M324_GELU_STEP(M324_GELU_Q5)
+    M324_GELU_STEP(M324_GELU_Q4)
+    M324_GELU_STEP(M324_GELU_Q3)
+    M324_GELU_STEP(M324_GELU_Q2)
+    M324_GELU_STEP(M324_GELU_Q1)
+    M324_GELU_STEP(M324_GELU_Q0)
+#undef M324_GELU_STEP
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = __builtin_elementwise_fma(u[i], p[i], (f32x2v)(0.5f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] * p[i];
+}
 __device__ __forceinline__ f32x2v gelu_poly2(f32x2v x) {
-    f32x2v z = x * 0.70710678118654752440f;
-    z.x = __builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f);
-    z.y = __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f);
-    const f32x2v t = z * z;
-    f32x2v p = (f32x2v)(4.074096087e-08f);
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-1.944782217e-06f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.105993727e-05f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-5.110323815e-04f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(4.235408041e-03f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-2.510281415e-02f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.110792751e-01f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(-3.753148415e-01f));
-    p = __builtin_elementwise_fma(p, t, (f32x2v)(1.128268421e+00f));
-    const f32x2v hx = x * 0.5f;
-    return __builtin_elementwise_fma(hx, z * p, hx);
+    f32x2v v[1] = {x};
+    gelu_poly2n<1>(v);
+    return v[0];
 }
 
 template <typename TOUT>
 __device__ __forceinline__ void apply_gelu4(float4& v) {
     if constexpr (sizeof(TOUT) == 2) {
-        f32x2v a = {v.x, v.y}, b = {v.z, v.w};
-        a = gelu_poly2(a);
-        b = gelu_poly2(b);
-        v = make_float4(a.x, a.y, b.x, b.y);
+        f32x2v a[2] = {{v.x, v.y}, {v.z, v.w}};
+        gelu_poly2n<2>(a);
+        v = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
     } else {
         v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+    }
+}
+template <typename TOUT>
+__device__ __forceinline__ void apply_gelu8(float4& v, float4& w) {
+    if constexpr (sizeof(TOUT) == 2) {
+        f32x2v a[4] = {{v.x, v.y}, {v.z, v.w}, {w.x, w.y}, {w.z, w.w}};
+        gelu_poly2n<4>(a);
+        v = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+        w = make_float4(a[2].x, a[2].y, a[3].x, a[3].y);
+    } else {
+        apply_gelu4<TOUT>(v);
+        apply_gelu4<TOUT>(w);
     }
 }
 
@@ -421,7 +459,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 if constexpr (ACT == 2)
                     *reinterpret_cast<uint4*>(static_cast<TOUT*>(ep.aux) + m * ep.ldaux + n8) =
                         make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-                if (ACT == 1 || ACT == 2) { apply_gelu4<TOUT>(x); apply_gelu4<TOUT>(y); }
+                if (ACT == 1 || ACT == 2) apply_gelu8<TOUT>(x, y);
                 if (ep.gamma) {
                     x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
                     y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
