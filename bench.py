@@ -452,7 +452,7 @@ def run_train(args, D: Dist):
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": f"train step: forward + backward + gradient all-reduce + fused AdamW, {args.batch} x 12 frames x "
-                                       f"4096 points x 224x224 per GPU (BASELINE configs[{2 if world == 1 else 3}])",
+                                       f"4096 points x 224x224 per GPU (BASELINE configs[{3 if (world > 1 or args.batch >= 32) else 2}])",
                            "parallelism": f"dp{world}", "grad_buckets": len(opt.buckets),
                            "grad_bucket_mb": round(opt.numel * 4 / len(opt.buckets) / 1e6, 1)},
                 "comm_ranks": D.comm_ranks, "forward_tflop_per_step_per_gpu": round(fwd / 1e12, 2),
