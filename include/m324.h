@@ -255,8 +255,9 @@ int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtyp
 int m324_gelu(const void* z, void* h, long n, int dtype, void* stream);
 int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, void* stream);
 /* LayerNorm backward (weight-only or with bias; the statistics are recomputed from x):
- *   dx[in_row(r)] (+)= d/dx ; partial[n_partial][2C] receives per-wave sums of dy*xhat | dy -- reduce with
- *   m324_colsum(partial, 2C, ..., rows = n_partial) to get dw | db (two-stage = deterministic). */
+ *   dx[in_row(r)] (+)= d/dx ; the launch has n_partial workgroups of 8 waves (one row per wave at a time) and
+ *   partial[n_partial][2C] receives every workgroup's sums of dy*xhat | dy -- reduce with
+ *   m324_colsum(partial, 2C, ..., rows = n_partial) to get dw | db (fixed order = deterministic). */
 int m324_layernorm_bwd(const float* x, long ldx, const float* w, float eps, const void* dy, long ldy, int dy_dtype,
                        float* dx, long lddx, int accumulate, float* partial, int n_partial, int rows, int C,
                        int gin, int gout, int off, void* stream);

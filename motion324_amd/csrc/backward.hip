@@ -7,6 +7,33 @@ namespace {
 template <typename T>
 __device__ __forceinline__ float ld1(const T* p) { return Elem<T>::load(p); }
 
+// eight consecutive values per lane: one 16-byte (bf16) or two 16-byte (fp32) accesses
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+// sum over the 8 lanes that share lane >> 3 (one (token, head) row of 64 values, 8 per lane)
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
 // ----------------------------------------------------------------------------------- cast
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
@@ -17,20 +44,38 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, lo
         Elem<TO>::store(out + r * ld_out + c, Elem<TI>::load(in + r * ld_in + c));
     }
 }
+// cols, both leading dimensions and both base addresses multiples of 8 elements / 16 bytes: 8 values per thread
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast8_kernel(const TI* __restrict__ in, long ld_in, TO* __restrict__ out, long ld_out,
+                                                    int rows, int cols8) {
+    const long n = (long)rows * cols8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cols8, c = (i - r * cols8) * 8;
+        float v[8];
+        load8(in + r * ld_in + c, v);
+        store8(out + r * ld_out + c, v);
+    }
+}
 
 // ----------------------------------------------------------------------------------- attention backward
-// D[b,h,q] = sum_d dO[q, h*64+d] * O[q, h*64+d]   (token-major O / dO, one wave per (token, head))
+// D[b,h,q] = sum_d dO[q, h*64+d] * O[q, h*64+d]   (token-major O / dO; 8 lanes x 8 values per (token, head), 8 of them per wave)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__ dO, long ld,
                                                          float* __restrict__ D, int B, int H, int L) {
-    const int lane = threadIdx.x & 63;
-    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= (long)B * L * H) return;
-    const int h = (int)(w % H);
-    const long row = w / H;                       // b * L + l
-    const float v = ld1(O + row * ld + h * 64 + lane) * ld1(dO + row * ld + h * 64 + lane);
-    const float s = wave_sum(v);
-    if (lane == 0) D[((row / L) * H + h) * L + row % L] = s;
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    const long w = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    const bool ok = w < (long)B * L * H;
+    const long wc = ok ? w : 0;
+    const int h = (int)(wc % H);
+    const long row = wc / H;                      // b * L + l
+    float a[8], b[8];
+    load8(O + row * ld + h * 64 + sub * 8, a);
+    load8(dO + row * ld + h * 64 + sub * 8, b);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += a[i] * b[i];
+    const float s = group8_sum(v);
+    if (ok && sub == 0) D[((row / L) * H + h) * L + row % L] = s;
 }
 
 // Reference-quality backward (fp32 arithmetic, one wave per row, lane = head dimension).  Used by the fp32 parity
@@ -90,7 +135,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 
 // ----------------------------------------------------------------------------------- qkv split backward
 // Head-major gradients (dQhat, dKhat: w.r.t. the RMS-normalised q / k; dV) -> token-major d(qkv); RMSNorm backward for
-// q and k needs the raw projections.  One wave per (token, head), lane = column.  w-gradients: per-block partial sums.
+// q and k needs the raw projections.  A (token, head) row of 64 values = 8 lanes x 8 values (16-byte accesses, 128-byte lines), 8 rows
+// per wave; the per-row sums are three xor-shuffles.  w-gradients: per-workgroup partial sums [q 64 | k 64].
 //   y = x * r * w, r = rsqrt(mean(x^2) + eps):  dx = r * (g - xh * mean(g * xh)), g = dy * w, xh = x * r ; dw += dy * xh
 template <typename T>
 __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const T* __restrict__ dQ, const T* __restrict__ dK, const T* __restrict__ dV,
@@ -100,30 +146,67 @@ __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const T* __restrict_
                                                             T* __restrict__ dv_out, long ldov, float* __restrict__ partial, int B, int L,
                                                             int H) {
     __shared__ float red[2][4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float pq = 0.f, pk = 0.f;
-    const long total = (long)B * L * H;
-    for (long w = (long)blockIdx.x * 4 + wv; w < total; w += (long)gridDim.x * 4) {
-        const int h = (int)(w % H);
-        const long row = w / H;                   // b * L + l
-        const long b = row / L, l = row % L;
-        const long hm = ((b * H + h) * L + l) * 64 + lane;
-        auto norm_bwd = [&](const T* dy_p, const T* raw, long ld, const float* wgt, T* out, long ldo, float& pw) {
-            const float dy = ld1(dy_p + hm);
-            if (!wgt) { Elem<T>::store(out + row * ldo + h * 64 + lane, dy); return; }
-            const float x = ld1(raw + row * ld + h * 64 + lane);
-            const float r = rsqrtf(wave_sum(x * x) * (1.0f / 64.0f) + eps);
-            const float xh = x * r, g = dy * wgt[lane];
-            const float m = wave_sum(g * xh) * (1.0f / 64.0f);
-            pw += dy * xh;
-            Elem<T>::store(out + row * ldo + h * 64 + lane, r * (g - xh * m));
-        };
-        if (dQ) norm_bwd(dQ, q_raw, ldq, qw, dq_out, ldoq, pq);
-        if (dK) norm_bwd(dK, k_raw, ldk, kw, dk_out, ldok, pk);
-        if (dV) Elem<T>::store(dv_out + row * ldov + h * 64 + lane, ld1(dV + hm));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 7, c0 = sub * 8;
+    float pq[8], pk[8], wq[8], wk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        pq[i] = 0.f; pk[i] = 0.f;
+        wq[i] = qw ? qw[c0 + i] : 1.f;
+        wk[i] = kw ? kw[c0 + i] : 1.f;
     }
-    red[0][wv][lane] = pq;
-    red[1][wv][lane] = pk;
+    const long total = (long)B * L * H;
+    for (long w0 = ((long)blockIdx.x * 4 + wv) * 8; w0 < total; w0 += (long)gridDim.x * 32) {
+        const long w = w0 + (lane >> 3);
+        const bool ok = w < total;
+        const long wc = ok ? w : total - 1;       // clamped lanes compute on a valid row and store nothing
+        const int h = (int)(wc % H);
+        const long row = wc / H;                  // b * L + l
+        const long b = row / L, l = row % L;
+        const long hm = ((b * H + h) * L + l) * 64 + c0;
+        auto norm_bwd = [&](const T* dy_p, const T* raw, long ld, const float* wgt, const float (&wv8)[8], T* out, long ldo,
+                            float (&pw)[8]) {
+            float dy[8];
+            load8(dy_p + hm, dy);
+            T* o = out + row * ldo + h * 64 + c0;
+            if (!wgt) { if (ok) store8(o, dy); return; }
+            float x[8];
+            load8(raw + row * ld + h * 64 + c0, x);
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+            const float r = rsqrtf(group8_sum(ss) * (1.0f / 64.0f) + eps);
+            float g[8], mm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                x[i] *= r;                         // xh
+                g[i] = dy[i] * wv8[i];
+                mm += g[i] * x[i];
+            }
+            const float m = group8_sum(mm) * (1.0f / 64.0f);
+            float res[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (ok) pw[i] += dy[i] * x[i];
+                res[i] = r * (g[i] - x[i] * m);
+            }
+            if (ok) store8(o, res);
+        };
+        if (dQ) norm_bwd(dQ, q_raw, ldq, qw, wq, dq_out, ldoq, pq);
+        if (dK) norm_bwd(dK, k_raw, ldk, kw, wk, dk_out, ldok, pk);
+        if (dV) {
+            float v[8];
+            load8(dV + hm, v);
+            if (ok) store8(dv_out + row * ldov + h * 64 + c0, v);
+        }
+    }
+    // the 8 rows of a wave (lanes with equal sub), then the 4 waves, in a fixed order
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float a = pq[i], c = pk[i];
+        a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+        if (lane < 8) { red[0][wv][c0 + i] = a; red[1][wv][c0 + i] = c; }
+    }
     __syncthreads();
     if (wv == 0) {
         partial[(long)blockIdx.x * 128 + lane] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
@@ -248,25 +331,28 @@ extern "C" int m324_cast(const void* in, long ld_in, int in_dtype, void* out, lo
                          void* stream) {
     M324_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= cols, "m324_cast: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = grid_for((long)rows * cols);
-    if (in_dtype == M324_F32 && out_dtype == M324_BF16)
-        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, s, (const float*)in, ld_in, (bf16_t*)out, ld_out, rows, cols);
-    else if (in_dtype == M324_BF16 && out_dtype == M324_F32)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, ld_in, (float*)out, ld_out, rows, cols);
-    else if (in_dtype == M324_F32 && out_dtype == M324_F32)
-        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(nb), dim3(256), 0, s, (const float*)in, ld_in, (float*)out, ld_out, rows, cols);
-    else if (in_dtype == M324_BF16 && out_dtype == M324_BF16)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, rows, cols);
+    const bool vec = cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    const int nb = grid_for(vec ? (long)rows * (cols / 8) : (long)rows * cols);
+#define M324_CAST(TI, TO)                                                                                                          \
+    do {                                                                                                                           \
+        if (vec) hipLaunchKernelGGL((cast8_kernel<TI, TO>), dim3(nb), dim3(256), 0, s, (const TI*)in, ld_in, (TO*)out, ld_out, rows, cols / 8); \
+        else hipLaunchKernelGGL((cast_kernel<TI, TO>), dim3(nb), dim3(256), 0, s, (const TI*)in, ld_in, (TO*)out, ld_out, rows, cols);          \
+    } while (0)
+    if (in_dtype == M324_F32 && out_dtype == M324_BF16) M324_CAST(float, bf16_t);
+    else if (in_dtype == M324_BF16 && out_dtype == M324_F32) M324_CAST(bf16_t, float);
+    else if (in_dtype == M324_F32 && out_dtype == M324_F32) M324_CAST(float, float);
+    else if (in_dtype == M324_BF16 && out_dtype == M324_BF16) M324_CAST(bf16_t, bf16_t);
     else
         M324_FAIL(M324_ERR_UNSUPPORTED, "m324_cast: dtypes %d -> %d", in_dtype, out_dtype);
+#undef M324_CAST
     M324_CHECK_LAUNCH("m324_cast");
     return M324_OK;
 }
 
 extern "C" int m324_attention_delta(const void* O, const void* dO, long ld, float* D, int B, int H, int L, int dtype, void* stream) {
-    M324_REQUIRE(O && dO && D && B > 0 && H > 0 && L > 0 && ld >= (long)H * 64, "m324_attention_delta: bad arguments");
+    M324_REQUIRE(O && dO && D && B > 0 && H > 0 && L > 0 && ld >= (long)H * 64 && ld % 8 == 0, "m324_attention_delta: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const long waves = (long)B * L * H;
+    const long waves = ceil_div((long)B * L * H, 8l);
     DISPATCH_DTYPE(dtype, "m324_attention_delta",
                    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(ceil_div(waves, 4)), dim3(256), 0, s, (const T*)O, (const T*)dO, ld, D,
                                       B, H, L));
@@ -297,6 +383,8 @@ extern "C" int m324_qkv_split_bwd(const void* dQ, const void* dK, const void* dV
     M324_REQUIRE(partial && n_partial > 0 && n_partial <= 2048 && B > 0 && L > 0 && H > 0, "m324_qkv_split_bwd: bad arguments");
     M324_REQUIRE((!dQ || (dq_out && (!q_w || q_raw))) && (!dK || (dk_out && (!k_w || k_raw))) && (!dV || dv_out),
                  "m324_qkv_split_bwd: missing buffer");
+    M324_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldoq % 8 == 0 && ldok % 8 == 0 && ldov % 8 == 0,
+                 "m324_qkv_split_bwd: leading dimensions must be multiples of 8");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_DTYPE(dtype, "m324_qkv_split_bwd",
                    hipLaunchKernelGGL(qkv_split_bwd_kernel<T>, dim3(n_partial), dim3(256), 0, s, (const T*)dQ, (const T*)dK,

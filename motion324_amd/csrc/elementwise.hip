@@ -541,17 +541,22 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ z, 
     }
 }
 
-// LayerNorm backward, one wave per row (grid-stride over rows):
+// LayerNorm backward, one wave per row (grid-stride over rows), 8 waves per workgroup:
 //   xh = (x - mean) * rstd ; g = dy * w ; dx += rstd * (g - mean(g) - xh * mean(g * xh))
-//   partial[wave][0:C] += dy * xh (dw), partial[wave][C:2C] += dy (db)  -> summed by m324_colsum (deterministic)
+//   partial[workgroup][0:C] = sum of dy * xh (dw), partial[workgroup][C:2C] = sum of dy (db) over the workgroup's rows (its 8 waves'
+//   sums added in wave order through LDS)  -> summed by m324_colsum (fixed order = deterministic).  Up to 512 workgroups = 4096
+//   waves: the row loop is a chain of dependent loads, and the 1024 waves of the first version left it latency-bound (110 us for
+//   24 672 rows x 768; the per-wave partials then cost m324_colsum another 58 us).
+constexpr int LNB_WAVES = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+__global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                             float eps, const T* __restrict__ dy, long ldy,
                                                             float* __restrict__ dx, long lddx, int accumulate,
                                                             float* __restrict__ partial, int rows, int C, int gin, int gout,
                                                             int off) {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    extern __shared__ float lnb_red[];                        // [LNB_WAVES][2 C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * LNB_WAVES + wave, nw = gridDim.x * LNB_WAVES;
     float4 pw[LN_MAXV], pb[LN_MAXV];
     LN_FOR(i, c) { pw[i] = make_float4(0.f, 0.f, 0.f, 0.f); pb[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
     for (long row = gw; row < rows; row += nw) {
@@ -586,12 +591,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             *reinterpret_cast<float4*>(dr + c) = o;
         }
     }
-    if (gw < nw) {
-        float* pr = partial + (long)gw * 2 * C;
-        LN_FOR(i, c) {
-            *reinterpret_cast<float4*>(pr + c) = pw[i];
-            *reinterpret_cast<float4*>(pr + C + c) = pb[i];
-        }
+    float* mine = lnb_red + wave * 2 * C;
+    LN_FOR(i, c) {
+        *reinterpret_cast<float4*>(mine + c) = pw[i];
+        *reinterpret_cast<float4*>(mine + C + c) = pb[i];
+    }
+    __syncthreads();
+    float* pr = partial + (long)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 64 * LNB_WAVES) {
+        float a = lnb_red[c];
+#pragma unroll
+        for (int w = 1; w < LNB_WAVES; ++w) a += lnb_red[w * 2 * C + c];
+        pr[c] = a;
     }
 }
 
@@ -779,7 +790,7 @@ extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int col
                            int scratch_rows, void* stream) {
     M324_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "m324_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (scratch && scratch_rows > 1 && rows >= 2048) {   // two-stage: row chunks in parallel, then a short deterministic sum
+    if (scratch && scratch_rows > 1 && rows >= 256) {    // two-stage: row chunks in parallel, then a short deterministic sum
         const int R = scratch_rows < 64 ? scratch_rows : 64;
         DISPATCH_DTYPE(dtype, "m324_colsum",
                        hipLaunchKernelGGL(colsum_chunk_kernel<T>, dim3(ceil_div(cols, 64), R), dim3(256), 0, s, (const T*)x, ld,
@@ -828,12 +839,12 @@ extern "C" int m324_layernorm_bwd(const float* x, long ldx, const float* w, floa
                                   int gout, int off, void* stream) {
     M324_REQUIRE(x && w && dy && dx && partial, "m324_layernorm_bwd: null pointer");
     M324_REQUIRE(rows > 0 && C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV, "m324_layernorm_bwd: rows=%d C=%d unsupported", rows, C);
-    M324_REQUIRE(n_partial > 0 && n_partial % 4 == 0 && n_partial <= 4096, "m324_layernorm_bwd: n_partial must be a multiple of 4");
+    M324_REQUIRE(n_partial > 0 && n_partial <= 4096, "m324_layernorm_bwd: n_partial = %d (1 .. 4096 workgroups)", n_partial);
     M324_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0, "m324_layernorm_bwd: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_DTYPE(dy_dtype, "m324_layernorm_bwd",
-                   hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(n_partial / 4), dim3(256), 0, s, x, ldx, w, eps, (const T*)dy,
-                                      ldy, dx, lddx, accumulate, partial, rows, C, gin, gout, off));
+                   hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(n_partial), dim3(64 * LNB_WAVES), (size_t)LNB_WAVES * 2 * C * 4, s, x,
+                                      ldx, w, eps, (const T*)dy, ldy, dx, lddx, accumulate, partial, rows, C, gin, gout, off));
     M324_CHECK_LAUNCH("m324_layernorm_bwd");
     return M324_OK;
 }

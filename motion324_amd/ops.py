@@ -422,8 +422,8 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
         out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
         accumulate = False
     scratch, srows = None, 0
-    if R >= 2048:
-        srows = 64
+    if R >= 256:                                   # two-stage: row chunks in parallel, then a short fixed-order sum
+        srows = 64 if R >= 2048 else 16
         scratch = torch.empty((srows, Cc), dtype=torch.float32, device=x.device)
     L.check(L.load().m324_colsum(px, ld, _vec(out, Cc, "out"), R, Cc, code_of(x.dtype), int(accumulate), _p(scratch), srows,
                                  _stream()), "m324_colsum")
@@ -453,7 +453,7 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     px, ldx = _rows(x, "x")
     pdy, ldy = _rows(dy, "dy")
     pdx, lddx = _rows(dx, "dx")
-    n_partial = min(1024, (rows + 3) // 4 * 4)
+    n_partial = min(512, (rows + 7) // 8)               # workgroups of 8 waves, one row per wave at a time
     partial = torch.empty((n_partial, 2 * Cdim), dtype=torch.float32, device=x.device)
     gin, gout, off = row_map
     L.check(L.load().m324_layernorm_bwd(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
@@ -519,7 +519,7 @@ def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: in
     """Writes token-major gradients into dq_out / dk_out / dv_out (2-D views, any may be None with its dX);
     returns (dq_norm_w [64] or None, dk_norm_w [64] or None)."""
     dtype = next(t for t in (dQ, dK, dV) if t is not None).dtype
-    n_partial = min(1024, max(1, (B * Lq * H + 3) // 4))
+    n_partial = min(1024, max(1, (B * Lq * H + 31) // 32))      # a workgroup takes 32 (token, head) rows per pass
     dev = next(t for t in (dQ, dK, dV) if t is not None).device
     partial = torch.empty((n_partial, 128), dtype=torch.float32, device=dev)
 
