@@ -32,6 +32,7 @@ from .prepared import Prepared, bump_generation, compute_dtype, pad_k
 from .timing import span
 from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
+HOIST_DECODER_Q = os.environ.get("M324_HOIST_Q", "1") != "0"    # A/B switch of the hoisted decoder q projection (forward())
 DECODE_ROWS = int(os.environ.get("M324_DECODE_ROWS", 1 << 17))     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
 
 
@@ -326,6 +327,16 @@ class Motion_Latent_Model(nn.Module):
                 blk.run(P, mesh, B, K)
             if cap is not None:
                 cap["mesh_feat"] = mesh.clone()
+            # the decoder's point features and q projection depend on the mesh points only: under graph capture they
+            # ride on this branch too (seven small launches, ~40 us, off the critical path between trunk and decoder)
+            hoisted = None
+            if (HOIST_DECODER_Q and side is not None and torch.cuda.is_current_stream_capturing()
+                    and DECODE_ROWS // sample["rgb_video"].shape[1] >= N):
+                pcd_h, nrm_h, rgb_h = (self._f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
+                hoisted = []
+                for b in range(B):
+                    pf_b = self._point_features(P, pcd_h[b], nrm_h[b].contiguous(), rgb_h[b].contiguous())
+                    hoisted.append((pf_b, self.decoder_cross_attn.project_q(P, pf_b, 1, N)))
 
         # B. image encoder (reference :466-475): resize + normalise + patchify + ViT, frozen
         video = sample["rgb_video"]
@@ -395,9 +406,13 @@ class Motion_Latent_Model(nn.Module):
         for b in range(B):
             for n0 in range(0, N, nchunk):
                 n1 = min(N, n0 + nchunk)
-                pf = self._point_features(P, pcd[b, n0:n1], nrm[b, n0:n1].contiguous(), rgb[b, n0:n1].contiguous())
+                if hoisted is not None:
+                    pf, Q = hoisted[b]
+                else:
+                    pf = self._point_features(P, pcd[b, n0:n1], nrm[b, n0:n1].contiguous(), rgb[b, n0:n1].contiguous())
                 with span("stage:decoder_cross_attn_block", 0.0):
-                    Q = dec.project_q(P, pf, 1, n1 - n0)
+                    if hoisted is None:
+                        Q = dec.project_q(P, pf, 1, n1 - n0)
                     x = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True)
                 if cap is not None and n0 == 0 and n1 == N:
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
