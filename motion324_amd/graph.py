@@ -8,6 +8,7 @@ hipStreamBeginCapture on the stream libm324 launches on) and replayed: one host 
     fast = GraphedForward(model)          # model.eval() on a HIP device
     out = fast(sample)                    # first call per (shapes, precision): warm-up + capture
     out.pcd_moved                         # static output buffer, overwritten by the next replay
+    buf = fast.static_inputs(sample)      # zero-copy handover: fill buf[...] in place, then fast(buf)
 
 Weights are read through the Prepared cache at capture time: a graph is keyed by the cache generation AND by a stamp
 of every parameter's storage pointer and in-place version counter, so ``model.train()/eval()`` toggles, the native
@@ -40,6 +41,13 @@ class GraphedForward:
     def _key(self, sample) -> Tuple:
         return (prepared.generation(), prepared.weight_stamp(self.model), compute_dtype()) + \
             tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
+
+    def static_inputs(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The graph's own input buffers for this sample's shapes (captured on first use), holding a copy of `sample`.
+        A producer that writes the next clip straight into these tensors and then calls ``fast(buffers)`` hands the clip
+        over without the device-to-device copies ``fast(sample)`` makes (100.7 MB of frames for the BASELINE clip)."""
+        self(sample)
+        return self._graphs[self._key(sample)][1]
 
     def __call__(self, sample: Dict[str, torch.Tensor]):
         if self.model.training:

@@ -192,6 +192,30 @@ def test_graph_replay_matches_eager():
     assert not torch.equal(a, b)
 
 
+def test_graph_static_inputs_are_a_zero_copy_handover():
+    """GraphedForward.static_inputs returns the captured graph's own input tensors: a clip written into them in place is
+    what the next replay reads (no copy made by the call), and the result equals the eager forward of the same values."""
+    import motion324_amd as m
+    model, dm = build("tiny")
+    sample = inputs("tiny", with_target=False)
+    m.set_precision("bf16")
+    try:
+        fast = m.GraphedForward(model)
+        buf = fast.static_inputs(sample)
+        assert all(buf[k].data_ptr() != sample[k].data_ptr() for k in buf)
+        assert torch.equal(fast(buf).pcd_moved, fast(sample).pcd_moved)
+        buf["rgb_video"].mul_(0.5)
+        buf["ref_pcd"].add_(0.01)
+        ptrs = {k: v.data_ptr() for k, v in buf.items()}
+        got = fast(buf).pcd_moved.clone()
+        assert {k: v.data_ptr() for k, v in fast.static_inputs(buf).items()} == ptrs
+        with torch.no_grad():
+            want = model({k: v.clone() for k, v in buf.items()}).pcd_moved
+    finally:
+        m.set_precision(None)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_image_encoder_two_graph_branches_match_one_chain(precision):
     """Under graph capture the image encoder runs its frames as two half-batches on two streams (two branches of the
