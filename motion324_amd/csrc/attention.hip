@@ -53,12 +53,15 @@ typedef __attribute__((ext_vector_type(4))) short a_s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short a_s16x8_t;
 typedef __attribute__((address_space(3))) a_s16x4_t a_lds_s16x4_t;
 
-template <bool PRESCALED, int NQ, int NWV, bool VROW = false>
-__global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
+// NST: stages of the K / V ring.  NST = 1 is the one-tile form (Lk <= 64: the decoder's 64 latent tokens under 2048 shared
+// queries x 32 frames = 6144 workgroups that each live for one tile): 16 KiB of LDS and a 128-register budget, so that
+// four of these latency-bound workgroups share a CU instead of two.
+template <bool PRESCALED, int NQ, int NWV, bool VROW = false, int NST = 3>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4 : 1)) void attn_bf16_kernel(const bf16_t* __restrict__ Q, long q_bstride,
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
                                                         int Lkp, float scale_log2e, float* __restrict__ lse, int nqt, int xflags) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * ASTAGE];   // [stage][K | Vt]
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ASTAGE];   // [stage][K | Vt]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_
     }
     auto issue_tile = [&](int t) {
         const int kv0 = t * KV;
-        unsigned char* sk = smem + (t % 3) * ASTAGE + wave * (GPW * 1024);
+        unsigned char* sk = smem + (t % NST) * ASTAGE + wave * (GPW * 1024);
         unsigned char* sv = sk + 8192;
 #pragma unroll
         for (int i = 0; i < GPW; ++i) {
@@ -161,9 +164,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + 2 < nt) issue_tile(t + 2);
-        const unsigned char* sk = smem + (t % 3) * ASTAGE;
+        const unsigned char* sk = smem + (t % NST) * ASTAGE;
         const unsigned char* sv = sk + 8192;
-        const int kos = ko0 + (t % 3) * ASTAGE;
+        const int kos = ko0 + (t % NST) * ASTAGE;
 
         // ---- S'^T = K Q^T - m_ref : two 32-key blocks per query block
         f32x16 s[NQ][2];
@@ -299,18 +302,27 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : 1) void attn_
         const float inv = 1.0f / l_tot;
         const int q = q0 + n * QW + l31;
         if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_ref[n] + log2f(l_tot);   // log2-domain LSE
-        if (q < Lq) {
-            bf16_t* orow = O + ((long)b * Lq + q) * ldo + h * 64;
+        // The two lanes of a query (l, l + 32) hold alternating 4-value groups of its row.  v_permlane32_swap trades the
+        // odd groups of the lower lanes for the even groups of the upper ones, so every lane ends up with whole 8-value
+        // (16-byte) chunks: half as many store instructions, each covering twice as much of a 128-byte line.
+        bf16_t* orow = O + ((long)b * Lq + min(q, Lq - 1)) * ldo + h * 64;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 w;
-                    w.x = pack_bf16x2(o[n][db][g * 4 + 0] * inv, o[n][db][g * 4 + 1] * inv);
-                    w.y = pack_bf16x2(o[n][db][g * 4 + 2] * inv, o[n][db][g * 4 + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + db * 32 + g * 8 + hi * 4) = w;
+            for (int gp = 0; gp < 2; ++gp) {
+                uint32_t a[2], c[2];             // a: group 2 gp (even), c: group 2 gp + 1 (odd)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    a[k] = pack_bf16x2(o[n][db][(2 * gp) * 4 + 2 * k] * inv, o[n][db][(2 * gp) * 4 + 2 * k + 1] * inv);
+                    c[k] = pack_bf16x2(o[n][db][(2 * gp + 1) * 4 + 2 * k] * inv, o[n][db][(2 * gp + 1) * 4 + 2 * k + 1] * inv);
+                    // a.lanes[32..63] <-> c.lanes[0..31]: lower lanes now hold (own even, partner's even), upper (partner's odd, own odd)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(a[k], c[k], false, false);
+                    a[k] = sw[0];
+                    c[k] = sw[1];
                 }
-        }
+                if (q < Lq)
+                    *reinterpret_cast<uint4*>(orow + db * 32 + (2 * gp + hi) * 8) = make_uint4(a[0], a[1], c[0], c[1]);
+            }
     }
 }
 
@@ -738,6 +750,9 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         if (vrow) {
             if (q_prescaled) { if (w8) M324_ATTN_VR(true, 8); else M324_ATTN_VR(true, 4); }
             else { if (w8) M324_ATTN_VR(false, 8); else M324_ATTN_VR(false, 4); }
+        } else if (q_prescaled && !w8 && !nq2 && Lk <= KV && m324::tunable(m324::TUN_ATTN_OCC) != 1) {      // one tile (M324_ATTN_OCC=1: A/B)
+            hipLaunchKernelGGL((attn_bf16_kernel<true, 1, 4, false, 1>), g2, dim3(256), 0, s, (const bf16_t*)Q, q_bstride,
+                               (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt, xfl);
         } else if (q_prescaled) { if (nq2) M324_ATTN(true, 2, 4); else if (w8) M324_ATTN(true, 1, 8); else M324_ATTN(true, 1, 4); }
         else { if (nq2) M324_ATTN(false, 2, 4); else if (w8) M324_ATTN(false, 1, 8); else M324_ATTN(false, 1, 4); }
 #undef M324_ATTN_VR
@@ -769,6 +784,8 @@ extern "C" int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int 
     if (w8 && m324::tunable(m324::TUN_ATTN_FLAT) != 0)
         snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s> grid=%ldx1x1", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
                  vrow ? "true" : "false", gx * H * B * nwv * 64);
+    else if (ps && !vrow && !w8 && !nq2 && Lk <= KV && m324::tunable(m324::TUN_ATTN_OCC) != 1)
+        snprintf(buf, (size_t)n, "attn_bf16_kernel<true, 1, 4, false, 1> grid=%ldx%dx%d", gx * nwv * 64, H, B);
     else
         snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s> grid=%ldx%dx%d", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
                  vrow ? "true" : "false", gx * nwv * 64, H, B);
