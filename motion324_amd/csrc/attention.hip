@@ -303,9 +303,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
         const int q = q0 + n * QW + l31;
         if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_ref[n] + log2f(l_tot);   // log2-domain LSE
         // The two lanes of a query (l, l + 32) hold alternating 4-value groups of its row.  v_permlane32_swap trades the
-        // odd groups of the lower lanes for the even groups of the upper ones, so every lane ends up with whole 8-value
-        // (16-byte) chunks: half as many store instructions, each covering twice as much of a 128-byte line.
-        bf16_t* orow = O + ((long)b * Lq + min(q, Lq - 1)) * ldo + h * 64;
+        // odd groups of the lower lanes for the even groups of the upper ones, so every lane has whole 8-value (16-byte)
+        // chunks; those bounce through a wave-private, XOR-swizzled 32 x 128-byte LDS block so that a store instruction
+        // writes 8 whole 128-byte rows instead of 32 quarter rows (partial-line writes were what the short attentions --
+        // one to six K / V tiles per workgroup -- spent their time on: decoder 48 us with 8-byte stores, 32 with 16-byte).
+        // The block lives in ring stages no tile occupies any more (tiles nt and nt + 1 were never issued); the one-stage
+        // form has no such stage and stores its 16-byte chunks directly.
+        unsigned char* scr = smem + ((nt + (wave >> 2)) % NST) * ASTAGE + (wave & 3) * 4096;
+        if (n > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // NQ = 2: the block is reused per query block
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -320,9 +325,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
                     a[k] = sw[0];
                     c[k] = sw[1];
                 }
-                if (q < Lq)
-                    *reinterpret_cast<uint4*>(orow + db * 32 + (2 * gp + hi) * 8) = make_uint4(a[0], a[1], c[0], c[1]);
+                const int chunk = db * 4 + 2 * gp + hi;
+                if constexpr (NST == 1) {        // no free stage, and a barrier costs this one-tile kernel more than quarter rows do
+                    if (q < Lq) *reinterpret_cast<uint4*>(O + ((long)b * Lq + q) * ldo + h * 64 + chunk * 8) = make_uint4(a[0], a[1], c[0], c[1]);
+                } else {
+                    *reinterpret_cast<uint4*>(scr + l31 * 128 + ((chunk ^ (l31 & 7)) << 4)) = make_uint4(a[0], a[1], c[0], c[1]);
+                }
             }
+        if constexpr (NST != 1) {
+            const int r8 = lane >> 3, c8 = lane & 7;
+            bf16_t* obase = O + ((long)b * Lq + q0 + n * QW) * ldo + h * 64 + c8 * 8;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = p * 8 + r8;
+                const uint4 v = *reinterpret_cast<const uint4*>(scr + r * 128 + ((c8 ^ (r & 7)) << 4));
+                if (q0 + n * QW + r < Lq) *reinterpret_cast<uint4*>(obase + (long)r * ldo) = v;
+            }
+        }
     }
 }
 
