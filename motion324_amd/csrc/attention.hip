@@ -801,12 +801,12 @@ extern "C" int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int 
     const long gx = ceil_div(Lq, (nq2 || w8) ? 2 * QB : QB);
     const int nwv = w8 ? 8 : 4;
     if (w8 && m324::tunable(m324::TUN_ATTN_FLAT) != 0)
-        snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s> grid=%ldx1x1", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
+        snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s, 3> grid=%ldx1x1", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
                  vrow ? "true" : "false", gx * H * B * nwv * 64);
     else if (ps && !vrow && !w8 && !nq2 && Lk <= KV && m324::tunable(m324::TUN_ATTN_OCC) != 1)
         snprintf(buf, (size_t)n, "attn_bf16_kernel<true, 1, 4, false, 1> grid=%ldx%dx%d", gx * nwv * 64, H, B);
     else
-        snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s> grid=%ldx%dx%d", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
+        snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s, 3> grid=%ldx%dx%d", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
                  vrow ? "true" : "false", gx * nwv * 64, H, B);
     return nwv;
 }
