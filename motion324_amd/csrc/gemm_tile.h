@@ -500,25 +500,30 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
             if (which == 2 && ep.qkv_vt) {
-                // V of this head, transposed: lane d owns column d of the 32 x 64 block (32 conflict-free b32 reads, the
-                // lanes of a wave hit 64 consecutive banks) and writes its 32 tokens as 64 contiguous bytes of Vt row d,
-                // token quarters of each 16-group in the order 0, 2, 1, 3 (what the attention's P^T fragments contract).
-                // qkv_L % 128 == 0 (host-checked): a 32-token block never straddles a batch and Vt has no padding.
+                // V of this head, transposed: four lanes share a column d of the 32 x 64 block, lane (d = (lane >> 2) + 16 p,
+                // c = lane & 3) gathers the 8 tokens of 16-byte chunk c (b32 reads, two-way bank conflicts) and a store
+                // instruction writes 16 Vt rows x 64 contiguous bytes (one lane per column wrote 64 rows x 16 bytes: four times
+                // as many partial-line writes).  Token quarters of each 16-group go out in the order 0, 2, 1, 3 (what the
+                // attention's P^T fragments contract): chunk c holds tokens base .. base+3 and base+8 .. base+11,
+                // base = 16 (c >> 1) + 4 (c & 1).  qkv_L % 128 == 0 (host-checked): a 32-token block never straddles a
+                // batch and Vt has no padding.
                 const int m0b = mw + i * 32;
                 if (m0b < M && nw + 64 <= N) {
-                    const float bd = ep.bias ? ep.bias[nw + lane] : 0.f;
                     const int bb = m0b / ep.qkv_L, ll = m0b - bb * ep.qkv_L;
-                    bf16_t* dst = ep.qkv_out[2] + (((long)bb * ep.qkv_H + head) * 64 + lane) * (long)ep.qkv_L + ll;
-                    float t[32];
+                    const int cq = lane & 3, base = 16 * (cq >> 1) + 4 * (cq & 1);
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) t[k] = scr[k * EP_LD + lane] + bd;
+                    for (int p = 0; p < 4; ++p) {
+                        const int d = (lane >> 2) + 16 * p;
+                        const float bd = ep.bias ? ep.bias[nw + d] : 0.f;
+                        float u[8];
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const float* u = t + g * 16;
-                        *reinterpret_cast<uint4*>(dst + g * 16) =
-                            make_uint4(pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[8], u[9]), pack_bf16x2(u[10], u[11]));
-                        *reinterpret_cast<uint4*>(dst + g * 16 + 8) =
-                            make_uint4(pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7]), pack_bf16x2(u[12], u[13]), pack_bf16x2(u[14], u[15]));
+                        for (int k = 0; k < 4; ++k) {
+                            u[k] = scr[(base + k) * EP_LD + d] + bd;
+                            u[4 + k] = scr[(base + 8 + k) * EP_LD + d] + bd;
+                        }
+                        bf16_t* dst = ep.qkv_out[2] + (((long)bb * ep.qkv_H + head) * 64 + d) * (long)ep.qkv_L + ll + cq * 8;
+                        *reinterpret_cast<uint4*>(dst) =
+                            make_uint4(pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7]));
                     }
                 }
                 continue;
