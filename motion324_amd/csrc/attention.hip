@@ -38,6 +38,28 @@ typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef __attribute__((address_space(1))) const void glb_ptr_t;
 constexpr int ASTAGE = 16384;   // K tile (8 KiB) + Vt tile (8 KiB)
 
+// A row of an O^T-style accumulator pair (lanes l and l + 32 hold alternating 4-value groups of row l & 31, 16 values per
+// 32-column block db): v_permlane32_swap trades the odd groups of the lower lanes for the even groups of the upper ones, so
+// each lane stores two whole 16-byte chunks per block instead of four 8-byte pieces.  chunk index = db * 4 + 2 gp + hi.
+template <typename F>
+__device__ __forceinline__ void store_row_chunks(const f32x16 (&acc)[2], float mul, int hi, bool ok, F&& put) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            uint32_t a[2], c[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                a[k] = pack_bf16x2(acc[db][(2 * gp) * 4 + 2 * k] * mul, acc[db][(2 * gp) * 4 + 2 * k + 1] * mul);
+                c[k] = pack_bf16x2(acc[db][(2 * gp + 1) * 4 + 2 * k] * mul, acc[db][(2 * gp + 1) * 4 + 2 * k + 1] * mul);
+                const auto sw = __builtin_amdgcn_permlane32_swap(a[k], c[k], false, false);
+                a[k] = sw[0];
+                c[k] = sw[1];
+            }
+            if (ok) put(db * 4 + 2 * gp + hi, make_uint4(a[0], a[1], c[0], c[1]));
+        }
+}
+
 // PRESCALED: Q already carries scale * log2(e) (m324_qkv_split's q_scale), so scores are log2-domain.
 // NQ: 32-row query blocks per wave (1 or 2).  With NQ = 2 every K / Vt fragment read from LDS feeds two
 // MFMAs, a wave issues 32 MFMAs per barrier instead of 16, and the two blocks' softmax chains are
@@ -467,17 +489,9 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dq_mfma_kernel(const bf16_t
                 acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[j], acc[db], 0, 0, 0);
             }
     }
-    if (qok) {
-        bf16_t* orow = dQ + (bh * Lq + q) * 64;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack_bf16x2(acc[db][g * 4 + 0] * scale, acc[db][g * 4 + 1] * scale);
-                w.y = pack_bf16x2(acc[db][g * 4 + 2] * scale, acc[db][g * 4 + 3] * scale);
-                *reinterpret_cast<uint2*>(orow + db * 32 + g * 8 + hi * 4) = w;
-            }
+    {
+        bf16_t* orow = dQ + (bh * Lq + (qok ? q : 0)) * 64;
+        store_row_chunks(acc, scale, hi, qok, [&](int chunk, uint4 v) { *reinterpret_cast<uint4*>(orow + chunk * 8) = v; });
     }
 }
 
@@ -587,22 +601,12 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_mfma_kernel(const bf16_
                 ak[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[j], ak[db], 0, 0, 0);
             }
     }
-    if (kok) {
-        bf16_t* krow = dK + (bh * Lk + kv) * 64;
-        bf16_t* vrow = dV + (bh * Lk + kv) * 64;
+    {
+        bf16_t* krow = dK + (bh * Lk + (kok ? kv : 0)) * 64;
+        bf16_t* vrow = dV + (bh * Lk + (kok ? kv : 0)) * 64;
         const float ln2 = 0.69314718055994530942f;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w, u;
-                w.x = pack_bf16x2(ak[db][g * 4 + 0] * ln2, ak[db][g * 4 + 1] * ln2);
-                w.y = pack_bf16x2(ak[db][g * 4 + 2] * ln2, ak[db][g * 4 + 3] * ln2);
-                u.x = pack_bf16x2(av[db][g * 4 + 0], av[db][g * 4 + 1]);
-                u.y = pack_bf16x2(av[db][g * 4 + 2], av[db][g * 4 + 3]);
-                *reinterpret_cast<uint2*>(krow + db * 32 + g * 8 + hi * 4) = w;
-                *reinterpret_cast<uint2*>(vrow + db * 32 + g * 8 + hi * 4) = u;
-            }
+        store_row_chunks(ak, ln2, hi, kok, [&](int chunk, uint4 v) { *reinterpret_cast<uint4*>(krow + chunk * 8) = v; });
+        store_row_chunks(av, 1.0f, hi, kok, [&](int chunk, uint4 v) { *reinterpret_cast<uint4*>(vrow + chunk * 8) = v; });
     }
 }
 
