@@ -285,6 +285,24 @@ def committed_traffic(symbol: str):
 
 
 # ----------------------------------------------------------------------------------------------- modes
+def roofline_from(rec, steps: int, precision: str, note: str):
+    """The `roofline` object of the secondary modes: dominant symbol of one instrumented eager pass (HIP events per launch)."""
+    rows = [r for r in roofline_rows(rec, steps) if not r["symbol"].startswith("stage:")]
+    if not rows:
+        return None
+    dom = rows[0]
+    peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
+    traffic, traffic_src = committed_traffic(dom["symbol"])
+    summ = {k: v for k, v in rec.summary().items() if not k.startswith("stage:")}
+    return {"bound": "mfma", "kernel": dom["symbol"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+            "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
+            "algorithmic_gflop_per_launch": dom["gflop_per_launch"], "timing": note, "by_symbol": rows[:8],
+            "class_totals": {k: {"ms_per_step": round(v["total_ms"] / steps, 3),
+                                 "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1),
+                                 "frac": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12 / peak, 4)} for k, v in summ.items()}}
+
+
 def run_infer(args, D: Dist):
     import motion324_amd as m
     from motion324_amd import parallel, synth
@@ -453,6 +471,11 @@ def run_train(args, D: Dist):
     for _ in range(args.warmup):
         step()
     dt, _ = timed(D, step, args.steps)
+    from motion324_amd.timing import Recorder
+    rec = Recorder()
+    with rec:                                     # one more step with an event pair around every GEMM / attention-forward launch
+        step()
+    D.fence()
     line = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -470,7 +493,10 @@ def run_train(args, D: Dist):
                 "losses": [round(float(x), 6) for x in losses[-min(6, len(losses)):]],
                 "grad_norm": round(infos[-1]["grad_norm"], 4), "skipped_steps": sum(1 for i in infos if i["skipped"]),
                 "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                "roofline": None, "cpu_baseline": None}
+                "roofline": roofline_from(rec, 1, args.precision, "HIP events around every GEMM / attention-forward launch of one extra "
+                                          "training step (forward, recompute, dgrad, wgrad; the attention backward kernels are "
+                                          f"not in the classes); symbols as in profiles/{PROFILE_ROUND}_p3_train_kernel_stats.md"),
+                "cpu_baseline": None}
     return line
 
 
@@ -499,6 +525,14 @@ def run_frame_parallel(args, D: Dist):
     for _ in range(args.warmup):
         step()
     dt, _ = timed(D, step, args.steps)
+    from motion324_amd.timing import Recorder
+    rec = Recorder()
+    with rec, torch.no_grad():                    # one eager forward with an event pair around every GEMM / attention launch
+        if world > 1:
+            model.forward_frame_parallel(sample)
+        else:
+            model(sample)
+    D.fence()
     line = None
     if rank == 0:
         flops = algorithmic_flops(1, T, 2048, args.surface)
@@ -513,7 +547,9 @@ def run_frame_parallel(args, D: Dist):
                 "end_to_end_tflops": round(flops * args.steps / dt / 1e12, 1),
                 "end_to_end_frac_of_bf16_peak": round(flops * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS / world, 4),
                 "finite": bool(torch.isfinite(last[0]).all()), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                "roofline": None, "cpu_baseline": None}
+                "roofline": roofline_from(rec, 1, args.precision, "HIP events around every GEMM / attention launch of one eager forward "
+                                          "on the launch stream (rank 0)"),
+                "cpu_baseline": None}
     return line
 
 
@@ -540,6 +576,9 @@ def main():
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     maybe_spawn(args)                     # N > 1 without a launcher: child ranks, before any GPU call in this process
+    if os.environ.get("M324_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["M324_BENCH_WATCHDOG"]), exit=True)
     D = Dist(args)
     line = {"infer": run_infer, "train": run_train, "frame-parallel": run_frame_parallel}[args.mode](args, D)
     if D.rank == 0:
