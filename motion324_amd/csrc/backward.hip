@@ -7,25 +7,6 @@ namespace {
 template <typename T>
 __device__ __forceinline__ float ld1(const T* p) { return Elem<T>::load(p); }
 
-// eight consecutive values per lane: one 16-byte (bf16) or two 16-byte (fp32) accesses
-__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
-    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xFFFF0000u);
-    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xFFFF0000u);
-}
-__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
-    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-}
-__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
 // sum over the 8 lanes that share lane >> 3 (one (token, head) row of 64 values, 8 per lane)
 __device__ __forceinline__ float group8_sum(float v) {
     v += __shfl_xor(v, 1, 64);

@@ -96,13 +96,13 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
 
     auto one = [&](const T* src, long ld, const float* w, float post, T* dst, T* dstT) {
         float v[16];
-        if (ok) {
+        if (ok) {                                 // 16-byte accesses: an 8-byte piece of a line costs a transaction like 16 do
             const T* p = src + srow * ld + h * 64 + part * 16;
+            float lo[8], hi8[8];
+            load8(p, lo);
+            load8(p + 8, hi8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 f = load4<T>(p + i * 4);
-                v[i * 4] = f.x; v[i * 4 + 1] = f.y; v[i * 4 + 2] = f.z; v[i * 4 + 3] = f.w;
-            }
+            for (int i = 0; i < 8; ++i) { v[i] = lo[i]; v[8 + i] = hi8[i]; }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = 0.f;
@@ -123,8 +123,10 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
         }
         if (dst && ok) {
             T* o = dst + (hbase * L + l) * 64 + part * 16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) store4<T>(o + i * 4, v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
+            const float lo[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+            const float hi8[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+            store8(o, lo);
+            store8(o + 8, hi8);
         }
         if (dstT) {
             __syncthreads();   // previous user of the tile is done
@@ -133,12 +135,12 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
             __syncthreads();
             const int d = t >> 2;   // output row d, 16 tokens (t & 3) * 16
             T* o = dstT + (hbase * 64 + d) * (long)Lp + l0 + part * 16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int slot = i == 1 ? 2 : (i == 2 ? 1 : i);   // token quarter i of the 16-group -> slot perm(i)
-                store4<T>(o + slot * 4, tile[d][part * 16 + i * 4], tile[d][part * 16 + i * 4 + 1],
-                          tile[d][part * 16 + i * 4 + 2], tile[d][part * 16 + i * 4 + 3]);
-            }
+            // token quarters of the 16-group go out in the order 0, 2, 1, 3: two 16-byte chunks (q0 | q2) and (q1 | q3)
+            const float* tr = &tile[d][part * 16];
+            const float c0[8] = {tr[0], tr[1], tr[2], tr[3], tr[8], tr[9], tr[10], tr[11]};
+            const float c1[8] = {tr[4], tr[5], tr[6], tr[7], tr[12], tr[13], tr[14], tr[15]};
+            store8(o, c0);
+            store8(o + 8, c1);
         }
     };
     if (qs) one(qs, ldq, qw, q_scale, Q, Qt);
@@ -632,7 +634,8 @@ extern "C" int m324_qkv_split(const void* q_src, long ldq, const void* k_src, lo
                               void* Kt, void* Vt, int B, int L, int H, int dtype, void* stream) {
     M324_REQUIRE(B > 0 && L > 0 && H > 0, "m324_qkv_split: empty problem");
     M324_REQUIRE((!q_src || Q || Qt) && (!k_src || K || Kt) && (!v_src || V || Vt), "m324_qkv_split: missing output");
-    M324_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "m324_qkv_split: leading dims must be multiples of 4");
+    const int al = dtype == M324_BF16 ? 8 : 4;          // 16-byte accesses
+    M324_REQUIRE(ldq % al == 0 && ldk % al == 0 && ldv % al == 0, "m324_qkv_split: leading dims must be multiples of %d", al);
     const int Lp = (L + 63) / 64 * 64;
     dim3 grid(Lp / 64, H, B);
     hipStream_t s = (hipStream_t)stream;
