@@ -542,6 +542,33 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ z, 
         Elem<T>::store(dz + i, Elem<T>::load(dh + i) * (cdf + x * pdf));
     }
 }
+// n % 8 == 0, 16-byte aligned operands: eight values per thread
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd8_kernel(const T* __restrict__ z, T* __restrict__ h, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8];
+        load8(z + i * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+        store8(h + i * 8, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd8_kernel(const T* __restrict__ z, const T* __restrict__ dh, T* __restrict__ dz,
+                                                        long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float x[8], g[8];
+        load8(z + i * 8, x);
+        load8(dh + i * 8, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float cdf = 0.5f * (1.0f + erff(x[k] * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * x[k] * x[k]);
+            g[k] *= cdf + x[k] * pdf;
+        }
+        store8(dz + i * 8, g);
+    }
+}
 
 // LayerNorm backward, one wave per row (grid-stride over rows), 8 waves per workgroup:
 //   xh = (x - mean) * rstd ; g = dy * w ; dx += rstd * (g - mean(g) - xh * mean(g * xh))
@@ -821,6 +848,12 @@ extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int col
 extern "C" int m324_gelu(const void* z, void* h, long n, int dtype, void* stream) {
     M324_REQUIRE(z && h && n > 0, "m324_gelu: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (n % 8 == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)h % 16) == 0) {
+        const int nb8 = (int)((n / 8 + 255) / 256 < 8192 ? (n / 8 + 255) / 256 : 8192);
+        DISPATCH_DTYPE(dtype, "m324_gelu", hipLaunchKernelGGL(gelu_fwd8_kernel<T>, dim3(nb8), dim3(256), 0, s, (const T*)z, (T*)h, n / 8));
+        M324_CHECK_LAUNCH("m324_gelu");
+        return M324_OK;
+    }
     const int nb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     DISPATCH_DTYPE(dtype, "m324_gelu", hipLaunchKernelGGL(gelu_fwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)z, (T*)h, n));
     M324_CHECK_LAUNCH("m324_gelu");
@@ -830,6 +863,13 @@ extern "C" int m324_gelu(const void* z, void* h, long n, int dtype, void* stream
 extern "C" int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, void* stream) {
     M324_REQUIRE(z && dh && dz && n > 0, "m324_gelu_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (n % 8 == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)dh % 16) == 0 && ((uintptr_t)dz % 16) == 0) {
+        const int nb8 = (int)((n / 8 + 255) / 256 < 8192 ? (n / 8 + 255) / 256 : 8192);
+        DISPATCH_DTYPE(dtype, "m324_gelu_bwd",
+                       hipLaunchKernelGGL(gelu_bwd8_kernel<T>, dim3(nb8), dim3(256), 0, s, (const T*)z, (const T*)dh, (T*)dz, n / 8));
+        M324_CHECK_LAUNCH("m324_gelu_bwd");
+        return M324_OK;
+    }
     const int nb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     DISPATCH_DTYPE(dtype, "m324_gelu_bwd",
                    hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)z, (const T*)dh, (T*)dz, n));
