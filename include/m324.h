@@ -54,7 +54,8 @@ int m324_set_tunable(const char* name, int value);
  *             DINOv2 patch_embed.proj / qkv / proj / fc1 / fc2 (model/image_encoder/dino/model_dino.py:160-170,
  *             174-231,338-354).
  *   epilogue, in this order:  v = acc (+ bias[n]) ; v = gelu_erf(v) if act ; v *= gamma[n] ;
- *                             v += residual[(m % res_rows) * ldr + n] ; store as out_dtype at
+ *                             v += residual[(m % res_rows) * ldr + n]  (fp32 -- except when `residual` IS `C` and out_dtype is
+ *                             bf16: then it is the bf16 stream being updated in place) ; store as out_dtype at
  *                             C[out_row(m) * ldc + n],  out_row(m) = (m / row_gin) * row_gout + m % row_gin + row_off.
  *   constraints: K % 64 == 0 (bf16) / K % 32 == 0 (f32) -- pad K with zeros; A, W rows 16-byte aligned.
  *   batch > 1 runs independent problems in one launch (used for split-K weight gradients: the token dimension is cut
@@ -115,6 +116,11 @@ int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, float* C, lon
 int m324_layernorm(const float* x, long ldx, const float* w, const float* b, float eps,
                    void* y, long ldy, int out_dtype, int rows, int C,
                    int gin, int gout, int off, void* stream);
+/* The same with the input's dtype given: x_dtype = M324_BF16 (bf16 output only) reads a bf16 residual stream -- the
+ * decoder's in bf16 inference, where x is two additions deep and its LayerNorm output is rounded to bf16 anyway. */
+int m324_layernorm_in(const void* x, int x_dtype, long ldx, const float* w, const float* b, float eps,
+                      void* y, long ldy, int out_dtype, int rows, int C,
+                      int gin, int gout, int off, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * m324_qkv_split: head-major operands for m324_attention from token-major projections.

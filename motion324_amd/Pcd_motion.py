@@ -32,6 +32,7 @@ from .prepared import Prepared, bump_generation, compute_dtype, pad_k
 from .timing import span
 from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
+BF16_DECODER_STREAM = os.environ.get("M324_BF16_DECODER", "1") != "0"   # A/B switch: the decoder's residual stream in bf16 (bf16 inference only)
 HOIST_DECODER_Q = os.environ.get("M324_HOIST_Q", "1") != "0"    # A/B switch of the hoisted decoder q projection (forward())
 DECODE_ROWS = int(os.environ.get("M324_DECODE_ROWS", 1 << 17))     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
 
@@ -413,7 +414,8 @@ class Motion_Latent_Model(nn.Module):
                 with span("stage:decoder_cross_attn_block", 0.0):
                     if hoisted is None:
                         Q = dec.project_q(P, pf, 1, n1 - n0)
-                    x = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True)
+                    x = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True,
+                                   bf16_stream=BF16_DECODER_STREAM)
                 if cap is not None and n0 == 0 and n1 == N:
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
                 h = torch.empty(x.shape, dtype=P.dtype, device=dev)

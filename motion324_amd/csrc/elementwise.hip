@@ -53,16 +53,16 @@ __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
 }
 
 // ----------------------------------------------------------------------------------- layernorm
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+template <typename T, typename TX = float>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
                                                         int rows, int C, int gin, int gout, int off) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + remap_row(row, gin, gout, off) * ldx;
+    const TX* xr = x + remap_row(row, gin, gout, off) * ldx;
     float4 v[LN_MAXV];
-    row_load(v, xr, lane, C);
+    LN_FOR(i, c) v[i] = load4<TX>(xr + c);
     float mean, rstd;
     row_stats(v, lane, C, eps, mean, rstd);
     T* yr = y + row * ldy;
@@ -641,6 +641,19 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const flo
     if ((dtype) == M324_BF16) { using T = bf16_t; __VA_ARGS__; }          \
     else if ((dtype) == M324_F32) { using T = float; __VA_ARGS__; }       \
     else M324_FAIL(M324_ERR_UNSUPPORTED, name ": dtype %d", (int)(dtype))
+
+extern "C" int m324_layernorm_in(const void* x, int x_dtype, long ldx, const float* w, const float* b, float eps, void* y, long ldy,
+                                 int out_dtype, int rows, int C, int gin, int gout, int off, void* stream) {
+    if (x_dtype == M324_F32) return m324_layernorm((const float*)x, ldx, w, b, eps, y, ldy, out_dtype, rows, C, gin, gout, off, stream);
+    M324_REQUIRE(x && w && y, "m324_layernorm_in: null pointer");
+    M324_REQUIRE(x_dtype == M324_BF16 && out_dtype == M324_BF16, "m324_layernorm_in: a bf16 input needs a bf16 output");
+    M324_REQUIRE(rows > 0 && C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV && ldx % 4 == 0 && ldy % 4 == 0,
+                 "m324_layernorm_in: rows=%d C=%d ldx=%ld ldy=%ld unsupported", rows, C, ldx, ldy);
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, w, b, eps, (bf16_t*)y, ldy, rows, C, gin, gout, off);
+    M324_CHECK_LAUNCH("m324_layernorm_in");
+    return M324_OK;
+}
 
 extern "C" int m324_layernorm(const float* x, long ldx, const float* w, const float* b, float eps, void* y, long ldy,
                               int out_dtype, int rows, int C, int gin, int gout, int off, void* stream) {

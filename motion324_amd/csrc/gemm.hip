@@ -770,7 +770,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const bf16_t* __restri
         x.x *= g.x; x.y *= g.y; x.z *= g.z; x.w *= g.w;
     }
     if (ep.residual) {
-        const float4 r = *reinterpret_cast<const float4*>(ep.residual + (long)rrow * ep.ldr + n);
+        const float4 r = ep.res_out ? load4_out<TOUT>(reinterpret_cast<const TOUT*>(ep.residual) + (long)rrow * ep.ldr + n)
+                                    : *reinterpret_cast<const float4*>(ep.residual + (long)rrow * ep.ldr + n);
         x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
     }
     store4_out<TOUT>(C + orow * ldc + n, x.x, x.y, x.z, x.w);
@@ -1086,7 +1087,8 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                 a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode,
                 {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
                 a->qkv_L, a->qkv_H, a->aux_mode == M324_AUX_QKV_HEADS_VT ? 1 : 0,
-                (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > (128l << 20)) ? 1 : 0};
+                (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > (128l << 20)) ? 1 : 0,
+                (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
     const int variant = nbatch > 1 ? 2 : pick_variant(a);

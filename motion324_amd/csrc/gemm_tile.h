@@ -24,6 +24,7 @@ struct Epilogue {
     int qkv_L, qkv_H;
     int qkv_vt;                  // M324_AUX_QKV_HEADS_VT: qkv_out[2] is Vt [B, H, 64, L] (key quarters of every 16 in the order 0,2,1,3)
     int stream;                  // bf16 outputs without residual: store non-temporal (host: output larger than the MALL keeps)
+    int res_out;                 // the residual has the OUTPUT's dtype (host: residual aliases a bf16 C -- a bf16 residual stream updated in place)
 };
 
 // gemm_ring4.hip (own translation unit: built WITHOUT -amdgpu-mfma-vgpr-form, its 256 accumulators live in AGPRs).
@@ -281,7 +282,8 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], TOUT* 
                 for (int r = 0; r < 16; ++r) {
                     int mc = min(mb + (r & 3) + 8 * (r >> 2), M - 1);
                     if (res_mod) mc %= ep.res_rows;
-                    res[r] = ep.residual[(long)mc * ep.ldr + nc];
+                    res[r] = ep.res_out ? Elem<TOUT>::load(reinterpret_cast<const TOUT*>(ep.residual) + (long)mc * ep.ldr + nc)
+                                        : ep.residual[(long)mc * ep.ldr + nc];
                 }
             }
 #pragma unroll
@@ -378,7 +380,8 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                         mr = CHECK ? min(mb + 4 * p, M - 1) : mb + 4 * p;
                         if (res_mod) mr %= ep.res_rows;
                     }
-                    res[p] = *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
+                    res[p] = ep.res_out ? load4_out<TOUT>(reinterpret_cast<const TOUT*>(ep.residual) + (long)mr * ep.ldr + ncl)
+                                        : *reinterpret_cast<const float4*>(ep.residual + (long)mr * ep.ldr + ncl);
                 }
             }
             if constexpr (ACT == 3) {
@@ -419,7 +422,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             }
         }
     };
-    // bf16 interior tiles without residual / row remap: 8 columns per lane, so a row is 8 lanes x 16 bytes and one
+    // bf16 interior tiles without row remap (residual: fp32, or the bf16 stream itself): 8 columns per lane, so a row is 8 lanes x 16 bytes and one
     // store instruction writes 8 whole 128-byte lines (half as many store instructions as the 4-column form)
     auto body8 = [&]() {
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
@@ -436,13 +439,33 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            float4 v0[4], v1[4], z0[4], z1[4];
+            float4 v0[4], v1[4], z0[4], z1[4], ra[4], rb[4];
             if constexpr (ACT == 3) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const TOUT* zp = static_cast<const TOUT*>(ep.aux) + (long)(mw + i * 32 + p * 8 + r8) * ep.ldaux + n8;
                     z0[p] = load4_out<TOUT>(zp);
                     z1[p] = load4_out<TOUT>(zp + 4);
+                }
+            }
+            if constexpr (RES != 0) {
+                // residual rows of the 4 passes: same row, or row modulo res_rows (one division per block, then steps of 8);
+                // 16 bytes per lane when the residual is the bf16 stream itself, two float4 when it is fp32
+                int mr = mw + i * 32 + r8;
+                if (res_mod) mr %= ep.res_rows;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (ep.res_out) {
+                        const TOUT* rp = reinterpret_cast<const TOUT*>(ep.residual) + (long)mr * ep.ldr + n8;
+                        ra[p] = load4_out<TOUT>(rp);
+                        rb[p] = load4_out<TOUT>(rp + 4);
+                    } else {
+                        const float* rp = ep.residual + (long)mr * ep.ldr + n8;
+                        ra[p] = *reinterpret_cast<const float4*>(rp);
+                        rb[p] = *reinterpret_cast<const float4*>(rp + 4);
+                    }
+                    mr += 8;
+                    if (res_mod) { while (mr >= ep.res_rows) mr -= ep.res_rows; }
                 }
             }
 #pragma unroll
@@ -463,6 +486,10 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 if (ep.gamma) {
                     x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
                     y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
+                }
+                if constexpr (RES != 0) {
+                    x.x += ra[p].x; x.y += ra[p].y; x.z += ra[p].z; x.w += ra[p].w;
+                    y.x += rb[p].x; y.y += rb[p].y; y.z += rb[p].z; y.w += rb[p].w;
                 }
                 if constexpr (ACT == 3) {
                     x.x *= gelu_grad<TOUT>(z0[p].x); x.y *= gelu_grad<TOUT>(z0[p].y);
@@ -563,8 +590,11 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
         body_qkv();
         return;
     }
-    if constexpr (sizeof(TOUT) == 2 && RES == 0 && ACT != 4) {
-        if (interior && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+    if constexpr (sizeof(TOUT) == 2 && ACT != 4) {
+        // with a residual: it must be present, without output row remap, and 16-byte addressable in its own dtype
+        const bool res8 = RES == 0 || (has_res && !remap && (reinterpret_cast<uintptr_t>(ep.residual) & 15) == 0 &&
+                                       (ep.ldr & (ep.res_out ? 7 : 3)) == 0 && (!res_mod || ep.res_rows >= 8));
+        if (interior && res8 && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
             (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0) &&
             (ACT < 2 || ((ep.ldaux & 7) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0))) {
             body8();

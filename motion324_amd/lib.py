@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class M324Error(RuntimeError):
@@ -55,6 +55,7 @@ SIGNATURES = {
     "m324_attention_plan": [_I, _I, _I, _I, _I, _I, C.c_char_p, _I],
     "m324_gemm_tn": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _L, _P],
     "m324_layernorm": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "m324_layernorm_in": [_P, _I, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m324_attention": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _I, _P, _I, _P],
     "m324_patchify": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -162,8 +162,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     args.act = act
     args.gamma = _vec(gamma, N, "gamma")
     if residual is not None:
-        if residual.dtype != torch.float32:
-            raise L.M324Error("gemm: residual must be fp32")
+        in_place_bf16 = residual.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and residual.data_ptr() == out.data_ptr()
+        if residual.dtype != torch.float32 and not in_place_bf16:
+            raise L.M324Error("gemm: residual must be fp32 (or the bf16 output itself, updated in place)")
         args.residual, args.ldr = _rows(residual, "residual")
         args.res_rows = res_rows
     gin, gout, off = row_map
@@ -186,7 +187,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     # algorithmic bytes: both operands once, the output once, the fp32 residual rows once
     nbytes = esz * (M * K + N * K) + out.element_size() * M * N
     if residual is not None:
-        nbytes += 4 * N * (res_rows if 0 < res_rows < M else M)
+        nbytes += residual.element_size() * N * (res_rows if 0 < res_rows < M else M)
     with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, nbytes, tag):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     return out
@@ -194,8 +195,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float, out: torch.Tensor,
               rows: Optional[int] = None, row_map=(0, 0, 0)) -> torch.Tensor:
-    if x.dtype != torch.float32:
-        raise L.M324Error("layernorm: x must be fp32")
+    if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16):
+        raise L.M324Error("layernorm: x must be fp32 (or bf16 with a bf16 output)")
     px, ldx = _rows(x, "x")
     py, ldy = _rows(out, "out")
     Cdim = x.shape[1]
@@ -204,6 +205,10 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: 
     need = ((rows - 1) // gin * gout + (rows - 1) % gin + off + 1) if gin > 0 else rows
     if x.shape[0] < need or out.shape[0] < rows or out.shape[1] != Cdim:
         raise L.M324Error("layernorm: shape mismatch")
+    if x.dtype == torch.bfloat16:
+        L.check(L.load().m324_layernorm_in(px, BF16, ldx, _vec(w, Cdim, "w"), _vec(b, Cdim, "b"), eps, py, ldy, code_of(out.dtype),
+                                           rows, Cdim, gin, gout, off, _stream()), "m324_layernorm_in")
+        return out
     L.check(L.load().m324_layernorm(px, ldx, _vec(w, Cdim, "w"), _vec(b, Cdim, "b"), eps, py, ldy, code_of(out.dtype),
                                     rows, Cdim, gin, gout, off, _stream()), "m324_layernorm")
     return out

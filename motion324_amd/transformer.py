@@ -242,13 +242,18 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         _, K, Vt = ops.qkv_split(None, kvp[:, :a.dim], kvp[:, a.dim:], None, kw, RMS_EPS, B, Lk, a.num_heads, P.dtype)
         return K, Vt
 
-    def attend(self, P: Prepared, Q, K, Vt, residual: torch.Tensor, res_rows: int, shared_q: bool) -> torch.Tensor:
-        """x = residual[(row % res_rows)] + fc(attention); x += mlp(LN x).  Returns fp32 [B*Lq, C]."""
+    def attend(self, P: Prepared, Q, K, Vt, residual: torch.Tensor, res_rows: int, shared_q: bool,
+               bf16_stream: bool = False) -> torch.Tensor:
+        """x = residual[(row % res_rows)] + fc(attention); x += mlp(LN x).  Returns fp32 [B*Lq, C] -- or, with bf16_stream in
+        bf16 inference, the same in bf16: the decoder's stream is two additions deep and only feeds a LayerNorm whose output
+        is rounded to bf16 anyway (+1.6e-3 on pcd_moved against 4.7e-3 of the bf16 mode as a whole), while its fp32 form costs
+        the out-projection, the MLP and both LayerNorms 400 MB of traffic per clip."""
         a = self.attn
         B, Lq = K.shape[0], Q.shape[2]
         o = torch.empty((B * Lq, a.dim), dtype=P.dtype, device=Q.device)
         ops.attention(Q, K, Vt, o, shared_q=shared_q, prescaled=True)
-        x = torch.empty((B * Lq, a.dim), dtype=torch.float32, device=Q.device)
+        xdt = torch.bfloat16 if (bf16_stream and P.dtype == torch.bfloat16 and not torch.is_grad_enabled()) else torch.float32
+        x = torch.empty((B * Lq, a.dim), dtype=xdt, device=Q.device)
         ops.gemm(o, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=residual, res_rows=res_rows)
         return _mlp_residual(P, self.norm2, self.mlp, x)
 

@@ -97,6 +97,49 @@ def test_gemm_inplace_residual(dtype):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
+@pytest.mark.parametrize("variant", ["v0", "v1", "v2", "v7", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("M,N", [(3 * 256, 768), (2 * 230, 328), (40, 192)])
+def test_gemm_bf16_residual_stream(tune, variant, M, N):
+    """The decoder's bf16 residual stream (bf16 inference): (1) bf16 output + fp32 residual broadcast over row groups (the
+    out-projection over the mesh points), (2) x += A W^T + b with x the bf16 OUTPUT ITSELF (the MLP's second Linear in place:
+    m324_gemm reads `residual` in the output's dtype exactly when it aliases C).  Interior tiles take the 8-column epilogue,
+    ragged ones the 4-column one, small M the skinny / direct kernels: all must agree with fp64 to bf16 rounding."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    K = 192
+    if variant != "v0":
+        tune("M324_GEMM", variant)
+    a, w = _q(_rand((M, K), 81), dtype), _q(_rand((N, K), 82, 0.1), dtype)
+    bias = _rand((N,), 83)
+    ad, wd, bd = a.to(dtype).to(DEV), w.to(dtype).to(DEV), bias.to(DEV)
+    prod = a.double() @ w.double().T + bias.double()
+    groups = 2 if M % 2 == 0 else 1
+    res = _rand((M // groups, N), 84)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(ad, wd, out, bias=bd, residual=res.to(DEV), res_rows=M // groups)
+    assert rel_err(out.float(), prod + res.double().repeat(groups, 1)) < 4e-3
+    x0 = _q(_rand((M, N), 85), dtype)
+    x = x0.to(dtype).to(DEV)
+    ops.gemm(ad, wd, x, bias=bd, residual=x)
+    assert rel_err(x.float(), prod + x0.double()) < 4e-3
+    with pytest.raises(Exception):                     # a bf16 residual that is NOT the output would be read as fp32: rejected
+        ops.gemm(ad, wd, out, residual=x)
+
+
+@pytest.mark.parametrize("rows,C,with_bias", [(77, 768, True), (4 * 19 + 1, 192, False)])
+def test_layernorm_bf16_input(rows, C, with_bias):
+    """m324_layernorm_in with a bf16 input row (the decoder's bf16 stream): statistics in fp32 on the rounded values."""
+    ops = _ops()
+    x = _q(_rand((rows, C), 91) * 2 + 0.3, torch.bfloat16)
+    w, b = 1 + 0.1 * _rand((C,), 92), (_rand((C,), 93) if with_bias else None)
+    out = torch.empty((rows, C), dtype=torch.bfloat16, device=DEV)
+    ops.layernorm(x.to(torch.bfloat16).to(DEV), w.to(DEV), None if b is None else b.to(DEV), 1e-5, out)
+    ref = torch.nn.functional.layer_norm(x.double(), (C,), w.double(), None if b is None else b.double(), 1e-5)
+    assert rel_err(out.float(), ref) < 4e-3
+    with pytest.raises(Exception):
+        ops.layernorm(x.to(torch.bfloat16).to(DEV), w.to(DEV), None, 1e-5, torch.empty((rows, C), dtype=torch.float32, device=DEV))
+
+
 @pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v7", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("K", [64, 192, 832])

@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     const Shape shapes[] = {
         {"trunk qkv", 10368, 2304, 768, 0},   {"trunk fc+res", 10368, 768, 768, 2},  {"trunk fc1 gelu", 10368, 3072, 768, 1},
         {"trunk fc2+res", 10368, 768, 3072, 2}, {"dino qkv", 8224, 2304, 768, 3},     {"dino fc1 gelu", 8224, 3072, 768, 1},
-        {"dino fc2+res", 8224, 768, 3072, 2},  {"dino fc+res", 8224, 768, 768, 2}, {"dec fc+res", 65536, 768, 768, 2}, {"dec fc+bres", 65536, 768, 768, 6}, {"dec fc f32", 65536, 768, 768, 7}, {"dec fc bf16", 65536, 768, 768, 0},    {"dec fc1 gelu", 65536, 3072, 768, 1},
+        {"dino fc2+res", 8224, 768, 3072, 2},  {"dino fc+res", 8224, 768, 768, 2}, {"dec fc+res", 65536, 768, 768, 2}, {"dec fc+bres", 65536, 768, 768, 6}, {"dec fc f32", 65536, 768, 768, 7}, {"dec fc bf16", 65536, 768, 768, 0}, {"dec fc b16+bres", 65536, 768, 768, 8}, {"dec fc2 b16 inpl", 65536, 768, 3072, 9},    {"dec fc1 gelu", 65536, 3072, 768, 1},
         {"dec fc1 plain", 65536, 3072, 768, 0}, {"dec fc2+res", 65536, 768, 3072, 2}, {"square 4096", 4096, 4096, 4096, 0},
         {"square 8192", 8192, 8192, 8192, 0},   {"pcd fc2", 64, 768, 3072, 2},         {"pcd fc1 gelu", 64, 3072, 768, 1},
         {"pcd qkv", 64, 2304, 768, 0},          {"pcd fc", 64, 768, 768, 2},
@@ -110,7 +110,8 @@ int main(int argc, char** argv) {
         a.act = s.epi == 1 ? M324_ACT_GELU : M324_ACT_NONE;
         if (s.epi == 2) { a.residual = (const float*)dC; a.ldr = s.N; }
         void* dBR = nullptr;
-        if (s.epi == 6) {
+        if (s.epi == 9) { a.residual = (const float*)dC; a.ldr = s.N; }
+        if (s.epi == 6 || s.epi == 8) {
             std::vector<float> hbr((size_t)2048 * s.N);
             for (auto& v : hbr) v = (rand() / (float)RAND_MAX - 0.5f);
             HIP_OK(hipMalloc(&dBR, hbr.size() * 4));
@@ -136,7 +137,7 @@ int main(int argc, char** argv) {
             settun("M324_GEMM", variant);
             m324_gemm_args b = a;
             b.C = out;
-            if (s.epi == 2) b.residual = (const float*)out;
+            if (s.epi == 2 || s.epi == 9) b.residual = (const float*)out;
             int rc = gemm(&b, st);
             if (rc) { char buf[256]; lasterr(buf, 256); fprintf(stderr, "m324_gemm v%d: %s\n", variant, buf); exit(3); }
         };
