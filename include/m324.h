@@ -33,7 +33,11 @@ typedef enum { M324_ACT_NONE = 0, M324_ACT_GELU = 1 } m324_act;
  *   M324_AUX_MUL_GELU_GRAD : the result is multiplied by gelu'(aux[m,n]) = Phi(z) + z phi(z) before it is stored -- the
  *                            dgrad GEMM of the MLP's second Linear then delivers d(pre-activation) directly.           */
 typedef enum { M324_AUX_NONE = 0, M324_AUX_STORE_PREACT = 1, M324_AUX_MUL_GELU_GRAD = 2, M324_AUX_QKV_HEADS = 3,
-               M324_AUX_QKV_HEADS_VT = 4 } m324_aux_mode;
+               M324_AUX_QKV_HEADS_VT = 4, M324_AUX_N3 = 5 } m324_aux_mode;
+/*   M324_AUX_N3 (inference, bf16): the regression head Linear -> GELU -> Linear(N -> 3) (Pcd_motion.py:336-341) without its
+ *   [M, N] intermediate: h = gelu(A W^T + bias) is contracted with the [3, N] fp32 weight passed in qkv_qw inside the
+ *   epilogue and only partial sums leave, aux = float part[N / 64][M][3] (C may be NULL); m324_n3_finish adds the N / 64
+ *   column blocks in a fixed order and the last layer's bias.  N % 256 == 0, K % 64 == 0, K >= 128.                       */
 
 /* ABI version of this header (bumped on any signature change). */
 int m324_abi_version(void);
@@ -92,6 +96,9 @@ int m324_gemm(const m324_gemm_args* a, void* stream);
  * launch for `a` into buf; returns the schedule number.  bench.py labels its per-launch HIP-event rows with it so that
  * they can be matched against the committed rocprofv3 summaries (profiles/). */
 int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n);
+
+/* out[m][j] = bias3[j] + sum over the ncb column blocks of part[cb][m][j]  (the second half of M324_AUX_N3). */
+int m324_n3_finish(const float* part, int ncb, int M, const float* bias3, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * m324_gemm_tn: C[s][n][j] (fp32) = sum over the tokens m of slice s of X[m, n] * Y[m, j]  -- the weight gradient

@@ -32,6 +32,7 @@ from .prepared import Prepared, bump_generation, compute_dtype, pad_k
 from .timing import span
 from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
+FUSE_HEAD_N3 = os.environ.get("M324_FUSE_HEAD", "1") != "0"        # A/B switch: head fc1 + GELU + 768 -> 3 in one GEMM epilogue (bf16 inference)
 BF16_DECODER_STREAM = os.environ.get("M324_BF16_DECODER", "1") != "0"   # A/B switch: the decoder's residual stream in bf16 (bf16 inference only)
 HOIST_DECODER_Q = os.environ.get("M324_HOIST_Q", "1") != "0"    # A/B switch of the hoisted decoder q projection (forward())
 DECODE_ROWS = int(os.environ.get("M324_DECODE_ROWS", 1 << 17))     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
@@ -420,13 +421,19 @@ class Motion_Latent_Model(nn.Module):
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
                 h = torch.empty(x.shape, dtype=P.dtype, device=dev)
                 ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
-                h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
-                ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
-                if n0 == 0 and n1 == N:
-                    ops.linear_n3(h2, w3, b3, out[b])
+                whole = n0 == 0 and n1 == N
+                o = out[b] if whole else torch.empty((T, n1 - n0, 3), dtype=torch.float32, device=dev)
+                if FUSE_HEAD_N3 and P.dtype == torch.bfloat16 and C % 256 == 0 and not torch.is_grad_enabled():
+                    # Linear -> GELU -> Linear(C -> 3) without the [rows, C] intermediate: the first GEMM's epilogue contracts
+                    # its GELU output with the 3 x C weight and leaves C / 64 partial sums per row (M324_AUX_N3)
+                    part = torch.empty((C // 64, x.shape[0], 3), dtype=torch.float32, device=dev)
+                    ops.gemm(h, P.mat(head_fc1.weight), None, bias=P.vec(head_fc1.bias), act=ACT_GELU, n3=(w3, part))
+                    ops.n3_finish(part, b3, o)
                 else:
-                    o = torch.empty((T, n1 - n0, 3), dtype=torch.float32, device=dev)
+                    h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
+                    ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
                     ops.linear_n3(h2, w3, b3, o)
+                if not whole:
                     out[b, :, n0:n1] = o
         if cap is not None and "decoder_out_t0" in cap:
             cap["decoder_out_t0"] = torch.stack(cap["decoder_out_t0"], dim=0)

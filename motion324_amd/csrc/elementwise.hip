@@ -635,6 +635,16 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const flo
     }
 }
 
+// second half of M324_AUX_N3: out[m][j] = bias[j] + sum_cb part[cb][m][j]; thread per output value, blocks added in order
+__global__ __launch_bounds__(256) void n3_finish_kernel(const float* __restrict__ part, int ncb, int M, const float* __restrict__ bias3,
+                                                        float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * 3) return;
+    float s = bias3[i % 3];
+    for (int cb = 0; cb < ncb; ++cb) s += part[(long)cb * M * 3 + i];
+    out[i] = s;
+}
+
 }  // namespace
 
 #define DISPATCH_DTYPE(dtype, name, ...)                                  \
@@ -744,6 +754,13 @@ extern "C" int m324_assemble_tokens(const float* dino_x, const float* dino_w, co
     hipLaunchKernelGGL(assemble_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, dino_x, dino_w, dino_b,
                        eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, out, B, T, K, P, C, drop_thr, drop_scale, drop_seed);
     M324_CHECK_LAUNCH("m324_assemble_tokens");
+    return M324_OK;
+}
+
+extern "C" int m324_n3_finish(const float* part, int ncb, int M, const float* bias3, float* out, void* stream) {
+    M324_REQUIRE(part && bias3 && out && ncb > 0 && M > 0, "m324_n3_finish: bad arguments");
+    hipLaunchKernelGGL(n3_finish_kernel, dim3(ceil_div((long)M * 3, 256)), dim3(256), 0, (hipStream_t)stream, part, ncb, M, bias3, out);
+    M324_CHECK_LAUNCH("m324_n3_finish");
     return M324_OK;
 }
 

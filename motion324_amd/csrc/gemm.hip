@@ -1091,6 +1091,17 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                 (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
+    if (a->aux_mode == M324_AUX_N3) {              // one schedule only: the 256 x 256 chunk ring (host-checked shape)
+        if constexpr (sizeof(TOUT) == 2 && sizeof(TIN) == 2) {
+            hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 5, 0>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+                               (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (bf16_t*)a->C, a->ldc, a->M, a->N, a->K, ep,
+                               ceil_div(a->N, BN5), xcd_mode(a));
+            M324_CHECK_LAUNCH("m324_gemm");
+            return M324_OK;
+        } else {
+            M324_FAIL(M324_ERR_UNSUPPORTED, "m324_gemm: M324_AUX_N3 is a bf16 mode");
+        }
+    }
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
     if (variant == 1) {
         hipLaunchKernelGGL((gemm_kernel<TIN, TOUT>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda, (const TIN*)a->W,
@@ -1147,6 +1158,10 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
 extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
     M324_REQUIRE(a && buf && n > 0, "m324_gemm_plan: bad arguments");
     const int nbatch = a->batch > 1 ? a->batch : 1;
+    if (a->aux_mode == M324_AUX_N3) {
+        snprintf(buf, (size_t)n, "gemm_ring_kernel<unsigned short, 5, 0> grid=%ldx1x1", (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5) * 512);
+        return 10;
+    }
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
     const char* tout = a->out_dtype == M324_BF16 ? "unsigned short" : "float";
     const char* tin = a->in_dtype == M324_BF16 ? "unsigned short" : "float";
@@ -1208,7 +1223,8 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
 
 extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
     const bool qkv_mode = a && (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT);
-    M324_REQUIRE(a && a->A && a->W && (a->C || qkv_mode), "m324_gemm: null pointer");
+    const bool n3_mode = a && a->aux_mode == M324_AUX_N3;
+    M324_REQUIRE(a && a->A && a->W && (a->C || qkv_mode || n3_mode), "m324_gemm: null pointer");
     M324_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "m324_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     const int bk = a->in_dtype == M324_BF16 ? 64 : 32;
     M324_REQUIRE(a->K % bk == 0, "m324_gemm: K=%d must be a multiple of %d", a->K, bk);
@@ -1220,7 +1236,15 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
     M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
                  "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
-    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 4, "m324_gemm: aux_mode %d", a->aux_mode);
+    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 5, "m324_gemm: aux_mode %d", a->aux_mode);
+    if (n3_mode) {
+        M324_REQUIRE(a->aux && a->qkv_qw && a->act == M324_ACT_GELU && !a->residual && !a->gamma && a->row_gin <= 0 && a->batch <= 1,
+                     "m324_gemm: M324_AUX_N3 = Linear + GELU + [3, N] contraction: aux (partial sums) and qkv_qw (the [3, N] weight) "
+                     "must be given, no residual / gamma / row map / batch");
+        M324_REQUIRE(a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16 && a->N % 256 == 0 && a->K % 64 == 0 && a->K >= 128,
+                     "m324_gemm: M324_AUX_N3 needs bf16, N %% 256 == 0, K %% 64 == 0, K >= 128 (N=%d K=%d)", a->N, a->K);
+        M324_REQUIRE(((uintptr_t)a->qkv_qw % 16) == 0 && (!a->bias || ((uintptr_t)a->bias % 16) == 0), "m324_gemm: M324_AUX_N3 operands misaligned");
+    }
     if (qkv_mode) {
         M324_REQUIRE(a->aux_mode != M324_AUX_QKV_HEADS_VT || a->qkv_L % 128 == 0,
                      "m324_gemm: M324_AUX_QKV_HEADS_VT needs qkv_L %% 128 == 0 (L=%d)", a->qkv_L);
@@ -1231,7 +1255,7 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
         M324_REQUIRE(((uintptr_t)a->qkv_q % 16) == 0 && ((uintptr_t)a->qkv_k % 16) == 0 && ((uintptr_t)a->qkv_v % 16) == 0 &&
                          (!a->qkv_qw || ((uintptr_t)a->qkv_qw % 16) == 0) && (!a->qkv_kw || ((uintptr_t)a->qkv_kw % 16) == 0),
                      "m324_gemm: misaligned qkv outputs / norm weights");
-    } else if (a->aux_mode) {
+    } else if (a->aux_mode && !n3_mode) {
         const int osz = a->out_dtype == M324_BF16 ? 2 : 4;
         M324_REQUIRE(a->aux && a->ldaux >= a->N && a->ldaux % 4 == 0 && ((uintptr_t)a->aux % (4 * osz)) == 0 && vec_ok(a) &&
                          a->row_gin <= 0 && a->batch <= 1,

@@ -585,9 +585,67 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             }
         }
     };
+    // M324_AUX_N3 (the head: Linear -> GELU -> Linear 768 -> 3): the GELU output is not stored at all; every wave contracts its
+    // 64 columns with the three rows of the last layer's weight and writes 3 partial sums per row into part[column block][M][3]
+    // (8 consecutive rows = 96 contiguous bytes per store group); m324_n3_finish adds the N / 64 column blocks in a fixed order.
+    auto body_n3 = [&]() {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+        const int n8 = nw + c8;
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
+        float4 w0[3], w1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            w0[j] = *reinterpret_cast<const float4*>(ep.qkv_w[0] + (long)j * N + n8);
+            w1[j] = *reinterpret_cast<const float4*>(ep.qkv_w[0] + (long)j * N + n8 + 4);
+        }
+        const float* rd8 = scr + r8 * EP_LD + c8;
+        float* part = static_cast<float*>(ep.aux) + (long)(nw >> 6) * M * 3;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            float4 v0[4], v1[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
+                v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 x = v0[p], y = v1[p];
+                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                apply_gelu8<TOUT>(x, y);
+                float sj[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float t = x.x * w0[j].x + x.y * w0[j].y + x.z * w0[j].z + x.w * w0[j].w + y.x * w1[j].x + y.y * w1[j].y +
+                              y.z * w1[j].z + y.w * w1[j].w;
+                    t += __shfl_xor(t, 1, 64);
+                    t += __shfl_xor(t, 2, 64);
+                    t += __shfl_xor(t, 4, 64);
+                    sj[j] = t;
+                }
+                const long m = mw + i * 32 + p * 8 + r8;
+                if ((lane & 7) == 0 && m < M && nw + 64 <= N) {
+                    float* o = part + m * 3;
+                    o[0] = sj[0]; o[1] = sj[1]; o[2] = sj[2];
+                }
+            }
+        }
+    };
     const bool interior = mw + MI * 32 <= M && nw + 64 <= N;
     if constexpr (ACT == 4) {
         body_qkv();
+        return;
+    }
+    if constexpr (ACT == 5) {
+        body_n3();
         return;
     }
     if constexpr (sizeof(TOUT) == 2 && ACT != 4) {

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class M324Error(RuntimeError):
@@ -54,6 +54,7 @@ SIGNATURES = {
     "m324_gemm_plan": [C.POINTER(GemmArgs), C.c_char_p, _I],
     "m324_attention_plan": [_I, _I, _I, _I, _I, _I, C.c_char_p, _I],
     "m324_gemm_tn": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _L, _P],
+    "m324_n3_finish": [_P, _I, _I, _P, _P, _P],
     "m324_layernorm": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_layernorm_in": [_P, _I, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

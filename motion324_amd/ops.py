@@ -119,7 +119,7 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1) -> torch.Tensor:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = L.ACT_NONE, gamma=None,
          residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0),
          preact_out: Optional[torch.Tensor] = None, gelu_grad_of: Optional[torch.Tensor] = None,
-         qkv_heads: Optional[tuple] = None) -> torch.Tensor:
+         qkv_heads: Optional[tuple] = None, n3: Optional[tuple] = None) -> torch.Tensor:
     """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm.
     preact_out [M, N] (out's dtype) also receives the value the activation is applied to (M324_AUX_STORE_PREACT);
     gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only.
@@ -156,6 +156,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
                   f"{_gemm_plan(args)} | M={M} N={N} K={K} qkv-heads" if _timing() else ""):
             L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
         return Qo
+    if n3 is not None:
+        # n3 = (w3 fp32 [3, N], part fp32 [N / 64, M, 3]): gelu(a w^T + bias) is contracted with w3 in the epilogue
+        # (M324_AUX_N3); `out` is ignored (may be None); finish with n3_finish(part, bias3, out3)
+        w3, part = n3
+        if (a.dtype != torch.bfloat16 or w3.dtype != torch.float32 or tuple(w3.shape) != (3, N) or not w3.is_contiguous()
+                or part.dtype != torch.float32 or tuple(part.shape) != (N // 64, M, 3) or not part.is_contiguous()
+                or residual is not None or gamma is not None or act != L.ACT_GELU or N % 256):
+            raise L.M324Error(f"gemm: n3 mode needs bf16 operands, act=GELU, N % 256 == 0, w3 [3,{N}] and part [{N // 64},{M},3] fp32")
+        args.C, args.ldc = None, N
+        args.in_dtype, args.out_dtype = BF16, BF16
+        args.bias = _vec(bias, N, "bias")
+        args.act = act
+        args.aux, args.ldaux, args.aux_mode = _p(part), 3, 5
+        args.qkv_qw = _p(w3)
+        with span("gemm_bf16", 2.0 * M * N * K + 2.0 * M * N * 3, 2.0 * (M * K + N * K) + 4.0 * part.numel(),
+                  f"{_gemm_plan(args)} | M={M} N={N} K={K} gelu n3" if _timing() else ""):
+            L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
+        return part
     args.C, args.ldc = _rows(out, "out")
     args.in_dtype, args.out_dtype = code_of(a.dtype), code_of(out.dtype)
     args.bias = _vec(bias, N, "bias")
@@ -353,6 +371,16 @@ def linear_n3(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.T
         raise L.M324Error("linear_n3: out must be contiguous fp32 [M,3]")
     L.check(L.load().m324_linear_n3(pa, lda, _p(w), _vec(bias, 3, "bias"), _p(out), M, K, code_of(a.dtype), _stream()),
             "m324_linear_n3")
+    return out
+
+
+def n3_finish(part: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[M, 3] (fp32, contiguous) = bias + sum over the column blocks of part[ncb, M, 3] (second half of gemm(..., n3=...))."""
+    ncb, M, three = part.shape
+    if three != 3 or part.dtype != torch.float32 or not part.is_contiguous() or out.dtype != torch.float32 \
+            or not out.is_contiguous() or out.numel() != M * 3:
+        raise L.M324Error("n3_finish: part [ncb, M, 3] and out [M, 3] must be contiguous fp32")
+    L.check(L.load().m324_n3_finish(_p(part), ncb, M, _vec(bias, 3, "bias"), _p(out), _stream()), "m324_n3_finish")
     return out
 
 

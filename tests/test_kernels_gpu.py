@@ -126,6 +126,33 @@ def test_gemm_bf16_residual_stream(tune, variant, M, N):
         ops.gemm(ad, wd, out, residual=x)
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (3 * 256 + 37, 256, 128), (100, 512, 192)])
+def test_gemm_head_contraction_in_the_epilogue(M, N, K):
+    """M324_AUX_N3: gelu(A W^T + b) contracted with a [3, N] weight inside the GEMM epilogue (partial sums per 64-column block)
+    + m324_n3_finish == the unfused Linear -> GELU -> Linear(N -> 3) in fp64 (the fused form skips the bf16 rounding of the
+    intermediate, so it is compared against the exact value); ragged row counts leave the rows past M untouched."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    dtype = torch.bfloat16
+    a, w = _q(_rand((M, K), 95), dtype), _q(_rand((N, K), 96, 0.1), dtype)
+    bias, w3, b3 = _rand((N,), 97), _rand((3, N), 98, 0.2), _rand((3,), 99)
+    part = torch.full((N // 64, M, 3), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), None, bias=bias.to(DEV), act=ACT_GELU, n3=(w3.to(DEV), part))
+    assert bool(torch.isfinite(part).all())
+    out = torch.empty((M, 3), dtype=torch.float32, device=DEV)
+    ops.n3_finish(part, b3.to(DEV), out)
+    v = a.double() @ w.double().T + bias.double()
+    g = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+    ref = g @ w3.double().T + b3.double()
+    assert rel_err(out, ref) < 2e-3
+    # the unfused path on the same operands (bf16 intermediate) agrees to bf16 rounding
+    h2 = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), h2, bias=bias.to(DEV), act=ACT_GELU)
+    un = torch.empty((M, 3), dtype=torch.float32, device=DEV)
+    ops.linear_n3(h2, w3.to(DEV), b3.to(DEV), un)
+    assert rel_err(out, un.cpu().double()) < 4e-3
+
+
 @pytest.mark.parametrize("rows,C,with_bias", [(77, 768, True), (4 * 19 + 1, 192, False)])
 def test_layernorm_bf16_input(rows, C, with_bias):
     """m324_layernorm_in with a bf16 input row (the decoder's bf16 stream): statistics in fp32 on the rounded values."""
