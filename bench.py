@@ -69,6 +69,7 @@ def build_model(device, frames, train=False):
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.Dims(frames=frames), seed=0).items()}
     model.load_state_dict(sd, strict=False)
     model = (model.train() if train else model.eval()).to(device)
+    model.auto_graph = False              # the bench drives its graphs and its eager (instrumented) passes explicitly
     return model, sd
 
 

@@ -17,6 +17,8 @@ Only an update through raw pointers that bypasses torch's version counters needs
 """
 from __future__ import annotations
 
+import gc
+import weakref
 from typing import Dict, Tuple
 
 import torch
@@ -30,10 +32,17 @@ _KEYS = ("ref_shape_pcd", "ref_shape_normals", "ref_shape_rgbs", "ref_pcd", "ref
 
 
 class GraphedForward:
-    def __init__(self, model: torch.nn.Module, warmup: int = 2):
-        self.model = model
+    def __init__(self, model: torch.nn.Module, warmup: int = 2, weak: bool = False):
+        # weak: the model itself owns this object (Motion_Latent_Model's automatic graph replay) -- a strong reference back
+        # would make model <-> graphs cyclic garbage, which Python's collector may free at any time, e.g. in the middle
+        # of a LATER stream capture, where destroying a hipGraph aborts the process
+        self._model = weakref.ref(model) if weak else (lambda: model)
         self.warmup = warmup
         self._graphs: Dict[Tuple, tuple] = {}
+
+    @property
+    def model(self) -> torch.nn.Module:
+        return self._model()
 
     def reset(self) -> None:
         self._graphs.clear()
@@ -66,8 +75,15 @@ class GraphedForward:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
-                static_out = self.model(static_in)
+            gc_was_on = gc.isenabled()
+            gc.collect()
+            gc.disable()                      # no collector run may free a stream / event / graph while the capture is open
+            try:
+                with torch.no_grad(), torch.cuda.graph(g):
+                    static_out = self.model(static_in)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             entry = (g, static_in, static_out)
             self._graphs[key] = entry
         g, static_in, static_out = entry

@@ -192,6 +192,41 @@ def test_graph_replay_matches_eager():
     assert not torch.equal(a, b)
 
 
+def test_forward_switches_to_graph_replay_for_repeated_shapes():
+    """model(sample) in inference serves the third and later calls with the same shapes from a private hipGraph
+    (Pcd_motion._forward_auto_graph): same values bit for bit, the caller owns its result (a later call must not change
+    it), new shapes start eager again, and `model.auto_graph = False` keeps everything eager."""
+    import motion324_amd as m
+    model, dm = build("tiny")
+    sample = inputs("tiny", with_target=False)
+    m.set_precision("bf16")
+    try:
+        model.auto_graph = False
+        with torch.no_grad():
+            eager = model(sample).pcd_moved.clone()
+        assert "_ag" not in model.__dict__
+        model.auto_graph = True
+        with torch.no_grad():
+            outs = [model(sample).pcd_moved for _ in range(4)]
+        assert "_ag" in model.__dict__ and len(model.__dict__["_ag"]._graphs) == 1          # calls 3 and 4 replayed
+        assert all(torch.equal(o, eager) for o in outs)
+        assert outs[2].data_ptr() != outs[3].data_ptr()
+        sample2 = {k: (v * 0.5 if k == "rgb_video" else v) for k, v in sample.items()}
+        with torch.no_grad():
+            other = model(sample2).pcd_moved
+        assert torch.equal(outs[3], eager) and not torch.equal(other, eager)               # earlier results untouched
+        model.auto_graph = False
+        with torch.no_grad():
+            assert torch.equal(model(sample2).pcd_moved, other)
+        # grad mode on: always the eager path (which also skips the inference-only fused epilogues: equal to rounding only)
+        model.auto_graph = True
+        n_graphs = len(model.__dict__["_ag"]._graphs)
+        out = model(sample).pcd_moved
+        assert rel_err(out, eager) < 1e-2 and len(model.__dict__["_ag"]._graphs) == n_graphs
+    finally:
+        m.set_precision(None)
+
+
 def test_graph_static_inputs_are_a_zero_copy_handover():
     """GraphedForward.static_inputs returns the captured graph's own input tensors: a clip written into them in place is
     what the next replay reads (no copy made by the call), and the result equals the eager forward of the same values."""
