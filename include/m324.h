@@ -90,12 +90,35 @@ typedef struct {
     const float* qkv_qw; const float* qkv_kw;
     float qkv_eps, qkv_qscale;
     int qkv_L, qkv_H;
+    /* LayerNorm fold (bf16 inference): the LayerNorm in front of a Linear (transformer.py:365-376,400-423; DINOv2 norm1 /
+     * norm2; Pcd_motion.py:336-338) without its own pass over the residual stream.
+     *   consumer: A holds the RAW stream x (bf16) and W the weight with the LayerNorm scale folded in, W'[n,k] = w_ln[k] W[n,k];
+     *     ln_rowstat[m] = (rstd_m, -rstd_m mean_m), ln_colsum[n] = sum_k W'[n,k] (of the rounded bf16 values), and `bias` is
+     *     b[n] + sum_k b_ln[k] W[n,k].  The epilogue starts from  rstd_m acc - rstd_m mean_m colsum[n] + bias[n]
+     *     = Linear(LayerNorm(x_m)) and continues as usual (activation, q|k|v heads, N3 ...).
+     *   producer: ln_stats_out[cb][m] = (sum, sum of squared deviations from the block mean) over the 64 columns of block cb
+     *     of the values row m of C receives (fp32, before they are rounded to out_dtype); m324_rowstats_finish merges the
+     *     N / 64 blocks of a row (Chan's update: no E[x^2] - mean^2 cancellation) into ln_rowstat.  ln_copy_out (fp32 C only):
+     *     the same values once more as bf16 [M, ln_ldcopy] -- the consumer's A operand.
+     *   Needs M > 64, N % 64 == 0, K >= 128, no batch.  Built combinations: a consumer (ln_rowstat) has no residual, gamma
+     *   or row map, and a bf16 output behind GELU; a producer (ln_stats_out) is a residual update without activation, row
+     *   map or aux mode, with ln_copy_out exactly when C is fp32; one GEMM is never both. */
+    const float* ln_rowstat; const float* ln_colsum;
+    float* ln_stats_out;
+    void* ln_copy_out; long ln_ldcopy;
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
 /* Host-only: writes the kernel symbol (as rocprofv3 prints the template) and its grid in threads that m324_gemm would
  * launch for `a` into buf; returns the schedule number.  bench.py labels its per-launch HIP-event rows with it so that
  * they can be matched against the committed rocprofv3 summaries (profiles/). */
 int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n);
+
+/* LayerNorm fold, between producer and consumer: rowstat[m] = (rstd, -rstd mean) of row m from the ncb per-block
+ * (sum, M2) pairs part[cb][m] a producer GEMM left (blocks of 64 columns, C = 64 ncb);  eps as in nn.LayerNorm. */
+int m324_rowstats_finish(const float* part, int ncb, int M, float eps, float* rowstat, void* stream);
+/* The same table straight from an fp32 stream x [rows, C] (the head of a chain: token assembly / patch embedding
+ * output), plus the bf16 copy [rows, ldcopy] a folded consumer reads (copy may be NULL).  C % 4 == 0, C <= 1024. */
+int m324_rowstats(const float* x, long ldx, int rows, int C, float eps, float* rowstat, void* copy, long ldcopy, void* stream);
 
 /* out[m][j] = bias3[j] + sum over the ncb column blocks of part[cb][m][j]  (the second half of M324_AUX_N3). */
 int m324_n3_finish(const float* part, int ncb, int M, const float* bias3, float* out, void* stream);

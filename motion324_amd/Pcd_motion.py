@@ -30,7 +30,7 @@ from .lib import ACT_GELU, M324Error
 from .loss import MSELossComputer
 from .prepared import Prepared, bump_generation, compute_dtype, pad_k
 from .timing import span
-from .transformer import LN_EPS, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
+from .transformer import LN_EPS, LNFold, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
 AUTO_GRAPH = os.environ.get("M324_AUTO_GRAPH", "1") != "0"          # forward(): graph replay for repeated inference shapes
 FUSE_HEAD_N3 = os.environ.get("M324_FUSE_HEAD", "1") != "0"        # A/B switch: head fc1 + GELU + 768 -> 3 in one GEMM epilogue (bf16 inference)
@@ -294,18 +294,36 @@ class Motion_Latent_Model(nn.Module):
         from .graph import GraphedForward, _KEYS
         key = (compute_dtype(),) + tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
         seen = self.__dict__.setdefault("_ag_seen", {})
+        if key not in seen and len(seen) >= 8:               # a caller that keeps changing shapes: forget the oldest
+            del seen[next(iter(seen))]
         seen[key] = seen.get(key, 0) + 1
         if seen[key] <= self.auto_graph_after:
             return None
         ag = self.__dict__.get("_ag")
         if ag is None:
-            ag = GraphedForward(self, warmup=1, weak=True)
+            # at most two shape sets stay captured (each holds a clip's activations and its static inputs in a private
+            # pool); "thread_local": a DataLoader thread or another stream may keep calling into HIP during the capture
+            ag = GraphedForward(self, warmup=1, weak=True, max_graphs=2, capture_error_mode="thread_local")
             self.__dict__["_ag"] = ag                       # not a submodule: plain attribute
-        if len(ag._graphs) > 3:                             # a caller that keeps changing shapes: start over
-            ag.reset()
+        fresh = ag._key(sample) not in ag._graphs
+        if fresh:
+            n = self.__dict__.get("_ag_captures", 0) + 1
+            self.__dict__["_ag_captures"] = n
+            if n > 6:                                       # shapes cycle faster than graphs pay off: stay eager
+                self.auto_graph = False
+                self._drop_auto_graph()
+                return None
         self.__dict__["_ag_busy"] = True                    # the capture's own warm-up / capture forwards stay eager
         try:
             res = ag(sample)
+        except Exception:                                   # capture invalidated, out of memory in the private pool, ...:
+            self.auto_graph = False                         # the eager path still serves the call
+            self._drop_auto_graph()
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            return None
         finally:
             self.__dict__["_ag_busy"] = False
         out = edict(input_data=sample, pcd_moved=res.pcd_moved.clone())
@@ -315,6 +333,17 @@ class Motion_Latent_Model(nn.Module):
                 lm[k] = v.clone() if isinstance(v, torch.Tensor) else v
             out.loss_metrics = lm
         return out
+
+    def _drop_auto_graph(self) -> None:
+        for k in ("_ag", "_ag_seen", "_ag_captures"):
+            self.__dict__.pop(k, None)
+
+    def __getstate__(self):
+        # captured graphs are process-local device objects: copy.deepcopy / pickle / torch.save(model) go without them
+        state = self.__dict__.copy()
+        for k in ("_ag", "_ag_seen", "_ag_busy", "_ag_captures", "_capture"):
+            state.pop(k, None)
+        return state
 
     def _forward_train(self, sample: Dict[str, torch.Tensor]):
         """Training forward (the reference's train.py:150-166 calls model(batch) then loss.backward()).  The HIP
@@ -426,9 +455,14 @@ class Motion_Latent_Model(nn.Module):
             rank, world, group = shard
             kv_gather = _KVGather(B, T, Lt, parallel.counts(T_full, world), group, dev)
 
-        for gblk, lblk in zip(self.global_transformer_blocks, self.local_transformer_blocks):
-            gblk.run(P, tok, B, T * Lt, kv_gather=kv_gather)
-            lblk.run(P, tok, B * T, Lt)
+        # LayerNorm fold (transformer.LNFold): the statistics of the stream travel from GEMM epilogue to GEMM epilogue
+        fold = None
+        if LNFold.usable(P, tok.shape[0], C):
+            fold = LNFold(tok).from_stream(tok, self.global_transformer_blocks[0].norm1.eps)
+        n_pairs = len(self.global_transformer_blocks)
+        for i, (gblk, lblk) in enumerate(zip(self.global_transformer_blocks, self.local_transformer_blocks)):
+            gblk.run(P, tok, B, T * Lt, kv_gather=kv_gather, fold=fold)
+            lblk.run(P, tok, B * T, Lt, fold=fold, feed_next=i + 1 < n_pairs)     # the decoder gathers its own rows
             if cap is not None and "trunk_block0" not in cap:
                 cap["trunk_block0"] = tok.clone()
         if cap is not None:
@@ -458,23 +492,29 @@ class Motion_Latent_Model(nn.Module):
                 with span("stage:decoder_cross_attn_block", 0.0):
                     if hoisted is None:
                         Q = dec.project_q(P, pf, 1, n1 - n0)
-                    x = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True,
-                                   bf16_stream=BF16_DECODER_STREAM)
+                    x, fold_d = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True,
+                                           bf16_stream=BF16_DECODER_STREAM, want_fold=True)
                 if cap is not None and n0 == 0 and n1 == N:
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
-                h = torch.empty(x.shape, dtype=P.dtype, device=dev)
-                ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
+                if fold_d is not None:
+                    # the head's LayerNorm rides in its first GEMM: statistics left by the MLP's last epilogue
+                    hw, hcs, hb = P.folded(head_ln.weight, head_ln.bias, head_fc1.weight, head_fc1.bias)
+                    h, lnk = fold_d.xb, dict(ln=(fold_d.ready(head_ln.eps), hcs))
+                else:
+                    h = torch.empty(x.shape, dtype=P.dtype, device=dev)
+                    ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
+                    hw, hb, lnk = P.mat(head_fc1.weight), P.vec(head_fc1.bias), {}
                 whole = n0 == 0 and n1 == N
                 o = out[b] if whole else torch.empty((T, n1 - n0, 3), dtype=torch.float32, device=dev)
                 if FUSE_HEAD_N3 and P.dtype == torch.bfloat16 and C % 256 == 0 and not torch.is_grad_enabled():
                     # Linear -> GELU -> Linear(C -> 3) without the [rows, C] intermediate: the first GEMM's epilogue contracts
                     # its GELU output with the 3 x C weight and leaves C / 64 partial sums per row (M324_AUX_N3)
                     part = torch.empty((C // 64, x.shape[0], 3), dtype=torch.float32, device=dev)
-                    ops.gemm(h, P.mat(head_fc1.weight), None, bias=P.vec(head_fc1.bias), act=ACT_GELU, n3=(w3, part))
+                    ops.gemm(h, hw, None, bias=hb, act=ACT_GELU, n3=(w3, part), **lnk)
                     ops.n3_finish(part, b3, o)
                 else:
                     h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
-                    ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
+                    ops.gemm(h, hw, h2, bias=hb, act=ACT_GELU, **lnk)
                     ops.linear_n3(h2, w3, b3, o)
                 if not whole:
                     out[b, :, n0:n1] = o

@@ -74,6 +74,43 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x
     }
 }
 
+// ----------------------------------------------------------------------------------- LayerNorm fold: row statistics
+// part[cb][m] = (sum, M2) of the 64 columns of block cb (left by a producer GEMM's epilogue) -> rowstat[m] = (rstd, -rstd mean).
+// Chan's parallel update: M2 = sum_b M2_b + 64 (mean_b - mean)^2 -- no E[x^2] - mean^2 cancellation.  Thread per row,
+// consecutive threads read consecutive float2 of a block (coalesced).
+__global__ __launch_bounds__(256) void rowstats_finish_kernel(const float2* __restrict__ part, int ncb, int M, float eps,
+                                                              float2* __restrict__ rowstat) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int b = 0; b < ncb; ++b) s += part[(long)b * M + m].x;
+    const float n = 64.0f * (float)ncb, mean = s / n;
+    float m2 = 0.f;
+    for (int b = 0; b < ncb; ++b) {
+        const float2 pb = part[(long)b * M + m];
+        const float d = pb.x * (1.0f / 64.0f) - mean;
+        m2 += fmaf(64.0f * d, d, pb.y);
+    }
+    const float rstd = rsqrtf(m2 / n + eps);
+    rowstat[m] = make_float2(rstd, -rstd * mean);
+}
+
+// The same table from an fp32 stream (head of a chain), two-pass like layernorm_kernel, plus the bf16 copy of the row.
+__global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, long ldx, int rows, int C, float eps,
+                                                       float2* __restrict__ rowstat, bf16_t* __restrict__ copy, long ldcopy) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[LN_MAXV];
+    row_load(v, x + row * ldx, lane, C);
+    float mean, rstd;
+    row_stats(v, lane, C, eps, mean, rstd);
+    if (lane == 0) rowstat[row] = make_float2(rstd, -rstd * mean);
+    if (copy) {
+        LN_FOR(i, c) store4<bf16_t>(copy + row * ldcopy + c, v[i].x, v[i].y, v[i].z, v[i].w);
+    }
+}
+
 // ----------------------------------------------------------------------------------- qkv split
 // One workgroup per (64-token tile, head, batch).  Thread t: token = t >> 2, 16 columns (t & 3) * 16.
 // Each of the three sources can be emitted row-major (head-major [B,H,L,64]) and / or transposed
@@ -651,6 +688,27 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(const float* __restrict_
     if ((dtype) == M324_BF16) { using T = bf16_t; __VA_ARGS__; }          \
     else if ((dtype) == M324_F32) { using T = float; __VA_ARGS__; }       \
     else M324_FAIL(M324_ERR_UNSUPPORTED, name ": dtype %d", (int)(dtype))
+
+extern "C" int m324_rowstats_finish(const float* part, int ncb, int M, float eps, float* rowstat, void* stream) {
+    M324_REQUIRE(part && rowstat && ncb > 0 && M > 0, "m324_rowstats_finish: bad arguments (ncb=%d M=%d)", ncb, M);
+    M324_REQUIRE(((uintptr_t)part % 8) == 0 && ((uintptr_t)rowstat % 8) == 0, "m324_rowstats_finish: tables must be 8-byte aligned");
+    hipLaunchKernelGGL(rowstats_finish_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(part), ncb, M, eps, reinterpret_cast<float2*>(rowstat));
+    M324_CHECK_LAUNCH("m324_rowstats_finish");
+    return M324_OK;
+}
+
+extern "C" int m324_rowstats(const float* x, long ldx, int rows, int C, float eps, float* rowstat, void* copy, long ldcopy,
+                             void* stream) {
+    M324_REQUIRE(x && rowstat && rows > 0, "m324_rowstats: bad arguments");
+    M324_REQUIRE(C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV && ldx % 4 == 0 && ldx >= C, "m324_rowstats: C=%d ldx=%ld unsupported", C, ldx);
+    M324_REQUIRE(((uintptr_t)rowstat % 8) == 0 && (!copy || (ldcopy % 4 == 0 && ldcopy >= C && ((uintptr_t)copy % 8) == 0)),
+                 "m324_rowstats: misaligned outputs");
+    hipLaunchKernelGGL(rowstats_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C, eps,
+                       reinterpret_cast<float2*>(rowstat), static_cast<bf16_t*>(copy), ldcopy);
+    M324_CHECK_LAUNCH("m324_rowstats");
+    return M324_OK;
+}
 
 extern "C" int m324_layernorm_in(const void* x, int x_dtype, long ldx, const float* w, const float* b, float eps, void* y, long ldy,
                                  int out_dtype, int rows, int C, int gin, int gout, int off, void* stream) {

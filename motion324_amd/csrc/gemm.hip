@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
 
     const int nk = K / BK;
     const int arow0 = wm * 64 + l31, brow0 = wn * 64 + l31;
+    LnPre ln_pre;
+    ln_prefetch<ACT, 2>(ep, M, N, m0 + wm * 64, n0 + wn * 64, lane, ln_pre);
     issue_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (never left to __syncthreads()'s fence)
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
         mma_tile<TIN, true>(sa, sa + TILE_BYTES, arow0, brow0, hi, acc);
     }
     __syncthreads();                            // all waves are done reading the stages: reuse them as epilogue scratch
-    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 64,
-                                      n0 + wn * 64, lane, ep);
+    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 64,
+                                      n0 + wn * 64, lane, ep, &ln_pre);
 }
 
 
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
 
     const int nk = K / BK;
     const int arow0 = wm * 128 + l31, brow0 = wn * 64 + l31;
+    const LnPre* const ln_pre_ptr = nullptr;
     issue_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (never left to __syncthreads()'s fence)
@@ -268,8 +271,8 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
         }
     }
     __syncthreads();
-    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
-                                      n0 + wn * 64, lane, ep);
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep, ln_pre_ptr);
 }
 
 
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const bf16_t* __restr
     };
 #define M324_WAIT_PIECES(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+    const LnPre* const ln_pre_ptr = nullptr;
     for (int h = 0; h < RING - 1; ++h) {
         issue_a(h < NH ? h : NH - 1, h);
         issue_b(h < NH ? h : NH - 1, h);
@@ -396,8 +400,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const bf16_t* __restr
 #undef M324_WAIT_PIECES
 #undef M324_SG
     M324_BARRIER();
-    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
-                                      n0 + wn * 64, lane, ep);
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep, ln_pre_ptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -501,6 +505,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
 #endif
     };
 
+    LnPre ln_pre;
+    ln_prefetch<ACT, 4>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, ln_pre);
     // prologue: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile (12 in all at
     // K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue and is peeled
     {
@@ -547,8 +553,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
 #undef M324_SG
     M324_BARRIER();
-    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
-                                      n0 + wn * 64, lane, ep);
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 128,
+                                      n0 + wn * 64, lane, ep, &ln_pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,6 +632,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __rest
         M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 2);
     };
 
+    LnPre ln_pre;
+    ln_prefetch<ACT, 2>(ep, M, N, m0 + wm * 64, n0 + wn * 64, lane, ln_pre);
     {
         const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
         issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
@@ -670,8 +678,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
 #undef M324_SG
     M324_BARRIER();
-    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 64,
-                                      n0 + wn * 64, lane, ep);
+    store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 64,
+                                      n0 + wn * 64, lane, ep, &ln_pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1027,7 +1035,9 @@ static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_
 
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
-    const int f = forced_variant();
+    int f = forced_variant();
+    if ((f == 1 || f == 5 || f == 7 || f == 9) && (a->ln_rowstat || a->ln_stats_out || a->ln_copy_out))
+        f = 0;                                   // the LayerNorm fold is built into v2 / v10 / v11 / v12 / v13 only
     const bool bf16 = a->in_dtype == M324_BF16;
     const bool ring_ok = bf16 && a->K % 64 == 0 && a->K >= 128;      // v10 / v11: K-stages of 64, at least two
     if (f == 1 || f == 2 || f == 5) return f;
@@ -1088,14 +1098,22 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                 {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
                 a->qkv_L, a->qkv_H, a->aux_mode == M324_AUX_QKV_HEADS_VT ? 1 : 0,
                 (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > (128l << 20)) ? 1 : 0,
-                (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0};
+                (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0,
+                reinterpret_cast<const float2*>(a->ln_rowstat), a->ln_colsum, reinterpret_cast<float2*>(a->ln_stats_out),
+                static_cast<bf16_t*>(a->ln_copy_out), a->ln_ldcopy};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
+    const bool lnf = a->ln_rowstat || a->ln_stats_out || a->ln_copy_out;     // LayerNorm fold: the ACT | 8 instantiations
     if (a->aux_mode == M324_AUX_N3) {              // one schedule only: the 256 x 256 chunk ring (host-checked shape)
         if constexpr (sizeof(TOUT) == 2 && sizeof(TIN) == 2) {
-            hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 5, 0>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
-                               (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (bf16_t*)a->C, a->ldc, a->M, a->N, a->K, ep,
-                               ceil_div(a->N, BN5), xcd_mode(a));
+            if (lnf)
+                hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 13, 0>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+                                   (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (bf16_t*)a->C, a->ldc, a->M, a->N, a->K, ep,
+                                   ceil_div(a->N, BN5), xcd_mode(a));
+            else
+                hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 5, 0>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+                                   (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (bf16_t*)a->C, a->ldc, a->M, a->N, a->K, ep,
+                                   ceil_div(a->N, BN5), xcd_mode(a));
             M324_CHECK_LAUNCH("m324_gemm");
             return M324_OK;
         } else {
@@ -1132,7 +1150,42 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                                (const TIN*)a->A, a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N,      \
                                a->K, ep, (int)grid.x, xcd_mode(a));                                                      \
     } while (0)
-        if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) {
+        // LayerNorm fold: bf16 operands on the chunk-ring / 128 x 128 LDS-DMA kernels only (m324_gemm checked the shape)
+#define M324_LNF(ACT, RES)                                                                                               \
+    do {                                                                                                                 \
+        if (variant == 11 || variant == 12) {                                                                            \
+            const int rc_ = m324::launch_ring4(a, s, ep, ACT, RES, xcd_mode(a), variant);                                \
+            if (rc_ != M324_OK) return rc_;                                                                              \
+        } else if (variant == 13)                                                                                        \
+            hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(grid.x * grid.y), dim3(256), 0, s,              \
+                               (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M,      \
+                               a->N, a->K, ep, (int)grid.x, xcd_mode(a));                                                \
+        else if (variant == 10)                                                                                          \
+            hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)),      \
+                               dim3(512), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C,   \
+                               a->ldc, a->M, a->N, a->K, ep, ceil_div(a->N, BN5), xcd_mode(a));                          \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, TOUT, ACT, RES>), dim3(grid.x * grid.y, 1), dim3(256), 0, s,    \
+                               (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M,      \
+                               a->N, a->K, ep, (int)grid.x, xcd_mode(a));                                                \
+    } while (0)
+        if (lnf) {                             // m324_gemm validated the combination: consumer XOR producer
+            if constexpr (sizeof(TIN) == 2) {
+                if (a->ln_rowstat) {               // consumer: ACT | 8, no residual
+                    if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) {
+                        if constexpr (sizeof(TOUT) == 2) M324_LNF(12, 0);
+                    } else if (a->act == M324_ACT_GELU) {
+                        if constexpr (sizeof(TOUT) == 2) M324_LNF(9, 0);
+                    } else {
+                        M324_LNF(8, 0);
+                    }
+                } else if constexpr (sizeof(TOUT) == 2) {      // producer, bf16 stream: statistics only
+                    if (res == 1) M324_LNF(16, 1); else M324_LNF(16, 2);
+                } else {                                        // producer, fp32 stream: statistics + bf16 twin
+                    if (res == 1) M324_LNF(48, 1); else M324_LNF(48, 2);
+                }
+            }
+        } else if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) {
             if constexpr (sizeof(TOUT) == 2) M324_GLDS(4, 0);
         } else if (a->aux_mode == M324_AUX_STORE_PREACT) {
             M324_GLDS(2, 0);
@@ -1144,6 +1197,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
             if (res == 0) M324_GLDS(0, 0); else if (res == 1) M324_GLDS(0, 1); else M324_GLDS(0, 2);
         }
 #undef M324_GLDS
+#undef M324_LNF
     }
     M324_CHECK_LAUNCH("m324_gemm");
     return M324_OK;
@@ -1158,8 +1212,10 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
 extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
     M324_REQUIRE(a && buf && n > 0, "m324_gemm_plan: bad arguments");
     const int nbatch = a->batch > 1 ? a->batch : 1;
+    const bool lnf = a->ln_rowstat || a->ln_stats_out || a->ln_copy_out;
     if (a->aux_mode == M324_AUX_N3) {
-        snprintf(buf, (size_t)n, "gemm_ring_kernel<unsigned short, 5, 0> grid=%ldx1x1", (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5) * 512);
+        snprintf(buf, (size_t)n, "gemm_ring_kernel<unsigned short, %d, 0> grid=%ldx1x1", lnf ? 13 : 5,
+                 (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5) * 512);
         return 10;
     }
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
@@ -1171,6 +1227,10 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
     if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) act = 4, rs = 0;
     else if (a->aux_mode == M324_AUX_STORE_PREACT) act = 2, rs = 0;
     else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD) act = 3, rs = 0;
+    if (lnf) {
+        if (a->ln_rowstat) act |= 8, rs = 0;
+        else act = a->out_dtype == M324_F32 ? 48 : 16, rs = res;
+    }
     long wg = 0, threads = 256;
     const char* name = "gemm_kernel";
     switch (variant) {
@@ -1265,6 +1325,35 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
         M324_REQUIRE(a->aux_mode != M324_AUX_MUL_GELU_GRAD || a->act == M324_ACT_NONE,
                      "m324_gemm: M324_AUX_MUL_GELU_GRAD excludes an activation");
         M324_REQUIRE(!a->residual, "m324_gemm: the aux operand excludes a residual");
+    }
+    if (a->ln_rowstat || a->ln_stats_out || a->ln_copy_out) {
+        // LayerNorm fold: the tile kernels' LDS-transposed epilogue only (not the skinny or the scalar-store kernel)
+        M324_REQUIRE(a->in_dtype == M324_BF16 && a->N % 64 == 0 && a->M > 64 && vec_ok(a) && a->batch <= 1 && a->K >= 128,
+                     "m324_gemm: the LayerNorm fold needs a bf16, vectorisable, un-batched problem with M > 64, N %% 64 == 0 and "
+                     "K >= 128 (M=%d N=%d K=%d)", a->M, a->N, a->K);
+        M324_REQUIRE(a->aux_mode != M324_AUX_STORE_PREACT && a->aux_mode != M324_AUX_MUL_GELU_GRAD,
+                     "m324_gemm: the LayerNorm fold is an inference feature (no training aux modes)");
+        // the combinations that are built (gemm_tile.h store_tile_lds, ACTX bits): a consumer has no residual / gamma / row
+        // map (and a bf16 output behind GELU); a producer is x = residual + A W^T (+ bias, gamma) with its statistics, plus
+        // the bf16 twin exactly when x is fp32
+        if (a->ln_rowstat) {
+            M324_REQUIRE(!a->ln_stats_out && !a->ln_copy_out, "m324_gemm: one GEMM either consumes or produces LayerNorm statistics");
+            M324_REQUIRE(!a->residual && !a->gamma && a->row_gin <= 0, "m324_gemm: a folded LayerNorm consumer takes no residual / gamma / row map");
+            M324_REQUIRE(a->act == M324_ACT_NONE || a->out_dtype == M324_BF16, "m324_gemm: LayerNorm fold + GELU needs a bf16 output");
+        } else {
+            M324_REQUIRE(a->ln_stats_out && a->residual && a->act == M324_ACT_NONE,
+                         "m324_gemm: a LayerNorm statistics producer is a residual update without activation");
+            M324_REQUIRE((a->out_dtype == M324_F32) == (a->ln_copy_out != nullptr),
+                         "m324_gemm: ln_copy_out goes with an fp32 output (and only with it)");
+        }
+        M324_REQUIRE(!a->ln_rowstat || (a->ln_colsum && ((uintptr_t)a->ln_rowstat % 8) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0),
+                     "m324_gemm: ln_rowstat needs ln_colsum (16-byte aligned) and an 8-byte aligned row table");
+        M324_REQUIRE((!a->ln_stats_out && !a->ln_copy_out) || (a->row_gin <= 0 && a->aux_mode == M324_AUX_NONE),
+                     "m324_gemm: ln_stats_out / ln_copy_out describe the rows of C: no row remap, no aux mode");
+        M324_REQUIRE(!a->ln_stats_out || ((uintptr_t)a->ln_stats_out % 8) == 0, "m324_gemm: ln_stats_out misaligned");
+        M324_REQUIRE(!a->ln_copy_out || (a->out_dtype == M324_F32 && a->ln_ldcopy >= a->N && a->ln_ldcopy % 4 == 0 &&
+                                         ((uintptr_t)a->ln_copy_out % 8) == 0),
+                     "m324_gemm: ln_copy_out is the bf16 twin of an fp32 output (ldcopy >= N, multiple of 4, 8-byte aligned)");
     }
     hipStream_t s = (hipStream_t)stream;
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16) return launch<bf16_t, bf16_t>(a, s);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
             issue_prologue();
         }
         mma16(1);                                           // (NS-1, k-step 3)
-        float* scr = reinterpret_cast<float*>(smem + 3 * CHUNK10) + wave * EP_WAVE_FLOATS;
+        float* scr = reinterpret_cast<float*>(smem + 3 * CHUNK10) + wave * ep_wave_floats(ACT);
         store_tile_lds<TOUT, ACT, RES, 4>(acc[0], scr, C, ldc, M, N, mt + wm * 128, nt + wn * 128, lane, ep);
         store_tile_lds<TOUT, ACT, RES, 4>(acc[1], scr, C, ldc, M, N, mt + wm * 128, nt + wn * 128 + 64, lane, ep);
         if (t + (int)gridDim.x < ntiles) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
 #undef M324_SG
     M324_BARRIER();
-    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, M, N, m0 + wm * 128,
+    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 128,
                                       n0 + wn * 64, lane, ep);
 }
 
@@ -338,6 +338,13 @@ int launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int
         case 2 * 4 + 0: M324_R4_OUT(2, 0); break;
         case 3 * 4 + 0: M324_R4_OUT(3, 0); break;
         case 4 * 4 + 0: M324_R4(bf16_t, 4, 0); break;
+        case 8 * 4 + 0: M324_R4_OUT(8, 0); break;          // the LayerNorm-fold instantiations: consumers (ACT | 8) ...
+        case 9 * 4 + 0: M324_R4(bf16_t, 9, 0); break;
+        case 12 * 4 + 0: M324_R4(bf16_t, 12, 0); break;
+        case 16 * 4 + 1: M324_R4(bf16_t, 16, 1); break;    // ... producers of a bf16 stream (statistics) ...
+        case 16 * 4 + 2: M324_R4(bf16_t, 16, 2); break;
+        case 48 * 4 + 1: M324_R4(float, 48, 1); break;     // ... and of an fp32 stream (statistics + bf16 twin)
+        case 48 * 4 + 2: M324_R4(float, 48, 2); break;
         default:                   // m324_gemm only builds the combinations above
             M324_FAIL(M324_ERR_UNSUPPORTED, "m324_gemm: no 4-wave ring kernel for epilogue act=%d res=%d", act_code, res_code);
     }

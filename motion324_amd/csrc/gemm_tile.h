@@ -25,6 +25,15 @@ struct Epilogue {
     int qkv_vt;                  // M324_AUX_QKV_HEADS_VT: qkv_out[2] is Vt [B, H, 64, L] (key quarters of every 16 in the order 0,2,1,3)
     int stream;                  // bf16 outputs without residual: store non-temporal (host: output larger than the MALL keeps)
     int res_out;                 // the residual has the OUTPUT's dtype (host: residual aliases a bf16 C -- a bf16 residual stream updated in place)
+    // LayerNorm folded around the GEMM (bf16 inference; m324.h "LayerNorm fold").  Consumer side: A holds the raw stream and W
+    // the weight with the LayerNorm's scale folded in; the epilogue turns acc into rstd (acc - mean colsum[n]).  Producer
+    // side: the epilogue leaves per-row (sum, M2) of every 64-column block of the values it stores, and (fp32 outputs) a
+    // bf16 copy of them -- the next GEMM's A operand.
+    const float2* rowstat;       // [M] (rstd, -rstd * mean) of the A rows, or null
+    const float* colsum;         // [N] sum over k of W[n, k]
+    float2* stats;               // [N / 64][M] (sum, sum of squared deviations from the block mean), or null
+    bf16_t* copy;                // [M, ldcopy] bf16 copy of the stored values (fp32 outputs), or null
+    long ldcopy;
 };
 
 // gemm_ring4.hip (own translation unit: built WITHOUT -amdgpu-mfma-vgpr-form, its 256 accumulators live in AGPRs).
@@ -301,6 +310,82 @@ __device__ __forceinline__ void store_tile_out(const f32x16 (&acc)[2][2], TOUT* 
 }
 
 
+// Sum over the aligned group of 8 (16) consecutive lanes, delivered to every lane of the group: v_add_f32 with a DPP operand
+// (quad_perm butterflies, then row_half_mirror / row_mirror) -- no LDS crossbar traffic, unlike ds_bpermute shuffles.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f<0xB1>(v);         // quad_perm [1, 0, 3, 2]
+    v += dpp_f<0x4E>(v);         // quad_perm [2, 3, 0, 1]
+    v += dpp_f<0x141>(v);        // row_half_mirror: lane i <- lane 7 - i of its group of 8
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+    v = group8_sum(v);
+    v += dpp_f<0x140>(v);        // row_mirror: lane i <- lane 15 - i
+    return v;
+}
+// LayerNorm fold, consumer side: v = rstd * acc - rstd * mean * colsum + bias  (rs = (rstd, -rstd * mean))
+__device__ __forceinline__ void ln_fold4(float4& v, const float2 rs, const float4& cs, const float4& bi) {
+    v.x = fmaf(rs.x, v.x, fmaf(rs.y, cs.x, bi.x)); v.y = fmaf(rs.x, v.y, fmaf(rs.y, cs.y, bi.y));
+    v.z = fmaf(rs.x, v.z, fmaf(rs.y, cs.z, bi.z)); v.w = fmaf(rs.x, v.w, fmaf(rs.y, cs.w, bi.w));
+}
+// producer side: (sum, M2) of the 64 columns of a row that `group` lanes hold (8 lanes x 8 values or 16 lanes x 4)
+// P independent rows at once, one reduction step of every row before the next step of any: a DPP add needs wait states
+// behind the VALU write of its source, and a wave that is alone on its SIMD (the 4-wave kernels) otherwise walks each
+// row's chain of ~25 dependent instructions to the end before it starts the next row's.
+template <int P, int CTRL>
+__device__ __forceinline__ void dpp_step(float (&v)[P]) {
+    float t[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) t[p] = dpp_f<CTRL>(v[p]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) v[p] += t[p];
+}
+template <int P, bool WIDE>          // WIDE: 16 lanes per row (4 values each); else 8 lanes (8 values each)
+__device__ __forceinline__ void group_sum_batch(float (&v)[P]) {
+    dpp_step<P, 0xB1>(v);
+    dpp_step<P, 0x4E>(v);
+    dpp_step<P, 0x141>(v);
+    if (WIDE) dpp_step<P, 0x140>(v);
+}
+// (sum, M2) of the 64 columns of P rows; x[p] (and y[p]) are this lane's 4 (8) values of row p
+template <int P>
+__device__ __forceinline__ void ln_stats4_batch(const float4 (&x)[P], float2 (&st)[P]) {
+    float s[P], q[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) s[p] = (x[p].x + x[p].y) + (x[p].z + x[p].w);
+    group_sum_batch<P, true>(s);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float bm = s[p] * (1.0f / 64.0f);
+        const float a = x[p].x - bm, b = x[p].y - bm, c = x[p].z - bm, d = x[p].w - bm;
+        q[p] = fmaf(a, a, fmaf(b, b, fmaf(c, c, d * d)));
+    }
+    group_sum_batch<P, true>(q);
+#pragma unroll
+    for (int p = 0; p < P; ++p) st[p] = make_float2(s[p], q[p]);
+}
+template <int P>
+__device__ __forceinline__ void ln_stats8_batch(const float4 (&x)[P], const float4 (&y)[P], float2 (&st)[P]) {
+    float s[P], q[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) s[p] = ((x[p].x + x[p].y) + (x[p].z + x[p].w)) + ((y[p].x + y[p].y) + (y[p].z + y[p].w));
+    group_sum_batch<P, false>(s);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float bm = s[p] * (1.0f / 64.0f);
+        const float a = x[p].x - bm, b = x[p].y - bm, c = x[p].z - bm, d = x[p].w - bm;
+        const float e = y[p].x - bm, f = y[p].y - bm, g = y[p].z - bm, h = y[p].w - bm;
+        q[p] = fmaf(a, a, fmaf(b, b, fmaf(c, c, d * d))) + fmaf(e, e, fmaf(f, f, fmaf(g, g, h * h)));
+    }
+    group_sum_batch<P, false>(q);
+#pragma unroll
+    for (int p = 0; p < P; ++p) st[p] = make_float2(s[p], q[p]);
+}
+
 // SWAPPED accumulators (all LDS-DMA kernels): lane = output row m (32 rows per block), registers = columns
 // n = 8*g + 4*hi + e (g = r >> 2, e = r & 3): every lane owns runs of 4 consecutive columns.  Needs N % 4 == 0.
 template <typename TOUT>
@@ -335,10 +420,40 @@ __device__ __forceinline__ void store16(void* p, bool stream, unsigned a, unsign
 // DS operations of one wave execute in order, so no barrier or wait is needed between the write and read passes.
 constexpr int EP_LD = 68;
 constexpr int EP_WAVE_FLOATS = 32 * EP_LD;     // 8704 bytes per wave
+// LayerNorm-fold instantiations (ACTX & 8) append wave-private tables to the scratch: the 128 rows' (rstd, -rstd mean) for
+// the consumer side -- fetched ONCE per tile, before the main loop where the kernel can, instead of a
+// dependent 8-byte global load per 8 rows in the middle of the epilogue (measured: +7 us on a 60 us GEMM) -- and the
+// colsum of its 64 columns.
+constexpr int EP_LN_FLOATS = 512;
+constexpr int ep_wave_floats(int actx) { return (actx & 8) ? EP_WAVE_FLOATS + EP_LN_FLOATS : EP_WAVE_FLOATS; }
+// Consumer side: the wave's rows' table entries, one (MI = 2) or two (MI = 4) per lane; kernels call this before their
+// prologue's LDS-DMA (older than every piece, so the counted vmcnt waits of the main loop retire it for free).
+struct LnPre {
+    float2 rs[2];                // (rstd, -rstd mean) of rows mw + lane, mw + 64 + lane
+    float cs;                    // colsum of column nw + lane
+};
+template <int ACTX, int MI>
+__device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, int mw, int nw, int lane, LnPre& pre) {
+    pre.rs[0] = pre.rs[1] = make_float2(0.f, 0.f);
+    pre.cs = 0.f;
+    if constexpr ((ACTX & 8) != 0) {
+        pre.rs[0] = ep.rowstat[min(mw + lane, M - 1)];
+        if (MI > 2) pre.rs[1] = ep.rowstat[min(mw + 64 + lane, M - 1)];
+        pre.cs = ep.colsum[min(nw + lane, N - 1)];
+    }
+}
 
-template <typename TOUT, int ACT, int RES, int MI>
+// ACTX: the low bits are the activation / aux code (0 none, 1 GELU, 2 GELU + pre-activation, 3 x gelu', 4 q|k|v heads,
+// 5 N3 head); bits 3-5 compile the LayerNorm-fold paths in: 8 = consumer (ep.rowstat / ep.colsum), 16 = producer statistics
+// (ep.stats), 32 = bf16 twin of an fp32 output (ep.copy).  Template bits, not run-time flags: a run-time `if` inside the
+// unrolled passes splits them into basic blocks, and the loads / stores of a block are then no longer issued as batches
+// (measured: +6 us on a 56 us GEMM whose fold work is 2 FMAs per element); the instantiations without the bits are
+// untouched.
+template <typename TOUT, int ACTX, int RES, int MI>
 __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float* scr, TOUT* C, long ldc, int M, int N, int mw,
-                                               int nw, int lane, const Epilogue& ep) {
+                                               int nw, int lane, const Epilogue& ep, const LnPre* pre = nullptr) {
+    constexpr int ACT = ACTX & 7;
+    constexpr bool fold = (ACTX & 8) != 0, STATS = (ACTX & 16) != 0, COPY = (ACTX & 32) != 0;
 #if defined(M324_LAB_NOSTORE) && defined(__HIP_DEVICE_COMPILE__)          // tools/ lab builds only: main loop without its epilogue (accumulators kept alive)
 #pragma unroll
     for (int i = 0; i < MI; ++i) { asm volatile("" ::"v"(acc[i][0])); asm volatile("" ::"v"(acc[i][1])); }
@@ -356,6 +471,15 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
     const float4 ga = ep.gamma ? *reinterpret_cast<const float4*>(ep.gamma + ncl) : make_float4(1.f, 1.f, 1.f, 1.f);
     float* wr = scr + l31 * EP_LD + 4 * hi;
     const float* rd = scr + rr * EP_LD + cc;
+    const bool wave_in = nw + 64 <= N;                       // producer side needs whole 64-column blocks (host: N % 64 == 0)
+    float2* const rsl = reinterpret_cast<float2*>(scr + EP_WAVE_FLOATS);   // [128] (rstd, -rstd mean) of rows mw .. (consumers)
+    float* const csl = scr + EP_WAVE_FLOATS + 256;                          // [64] colsum of columns nw ..
+    if (fold) {                                              // DS operations of a wave execute in order: no barrier needed
+        rsl[lane] = pre ? pre->rs[0] : ep.rowstat[min(mw + lane, M - 1)];
+        if (MI > 2) rsl[64 + lane] = pre ? pre->rs[1] : ep.rowstat[min(mw + 64 + lane, M - 1)];
+        csl[lane] = pre ? pre->cs : ep.colsum[min(nw + lane, N - 1)];
+    }
+    float2* const stats_wave = (STATS && wave_in) ? ep.stats + (long)(nw >> 6) * M : nullptr;
     // interior tiles (all but the last row / column of tiles) take a copy without per-store predicates, so the 8 LDS
     // reads and the 8 stores of a block are scheduled as batches instead of read-wait-store chains
     auto body = [&](auto checked) {
@@ -364,6 +488,13 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
         for (int i = 0; i < MI; ++i) {
             const int mb = mw + i * 32 + rr;       // row of pass p: mb + 4 p
             float4 res[8], az[8];
+            float2 rs[8];
+            const float4 cs = fold ? *reinterpret_cast<const float4*>(csl + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 xs[8];                                    // STATS: the stored values of the 8 passes
+            if (fold) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) rs[p] = rsl[i * 32 + rr + 4 * p];
+            }
             if (has_res) {
                 // broadcast residual (the decoder's out-projection: the same 2048 point rows under every frame): ONE
                 // division per 32-row block, then a compare-subtract per pass (an integer modulo per row cost this
@@ -403,7 +534,8 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 float4 x = v[p];
-                x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w;
+                if (fold) ln_fold4(x, rs[p], cs, bi);
+                else { x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w; }
                 const int m = mb + 4 * p;
                 if (ACT == 2 && (!CHECK || (m < M && nok)))
                     store4_out<TOUT>(static_cast<TOUT*>(ep.aux) + (long)m * ep.ldaux + n, x.x, x.y, x.z, x.w);
@@ -414,11 +546,27 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     x.x *= gelu_grad<TOUT>(az[p].x); x.y *= gelu_grad<TOUT>(az[p].y);
                     x.z *= gelu_grad<TOUT>(az[p].z); x.w *= gelu_grad<TOUT>(az[p].w);
                 }
+                if constexpr (STATS) xs[p] = x;
                 if (!CHECK || (m < M && nok)) {
                     long orow = m;
                     if (remap) orow = (long)(m / ep.row_gin) * ep.row_gout + (m % ep.row_gin) + ep.row_off;
                     store4_out<TOUT>(C + orow * ldc + n, x.x, x.y, x.z, x.w);
+                    if constexpr (COPY) store4_out<bf16_t>(ep.copy + (long)m * ep.ldcopy + n, x.x, x.y, x.z, x.w);
                 }
+            }
+            if constexpr (STATS) {
+                // every lane takes part in the DPP sums; all 16 lanes of a row end up with its pair, lane g == p keeps it
+                // (no branch), so that lanes g < 8 hold rows rr + 4 g: one store per 32-row block, 32 lanes x 8 bytes
+                float2 st[8], keep = make_float2(0.f, 0.f);
+                ln_stats4_batch<8>(xs, st);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const bool mine = (lane & 15) == p;
+                    keep.x = mine ? st[p].x : keep.x;
+                    keep.y = mine ? st[p].y : keep.y;
+                }
+                const int m = mb + 4 * (lane & 15);
+                if (stats_wave && (lane & 15) < 8 && (!CHECK || m < M)) stats_wave[m] = keep;
             }
         }
     };
@@ -430,9 +578,17 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
         float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, g0 = make_float4(1.f, 1.f, 1.f, 1.f), g1 = g0;
         if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }
         if (ep.gamma) { g0 = *reinterpret_cast<const float4*>(ep.gamma + n8); g1 = *reinterpret_cast<const float4*>(ep.gamma + n8 + 4); }
+        float4 cs0 = make_float4(0.f, 0.f, 0.f, 0.f), cs1 = cs0;
+        if (fold) { cs0 = *reinterpret_cast<const float4*>(csl + c8); cs1 = *reinterpret_cast<const float4*>(csl + c8 + 4); }
         const float* rd8 = scr + r8 * EP_LD + c8;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            float4 xa[4], ya[4];                             // STATS: the stored values of the 4 passes
+            float2 rs[4];
+            if (fold) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rs[p] = rsl[i * 32 + p * 8 + r8];
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -476,8 +632,11 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 float4 x = v0[p], y = v1[p];
-                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
-                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                if (fold) { ln_fold4(x, rs[p], cs0, b0); ln_fold4(y, rs[p], cs1, b1); }
+                else {
+                    x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                    y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                }
                 const long m = mw + i * 32 + p * 8 + r8;
                 if constexpr (ACT == 2)
                     *reinterpret_cast<uint4*>(static_cast<TOUT*>(ep.aux) + m * ep.ldaux + n8) =
@@ -497,7 +656,19 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     y.x *= gelu_grad<TOUT>(z1[p].x); y.y *= gelu_grad<TOUT>(z1[p].y);
                     y.z *= gelu_grad<TOUT>(z1[p].z); y.w *= gelu_grad<TOUT>(z1[p].w);
                 }
+                if constexpr (STATS) { xa[p] = x; ya[p] = y; }
                 store16(C + m * ldc + n8, ep.stream != 0, pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+            }
+            if constexpr (STATS) {                          // lane (r8, g) keeps the pair of row r8 + 8 g: lanes g < 4 store
+                float2 st[4], keep = make_float2(0.f, 0.f);
+                ln_stats8_batch<4>(xa, ya, st);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bool mine = (lane & 7) == p;
+                    keep.x = mine ? st[p].x : keep.x;
+                    keep.y = mine ? st[p].y : keep.y;
+                }
+                if (stats_wave && (lane & 7) < 4) stats_wave[mw + i * 32 + r8 + 8 * (lane & 7)] = keep;
             }
         }
     };
@@ -518,6 +689,8 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
         const float post = which == 0 ? ep.qkv_qscale : 1.0f;
         bf16_t* const base = ep.qkv_out[which] + (long)head * ep.qkv_L * 64 + c8;
         const float* rd8 = scr + r8 * EP_LD + c8;
+        float4 cs0 = make_float4(0.f, 0.f, 0.f, 0.f), cs1 = cs0;
+        if (fold) { cs0 = *reinterpret_cast<const float4*>(csl + c8); cs1 = *reinterpret_cast<const float4*>(csl + c8 + 4); }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -542,11 +715,18 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     for (int p = 0; p < 4; ++p) {
                         const int d = (lane >> 2) + 16 * p;
                         const float bd = ep.bias ? ep.bias[nw + d] : 0.f;
+                        const float cd = fold ? csl[d] : 0.f;
                         float u[8];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            u[k] = scr[(base + k) * EP_LD + d] + bd;
-                            u[4 + k] = scr[(base + 8 + k) * EP_LD + d] + bd;
+                            if (fold) {
+                                const float2 ra = rsl[i * 32 + base + k], rb = rsl[i * 32 + base + 8 + k];
+                                u[k] = fmaf(ra.x, scr[(base + k) * EP_LD + d], fmaf(ra.y, cd, bd));
+                                u[4 + k] = fmaf(rb.x, scr[(base + 8 + k) * EP_LD + d], fmaf(rb.y, cd, bd));
+                            } else {
+                                u[k] = scr[(base + k) * EP_LD + d] + bd;
+                                u[4 + k] = scr[(base + 8 + k) * EP_LD + d] + bd;
+                            }
                         }
                         bf16_t* dst = ep.qkv_out[2] + (((long)bb * ep.qkv_H + head) * 64 + d) * (long)ep.qkv_L + ll + cq * 8;
                         *reinterpret_cast<uint4*>(dst) =
@@ -564,11 +744,19 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             // token of pass p: m = mw + 32 i + r8 + 8 p  ->  (batch, position); one division per block, then steps of 8
             const int m0r = mw + i * 32 + r8;
             int bb = m0r / ep.qkv_L, ll = m0r - bb * ep.qkv_L;
+            float2 rst[4];
+            if (fold) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rst[p] = rsl[i * 32 + r8 + 8 * p];
+            }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 float4 x = v0[p], y = v1[p];
-                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
-                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                if (fold) { ln_fold4(x, rst[p], cs0, b0); ln_fold4(y, rst[p], cs1, b1); }
+                else {
+                    x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                    y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                }
                 float rs = post;
                 if (norm) {
                     float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w + y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
@@ -601,6 +789,8 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
         }
         const float* rd8 = scr + r8 * EP_LD + c8;
         float* part = static_cast<float*>(ep.aux) + (long)(nw >> 6) * M * 3;
+        float4 cs0 = make_float4(0.f, 0.f, 0.f, 0.f), cs1 = cs0;
+        if (fold) { cs0 = *reinterpret_cast<const float4*>(csl + c8); cs1 = *reinterpret_cast<const float4*>(csl + c8 + 4); }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -615,11 +805,19 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 v0[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD);
                 v1[p] = *reinterpret_cast<const float4*>(rd8 + p * 8 * EP_LD + 4);
             }
+            float2 rst[4];
+            if (fold) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rst[p] = rsl[i * 32 + p * 8 + r8];
+            }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 float4 x = v0[p], y = v1[p];
-                x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
-                y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                if (fold) { ln_fold4(x, rst[p], cs0, b0); ln_fold4(y, rst[p], cs1, b1); }
+                else {
+                    x.x += b0.x; x.y += b0.y; x.z += b0.z; x.w += b0.w;
+                    y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
+                }
                 apply_gelu8<TOUT>(x, y);
                 float sj[3];
 #pragma unroll

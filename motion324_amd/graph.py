@@ -32,13 +32,20 @@ _KEYS = ("ref_shape_pcd", "ref_shape_normals", "ref_shape_rgbs", "ref_pcd", "ref
 
 
 class GraphedForward:
-    def __init__(self, model: torch.nn.Module, warmup: int = 2, weak: bool = False):
+    def __init__(self, model: torch.nn.Module, warmup: int = 2, weak: bool = False, max_graphs: int = 0,
+                 capture_error_mode: str = "global"):
+        # max_graphs > 0: keep at most that many captured shape sets, dropping the least recently used (each graph owns a
+        # private memory pool with a clip's activations and its static inputs).  capture_error_mode: torch.cuda.graph's
+        # -- "thread_local" lets other threads (a DataLoader's pin-memory thread, another stream's allocation) keep
+        # calling into HIP while this thread captures.
         # weak: the model itself owns this object (Motion_Latent_Model's automatic graph replay) -- a strong reference back
         # would make model <-> graphs cyclic garbage, which Python's collector may free at any time, e.g. in the middle
         # of a LATER stream capture, where destroying a hipGraph aborts the process
         self._model = weakref.ref(model) if weak else (lambda: model)
         self.warmup = warmup
-        self._graphs: Dict[Tuple, tuple] = {}
+        self.max_graphs = max_graphs
+        self.capture_error_mode = capture_error_mode
+        self._graphs: Dict[Tuple, tuple] = {}               # insertion order = recency (re-inserted on every use)
 
     @property
     def model(self) -> torch.nn.Module:
@@ -66,31 +73,40 @@ class GraphedForward:
         if entry is None:
             for stale in [k for k in self._graphs if k[:2] != key[:2]]:   # graphs that point at dropped weight copies
                 del self._graphs[stale]
-            static_in = {k: sample[k].detach().to(torch.float32).contiguous().clone() for k in _KEYS if k in sample}
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(self.warmup):          # populates the Prepared cache and the allocator pools
-                    self.model(static_in)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            gc_was_on = gc.isenabled()
-            gc.collect()
-            gc.disable()                      # no collector run may free a stream / event / graph while the capture is open
-            try:
-                with torch.no_grad(), torch.cuda.graph(g):
-                    static_out = self.model(static_in)
-            finally:
-                if gc_was_on:
-                    gc.enable()
+            while self.max_graphs > 0 and len(self._graphs) >= self.max_graphs:
+                del self._graphs[next(iter(self._graphs))]                 # least recently used
+            # The static buffers and the captured forward live OUTSIDE inference mode, whatever mode the caller is in:
+            # tensors created under torch.inference_mode() could not be updated in place by a later call that runs
+            # under plain no_grad ("Inplace update to inference tensor outside InferenceMode").
+            with torch.inference_mode(False), torch.no_grad():
+                static_in = {k: sample[k].detach().to(torch.float32).contiguous().clone() for k in _KEYS if k in sample}
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(self.warmup):          # populates the Prepared cache and the allocator pools
+                        self.model(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                gc_was_on = gc.isenabled()
+                gc.collect()
+                gc.disable()                  # no collector run may free a stream / event / graph while the capture is open
+                try:
+                    with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
+                        static_out = self.model(static_in)
+                finally:
+                    if gc_was_on:
+                        gc.enable()
             entry = (g, static_in, static_out)
-            self._graphs[key] = entry
+        else:
+            del self._graphs[key]                            # re-insert: most recently used last
+        self._graphs[key] = entry
         g, static_in, static_out = entry
-        for k, buf in static_in.items():
-            src = sample[k]
-            if src.data_ptr() != buf.data_ptr():
-                buf.copy_(src, non_blocking=True)
+        with torch.inference_mode(False), torch.no_grad():
+            for k, buf in static_in.items():
+                src = sample[k]
+                if src.data_ptr() != buf.data_ptr():
+                    buf.copy_(src, non_blocking=True)
         g.replay()
         out = edict(input_data=sample, pcd_moved=static_out["pcd_moved"])
         if "loss_metrics" in static_out:

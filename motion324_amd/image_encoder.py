@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import ops
 from .lib import ACT_GELU
 from .prepared import Prepared, pad_k
-from .transformer import fuse_qkv
+from .transformer import LNFold, fuse_qkv
 
 DINO_EPS = 1e-6
 TWO_STREAMS = True       # run(): under graph capture, two half-batches of frames as two branches (see the comment there)
@@ -154,28 +154,51 @@ class DinoEncoder(nn.Module):
             qkv = torch.empty((Fr * Lt, 3 * C), dtype=P.dtype, device=video.device)
         h1 = torch.empty((Fr * Lt, m.blocks[0].mlp.fc1.out_features), dtype=P.dtype, device=video.device)
         # every weight in its compute form BEFORE the fork below (a cold cache converts on the current stream)
+        # LayerNorm fold (transformer.LNFold): norm1 / norm2 ride in the q|k|v and fc1 projections
+        folding = LNFold.usable(P, Fr * Lt, C)
         W = [dict(n1=(P.vec(b.norm1.weight), P.vec(b.norm1.bias)), qkv=(P.mat(b.attn.qkv.weight), P.vec(b.attn.qkv.bias)),
                   proj=(P.mat(b.attn.proj.weight), P.vec(b.attn.proj.bias), P.vec(b.ls1.gamma)),
                   n2=(P.vec(b.norm2.weight), P.vec(b.norm2.bias)), fc1=(P.mat(b.mlp.fc1.weight), P.vec(b.mlp.fc1.bias)),
-                  fc2=(P.mat(b.mlp.fc2.weight), P.vec(b.mlp.fc2.bias), P.vec(b.ls2.gamma))) for b in m.blocks]
+                  fc2=(P.mat(b.mlp.fc2.weight), P.vec(b.mlp.fc2.bias), P.vec(b.ls2.gamma)),
+                  f_qkv=P.folded(b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias) if folding else None,
+                  f_fc1=P.folded(b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias) if folding else None)
+             for b in m.blocks]
 
-        def block(w, f0, f1):
+        def block(w, f0, f1, fold=None, feed_next=True):
             """One ViT block on frames f0 .. f1 (rows f0*Lt .. f1*Lt of every buffer), on the current stream."""
             r = slice(f0 * Lt, f1 * Lt)
-            ops.layernorm(x[r], *w["n1"], DINO_EPS, h[r])
+            if fold is not None:
+                src, (wq, csq, bq) = fold.xb, w["f_qkv"]
+                lnk = dict(ln=(fold.ready(DINO_EPS), csq))
+            else:
+                ops.layernorm(x[r], *w["n1"], DINO_EPS, h[r])
+                src, wq, bq, lnk = h[r], w["qkv"][0], w["qkv"][1], {}
             if fused:
-                ops.gemm(h[r], w["qkv"][0], None, bias=w["qkv"][1],
-                         qkv_heads=(Qh[f0:f1], Kh[f0:f1], Vh[f0:f1], None, None, 0.0, ops.Q_PRESCALE, Lt, H))
+                ops.gemm(src, wq, None, bias=bq,
+                         qkv_heads=(Qh[f0:f1], Kh[f0:f1], Vh[f0:f1], None, None, 0.0, ops.Q_PRESCALE, Lt, H), **lnk)
                 ops.attention(Qh[f0:f1], Kh[f0:f1], Vh[f0:f1], h[r], prescaled=True, v_rowmajor=True)
             else:
-                ops.gemm(h[r], w["qkv"][0], qkv[r], bias=w["qkv"][1])
+                ops.gemm(src, wq, qkv[r], bias=bq, **lnk)
                 Q, K, Vt = ops.qkv_split(qkv[r, :C], qkv[r, C:2 * C], qkv[r, 2 * C:], None, None, 0.0, f1 - f0, Lt, H, P.dtype,
                                          q_scale=ops.Q_PRESCALE)
                 ops.attention(Q, K, Vt, h[r], prescaled=True)
-            ops.gemm(h[r], w["proj"][0], x[r], bias=w["proj"][1], gamma=w["proj"][2], residual=x[r])
-            ops.layernorm(x[r], *w["n2"], DINO_EPS, h[r])
-            ops.gemm(h[r], w["fc1"][0], h1[r], bias=w["fc1"][1], act=ACT_GELU)
-            ops.gemm(h1[r], w["fc2"][0], x[r], bias=w["fc2"][1], gamma=w["fc2"][2], residual=x[r])
+            ops.gemm(h[r], w["proj"][0], x[r], bias=w["proj"][1], gamma=w["proj"][2], residual=x[r],
+                     **(fold.producer() if fold is not None else {}))
+            if fold is not None:
+                w1, cs1, b1 = w["f_fc1"]
+                ops.gemm(fold.xb, w1, h1[r], bias=b1, act=ACT_GELU, ln=(fold.ready(DINO_EPS), cs1))
+            else:
+                ops.layernorm(x[r], *w["n2"], DINO_EPS, h[r])
+                ops.gemm(h[r], w["fc1"][0], h1[r], bias=w["fc1"][1], act=ACT_GELU)
+            ops.gemm(h1[r], w["fc2"][0], x[r], bias=w["fc2"][1], gamma=w["fc2"][2], residual=x[r],
+                     **(fold.producer() if (fold is not None and feed_next) else {}))
+
+        def chain(f0, f1):
+            """All blocks on frames f0 .. f1; the statistics of the stream start from m324_rowstats and then travel from
+            epilogue to epilogue (the final LayerNorm lives in the trunk's token assembly and reads the fp32 stream)."""
+            fold = LNFold(x[f0 * Lt:f1 * Lt]).from_stream(x[f0 * Lt:f1 * Lt], DINO_EPS) if folding else None
+            for i, w in enumerate(W):
+                block(w, f0, f1, fold, feed_next=i + 1 < len(W))
 
         # Frames are independent through the whole ViT.  At the BASELINE clip (32 x 257 = 8224 rows) every GEMM of a
         # block fills only ~76 % of its last round of workgroups (33 x 12 tiles of 256 x 256 on 256 CUs = 1.55 rounds);
@@ -188,15 +211,19 @@ class DinoEncoder(nn.Module):
         if TWO_STREAMS and two_streams and Fr >= 8 and torch.cuda.is_current_stream_capturing():
             side = _second_stream(video.device)
         if side is None:
-            for w in W:
-                block(w, 0, Fr)
+            chain(0, Fr)
             return x
         main, Fh = torch.cuda.current_stream(video.device), (Fr + 1) // 2
         side.wait_stream(main)
-        for w in W:
-            block(w, 0, Fh)
+        folds = [None, None]
+        if folding:
+            folds[0] = LNFold(x[:Fh * Lt]).from_stream(x[:Fh * Lt], DINO_EPS)
             with torch.cuda.stream(side):
-                block(w, Fh, Fr)
+                folds[1] = LNFold(x[Fh * Lt:]).from_stream(x[Fh * Lt:], DINO_EPS)
+        for i, w in enumerate(W):
+            block(w, 0, Fh, folds[0], feed_next=i + 1 < len(W))
+            with torch.cuda.stream(side):
+                block(w, Fh, Fr, folds[1], feed_next=i + 1 < len(W))
         main.wait_stream(side)
         return x
 

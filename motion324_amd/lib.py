@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class M324Error(RuntimeError):
@@ -39,6 +39,9 @@ class GemmArgs(C.Structure):
         ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_v", C.c_void_p),
         ("qkv_qw", C.c_void_p), ("qkv_kw", C.c_void_p),
         ("qkv_eps", C.c_float), ("qkv_qscale", C.c_float), ("qkv_L", C.c_int), ("qkv_H", C.c_int),
+        ("ln_rowstat", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("ln_stats_out", C.c_void_p),
+        ("ln_copy_out", C.c_void_p), ("ln_ldcopy", C.c_long),
     ]
 
 
@@ -55,6 +58,8 @@ SIGNATURES = {
     "m324_attention_plan": [_I, _I, _I, _I, _I, _I, C.c_char_p, _I],
     "m324_gemm_tn": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _L, _P],
     "m324_n3_finish": [_P, _I, _I, _P, _P, _P],
+    "m324_rowstats_finish": [_P, _I, _I, _F, _P, _P],
+    "m324_rowstats": [_P, _L, _I, _I, _F, _P, _P, _L, _P],
     "m324_layernorm": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_layernorm_in": [_P, _I, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

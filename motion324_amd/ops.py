@@ -119,14 +119,18 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1) -> torch.Tensor:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = L.ACT_NONE, gamma=None,
          residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0),
          preact_out: Optional[torch.Tensor] = None, gelu_grad_of: Optional[torch.Tensor] = None,
-         qkv_heads: Optional[tuple] = None, n3: Optional[tuple] = None) -> torch.Tensor:
+         qkv_heads: Optional[tuple] = None, n3: Optional[tuple] = None, ln: Optional[tuple] = None,
+         stats_out: Optional[torch.Tensor] = None, copy_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm.
     preact_out [M, N] (out's dtype) also receives the value the activation is applied to (M324_AUX_STORE_PREACT);
     gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only.
     qkv_heads = (Q, K, V, q_w, k_w, eps, q_scale, L, H): the fused q|k|v projection is written head-major into Q / K / V
     [B, H, L, 64] with per-head RMSNorm and the q pre-scale (M324_AUX_QKV_HEADS); `out` is ignored (may be None).
     A V of shape [B, H, 64, L] selects M324_AUX_QKV_HEADS_VT: V leaves transposed and key-permuted, the operand
-    attention() reads by default (L % 128 == 0)."""
+    attention() reads by default (L % 128 == 0).
+    LayerNorm fold (include/m324.h): ln = (rowstat fp32 [M, 2], colsum fp32 [N]) -- `a` is the raw stream, `w` carries the
+    LayerNorm scale; stats_out fp32 [N / 64, M, 2] receives the per-block row statistics of the stored values and copy_out
+    bf16 [M, N] their bf16 twin (fp32 `out` only)."""
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K or a.dtype != w.dtype:
@@ -135,6 +139,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     args.A, args.lda = _rows(a, "a")
     args.W, args.ldw = _rows(w, "w")
     args.M, args.N, args.K = M, N, K
+    if ln is not None:
+        rowstat, colsum = ln
+        if (rowstat.dtype != torch.float32 or not rowstat.is_contiguous() or rowstat.numel() != 2 * M or a.dtype != torch.bfloat16):
+            raise L.M324Error(f"gemm: ln rowstat {rowstat.dtype}{tuple(rowstat.shape)} (want contiguous fp32 [{M}, 2], bf16 operands)")
+        args.ln_rowstat, args.ln_colsum = _p(rowstat), _vec(colsum, N, "ln colsum")
+    if stats_out is not None:
+        if (stats_out.dtype != torch.float32 or not stats_out.is_contiguous() or N % 64 or tuple(stats_out.shape) != (N // 64, M, 2)):
+            raise L.M324Error(f"gemm: stats_out {stats_out.dtype}{tuple(stats_out.shape)} (want contiguous fp32 [{N // 64}, {M}, 2])")
+        args.ln_stats_out = _p(stats_out)
+    if copy_out is not None:
+        if copy_out.dtype != torch.bfloat16 or copy_out.shape[0] < M or copy_out.shape[1] < N:
+            raise L.M324Error(f"gemm: copy_out {copy_out.dtype}{tuple(copy_out.shape)} (want bf16 [{M}, {N}])")
+        args.ln_copy_out, args.ln_ldcopy = _rows(copy_out, "copy_out")
     if qkv_heads is not None:
         Qo, Ko, Vo, qw, kw, eps, q_scale, Lh, Hh = qkv_heads
         Bh = M // Lh
@@ -201,14 +218,42 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     esz = a.element_size()
     tag = "" if not _timing() else (
         f"{_gemm_plan(args)} | M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}"
-        f"{' gamma' if gamma is not None else ''}{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}")
+        f"{' gamma' if gamma is not None else ''}{' res' if residual is not None else ''} out={'bf16' if out.element_size() == 2 else 'f32'}"
+        f"{' ln-fold' if ln is not None else ''}{' ln-stats' if stats_out is not None else ''}")
     # algorithmic bytes: both operands once, the output once, the fp32 residual rows once
     nbytes = esz * (M * K + N * K) + out.element_size() * M * N
     if residual is not None:
         nbytes += residual.element_size() * N * (res_rows if 0 < res_rows < M else M)
+    if copy_out is not None:
+        nbytes += 2 * M * N
     with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, nbytes, tag):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     return out
+
+
+def rowstats_finish(part: torch.Tensor, eps: float, rowstat: torch.Tensor) -> torch.Tensor:
+    """rowstat[m] = (rstd, -rstd mean) from the per-block (sum, M2) pairs part[ncb, M, 2] a producer GEMM left."""
+    ncb, M, two = part.shape
+    if (two != 2 or part.dtype != torch.float32 or not part.is_contiguous() or rowstat.dtype != torch.float32
+            or not rowstat.is_contiguous() or rowstat.numel() != 2 * M):
+        raise L.M324Error("rowstats_finish: part [ncb, M, 2] and rowstat [M, 2] must be contiguous fp32")
+    L.check(L.load().m324_rowstats_finish(_p(part), ncb, M, eps, _p(rowstat), _stream()), "m324_rowstats_finish")
+    return rowstat
+
+
+def rowstats(x: torch.Tensor, eps: float, rowstat: torch.Tensor, copy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same table straight from an fp32 stream x [rows, C], plus its bf16 twin `copy` (head of a folded chain)."""
+    px, ldx = _rows(x, "x")
+    rows, Cdim = x.shape
+    if x.dtype != torch.float32 or rowstat.dtype != torch.float32 or not rowstat.is_contiguous() or rowstat.numel() != 2 * rows:
+        raise L.M324Error("rowstats: x fp32 [rows, C], rowstat contiguous fp32 [rows, 2]")
+    pc, ldc = (None, 0)
+    if copy is not None:
+        if copy.dtype != torch.bfloat16 or copy.shape[0] < rows or copy.shape[1] != Cdim:
+            raise L.M324Error("rowstats: copy must be bf16 [rows, C]")
+        pc, ldc = _rows(copy, "copy")
+    L.check(L.load().m324_rowstats(px, ldx, rows, Cdim, eps, _p(rowstat), pc, ldc, _stream()), "m324_rowstats")
+    return rowstat
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float, out: torch.Tensor,

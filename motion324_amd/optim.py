@@ -91,6 +91,11 @@ class FusedAdamW:
         self.names: List[str] = [n for n, _ in decay + nodecay]
         self.params: List[torch.nn.Parameter] = [p for _, p in decay + nodecay]
         self.n_decay_params = len(decay)
+        # Checkpoint numbering = the reference's create_optimizer (utils/training_utils.py:38-52): named_parameters()
+        # order, the decay group first.  The LAYOUT above may be re-sorted by gradient-completion order (buckets); the
+        # numbering a checkpoint carries never is.  ckpt_names[k] = name of checkpoint parameter k.
+        is_decay = lambda p: p.dim() > 1 and not getattr(p, "_no_weight_decay", False)
+        self.ckpt_names: List[str] = [n for n, p in named if is_decay(p)] + [n for n, p in named if not is_decay(p)]
         self.decay = [i < self.n_decay_params for i in range(len(self.params))]
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.clip, self.skip_factor, self.group = grad_clip_norm, allowed_gradnorm_factor, group
@@ -263,10 +268,13 @@ class FusedAdamW:
         parameter numbering of utils/training_utils.py:38-52 (decay parameters first), so the dict loads into
         torch.optim.AdamW built by the reference's create_optimizer and vice versa."""
         state = {}
+        layout = {n: i for i, n in enumerate(self.names)}
         if self.step_count > 0:
-            for i, p in enumerate(self.params):
+            for k, name in enumerate(self.ckpt_names):       # k: the reference's parameter number, i: our layout slot
+                i = layout[name]
+                p = self.params[i]
                 o, n = self.offsets[i], p.numel()
-                state[i] = {"step": torch.tensor(float(self.step_count)),
+                state[k] = {"step": torch.tensor(float(self.step_count)),
                             "exp_avg": self.m[o:o + n].view(p.shape).clone(),
                             "exp_avg_sq": self.v[o:o + n].view(p.shape).clone()}
         common = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "amsgrad": False, "maximize": False,
@@ -275,22 +283,21 @@ class FusedAdamW:
         nd = self.n_decay_params
         groups = [dict(common, weight_decay=self.wd, params=list(range(nd))),
                   dict(common, weight_decay=0.0, params=list(range(nd, len(self.params))))]
-        return {"state": state, "param_groups": groups, "param_names": list(self.names)}
+        return {"state": state, "param_groups": groups, "param_names": list(self.ckpt_names)}
 
     def load_state_dict(self, sd: dict) -> None:
         groups = sd.get("param_groups", [])
         ids = [i for g in groups for i in g.get("params", [])]
         if ids and len(ids) != len(self.params):
             raise ValueError(f"optimizer state has {len(ids)} parameters, this optimizer {len(self.params)}")
+        # A dict without names comes from torch.optim.AdamW as the reference builds it (torch drops unknown keys and
+        # never writes names): its numbering is create_optimizer's = self.ckpt_names.  Ours carries the names anyway.
         names = sd.get("param_names")
-        if names is not None and list(names) != list(self.names):
-            # same tensors, different numbering (e.g. saved without a completion order): map by name
-            pos = {n: i for i, n in enumerate(names)}
-            if set(pos) != set(self.names):
-                raise ValueError("optimizer state names do not match the parameters")
-            remap = [pos[n] for n in self.names]
-        else:
-            remap = list(range(len(self.params)))
+        names = list(self.ckpt_names) if names is None else list(names)
+        pos = {n: k for k, n in enumerate(names)}
+        if set(pos) != set(self.names):
+            raise ValueError("optimizer state names do not match the parameters")
+        remap = [pos[n] for n in self.names]               # layout slot i <- checkpoint parameter remap[i]
         state = sd.get("state", {})
         steps = set()
         self.m.zero_()

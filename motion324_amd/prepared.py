@@ -136,6 +136,29 @@ class Prepared:
         return self._get("catv", tuple(ps), lambda: torch.cat(
             [p.detach().to(device=self.device, dtype=torch.float32).reshape(-1) for p in ps]).contiguous())
 
+    def folded(self, ln_w: torch.Tensor, ln_b: Optional[torch.Tensor], w: torch.Tensor, b: Optional[torch.Tensor]):
+        """A LayerNorm folded into the Linear behind it (m324_gemm's LayerNorm fold): returns
+        (W' bf16 [N, K] = w_ln[k] W[n, k], colsum fp32 [N] = sum_k W'[n, k] of the ROUNDED values, bias' fp32 [N] =
+        b + W b_ln or None).  One-time weight preparation, like mat()."""
+        ps = tuple(p for p in (ln_w, ln_b, w, b) if p is not None)
+
+        def make():
+            W = w.detach().reshape(w.shape[0], -1).to(device=self.device, dtype=torch.float32)
+            if W.shape[1] % K_ALIGN:
+                raise ValueError("folded(): K must be a multiple of 64")
+            Wf = (W * ln_w.detach().to(device=self.device, dtype=torch.float32)[None, :]).to(torch.bfloat16).contiguous()
+            colsum = Wf.double().sum(dim=1).float().contiguous()
+            bias = None
+            if ln_b is not None or b is not None:
+                bias = torch.zeros(W.shape[0], dtype=torch.float64, device=self.device)
+                if b is not None:
+                    bias += b.detach().to(device=self.device, dtype=torch.float64)
+                if ln_b is not None:
+                    bias += W.double() @ ln_b.detach().to(device=self.device, dtype=torch.float64)
+                bias = bias.float().contiguous()
+            return (Wf, colsum, bias)
+        return self._get("folded", ps, make)
+
     def f32(self, p: torch.Tensor) -> torch.Tensor:
         """fp32 contiguous device copy of a parameter/buffer of any shape (tokens, position tables)."""
         if p.dtype == torch.float32 and p.device == self.device and p.is_contiguous():

@@ -95,13 +95,64 @@ class QK_Norm_CrossAttention(_AttnBase):
         self.fc = nn.Linear(dim, dim, bias=fc_bias)
 
 
-def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor) -> torch.Tensor:
-    """x += fc2(gelu(fc1(LN(x))))  (reference transformer.py:376,422), x fp32 [rows, C], in place."""
+# LayerNorm fold (bf16 inference, include/m324.h): the GEMM that writes a residual stream leaves the row statistics of
+# what it stored (and, next to an fp32 stream, its bf16 twin); the GEMM behind the LayerNorm reads that twin with the
+# LayerNorm's scale folded into its weight and applies mean / rstd in its epilogue.  The LayerNorm pass itself -- 6 bytes
+# per element of pure HBM traffic, 85 launches per clip -- disappears.  M324_FOLD_LN=0 restores the separate passes.
+FOLD_LN = os.environ.get("M324_FOLD_LN", "1") != "0"
+
+
+class LNFold:
+    """What travels with a residual stream x [rows, C] under the LayerNorm fold: xb (bf16 twin = the folded GEMMs' A operand;
+    the stream itself when that is bf16), part (per-64-column-block (sum, M2) left by the producer GEMM) and stat
+    ((rstd, -rstd mean) per row, valid once ready(eps) has merged the blocks)."""
+
+    def __init__(self, x: torch.Tensor):
+        rows, C = x.shape
+        self.rows, self.C = rows, C
+        self.xb = x if x.dtype == torch.bfloat16 else torch.empty((rows, C), dtype=torch.bfloat16, device=x.device)
+        self.part = torch.empty((C // 64, rows, 2), dtype=torch.float32, device=x.device)
+        self.stat = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        self.pending = False
+        self.own_copy = x.dtype != torch.bfloat16
+
+    @staticmethod
+    def usable(P: Prepared, rows: int, C: int) -> bool:
+        return (FOLD_LN and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64 and C % 64 == 0
+                and not torch.is_grad_enabled())
+
+    def from_stream(self, x: torch.Tensor, eps: float) -> "LNFold":
+        """Head of a chain: statistics (and the bf16 twin) straight from the fp32 stream."""
+        ops.rowstats(x, eps, self.stat, self.xb if self.own_copy else None)
+        self.pending = False
+        return self
+
+    def producer(self) -> dict:
+        """Keyword arguments for the ops.gemm call that writes the stream."""
+        self.pending = True
+        return dict(stats_out=self.part, copy_out=self.xb if self.own_copy else None)
+
+    def ready(self, eps: float) -> torch.Tensor:
+        if self.pending:
+            ops.rowstats_finish(self.part, eps, self.stat)
+            self.pending = False
+        return self.stat
+
+
+def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor, fold: Optional[LNFold] = None,
+                  feed_next: bool = True) -> torch.Tensor:
+    """x += fc2(gelu(fc1(LN(x))))  (reference transformer.py:376,422), x [rows, C] (fp32, or the decoder's bf16 stream), in
+    place.  fold: the stream's LNFold with statistics pending or ready; fc2 then leaves the next LayerNorm's (feed_next)."""
     rows, C = x.shape
     fc1, fc2 = mlp.mlp[0], mlp.mlp[2]
+    h1 = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=x.device)
+    if fold is not None:
+        w1, cs1, b1 = P.folded(norm2.weight, norm2.bias, fc1.weight, fc1.bias)
+        ops.gemm(fold.xb, w1, h1, bias=b1, act=ACT_GELU, ln=(fold.ready(norm2.eps), cs1))
+        ops.gemm(h1, P.mat(fc2.weight), x, bias=P.vec(fc2.bias), residual=x, **(fold.producer() if feed_next else {}))
+        return x
     h = torch.empty((rows, C), dtype=P.dtype, device=x.device)
     ops.layernorm(x, P.vec(norm2.weight), P.vec(norm2.bias), norm2.eps, h)
-    h1 = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=x.device)
     ops.gemm(h, P.mat(fc1.weight), h1, bias=P.vec(fc1.bias), act=ACT_GELU)
     ops.gemm(h1, P.mat(fc2.weight), x, bias=P.vec(fc2.bias), residual=x)
     return x
@@ -149,50 +200,58 @@ class QK_Norm_TransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim, bias=ln_bias)
         self.mlp = MLP(dim, mlp_ratio=mlp_ratio, bias=mlp_bias, dropout=mlp_dropout)
 
-    def run(self, P: Prepared, x: torch.Tensor, B: int, L: int, kv_gather=None) -> torch.Tensor:
+    def run(self, P: Prepared, x: torch.Tensor, B: int, L: int, kv_gather=None, fold: Optional[LNFold] = None,
+            feed_next: bool = True) -> torch.Tensor:
         """x: fp32 [B*L, C] residual stream, updated in place (x + attn(LN x); x + mlp(LN x)).
 
         kv_gather (frame-parallel global attention): object with start(kv_local [B*L, 2C]) / finish() -> (all ranks'
         [B*L_full, 2C], L_full) -- Pcd_motion._KVGather; queries stay local, keys/values cover the whole clip.  The k|v
-        projection runs first so that its all-gather travels while the q projection and the q split execute."""
+        projection runs first so that its all-gather travels while the q projection and the q split execute.
+        fold: the stream's LNFold (statistics of x pending or ready): both LayerNorms of the block are folded into the
+        projections behind them; the last GEMM leaves the statistics for the next block unless feed_next is False."""
         rows, C = x.shape
         assert rows == B * L
         a = self.attn
         h = torch.empty((rows, C), dtype=P.dtype, device=x.device)
-        ops.layernorm(x, P.vec(self.norm1.weight), P.vec(self.norm1.bias), self.norm1.eps, h)
         qw, kw = a._qk_w(P)
+        if fold is not None:
+            w, cs, bias = P.folded(self.norm1.weight, self.norm1.bias, a.to_qkv.weight, a.to_qkv.bias)
+            src, lnk = fold.xb, (lambda lo, hi: dict(ln=(fold.ready(self.norm1.eps), cs[lo:hi])))
+        else:
+            ops.layernorm(x, P.vec(self.norm1.weight), P.vec(self.norm1.bias), self.norm1.eps, h)
+            w, bias = P.mat(a.to_qkv.weight), P.vec(a.to_qkv.bias)
+            src, lnk = h, (lambda lo, hi: {})
+        out_kw = fold.producer if fold is not None else dict
         if fuse_qkv(P, rows, L) and kv_gather is None:
             # short sequences (the per-frame blocks): the projection's epilogue writes head-major Q / K / V itself
             # (RMSNorm + q pre-scale on the fp32 accumulators) and the attention reads V row-major
             long_seq = L >= 2048
             Q, K = (torch.empty((B, a.num_heads, L, 64), dtype=P.dtype, device=x.device) for _ in range(2))
             V = torch.empty((B, a.num_heads, 64, L) if long_seq else (B, a.num_heads, L, 64), dtype=P.dtype, device=x.device)
-            ops.gemm(h, P.mat(a.to_qkv.weight), None, bias=P.vec(a.to_qkv.bias),
-                     qkv_heads=(Q, K, V, qw, kw, RMS_EPS, ops.Q_PRESCALE, L, a.num_heads))
+            ops.gemm(src, w, None, bias=bias, qkv_heads=(Q, K, V, qw, kw, RMS_EPS, ops.Q_PRESCALE, L, a.num_heads),
+                     **lnk(0, 3 * C))
             ops.attention(Q, K, V, h, prescaled=True, v_rowmajor=not long_seq)
-            ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
-            return _mlp_residual(P, self.norm2, self.mlp, x)
+            ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x, **out_kw())
+            return _mlp_residual(P, self.norm2, self.mlp, x, fold, feed_next)
         if kv_gather is None:
             qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=x.device)
-            ops.gemm(h, P.mat(a.to_qkv.weight), qkv, bias=P.vec(a.to_qkv.bias))
+            ops.gemm(src, w, qkv, bias=bias, **lnk(0, 3 * C))
             Q, K, Vt = ops.qkv_split(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kw, RMS_EPS, B, L, a.num_heads,
                                      P.dtype, q_scale=ops.Q_PRESCALE)
         else:
             # to_qkv.weight rows [C, 3C) are the k|v projection, rows [0, C) the q projection (contiguous row slices)
-            w = P.mat(a.to_qkv.weight)
-            bias = P.vec(a.to_qkv.bias)
             kv = torch.empty((rows, 2 * C), dtype=P.dtype, device=x.device)
-            ops.gemm(h, w[C:], kv, bias=None if bias is None else bias[C:])
+            ops.gemm(src, w[C:], kv, bias=None if bias is None else bias[C:], **lnk(C, 3 * C))
             kv_gather.start(kv)                                                       # collective on the side stream ...
             q = torch.empty((rows, C), dtype=P.dtype, device=x.device)
-            ops.gemm(h, w[:C], q, bias=None if bias is None else bias[:C])            # ... under the q projection + split
+            ops.gemm(src, w[:C], q, bias=None if bias is None else bias[:C], **lnk(0, C))   # ... under the q projection + split
             Q, _, _ = ops.qkv_split(q, None, None, qw, None, RMS_EPS, B, L, a.num_heads, P.dtype, q_scale=ops.Q_PRESCALE)
             kv_full, L_full = kv_gather.finish()
             _, K, Vt = ops.qkv_split(None, kv_full[:, :C], kv_full[:, C:], None, kw, RMS_EPS, B, L_full, a.num_heads,
                                      P.dtype)
         ops.attention(Q, K, Vt, h, prescaled=True)                                       # h reused as the attention output
-        ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x)
-        return _mlp_residual(P, self.norm2, self.mlp, x)
+        ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x, **out_kw())
+        return _mlp_residual(P, self.norm2, self.mlp, x, fold, feed_next)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Stand-alone use: x [B, L, C] on a HIP device; precision follows torch.autocast like the reference."""
@@ -243,7 +302,7 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         return K, Vt
 
     def attend(self, P: Prepared, Q, K, Vt, residual: torch.Tensor, res_rows: int, shared_q: bool,
-               bf16_stream: bool = False) -> torch.Tensor:
+               bf16_stream: bool = False, want_fold: bool = False):
         """x = residual[(row % res_rows)] + fc(attention); x += mlp(LN x).  Returns fp32 [B*Lq, C] -- or, with bf16_stream in
         bf16 inference, the same in bf16: the decoder's stream is two additions deep and only feeds a LayerNorm whose output
         is rounded to bf16 anyway (+1.6e-3 on pcd_moved against 4.7e-3 of the bf16 mode as a whole), while its fp32 form costs
@@ -254,8 +313,11 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         ops.attention(Q, K, Vt, o, shared_q=shared_q, prescaled=True)
         xdt = torch.bfloat16 if (bf16_stream and P.dtype == torch.bfloat16 and not torch.is_grad_enabled()) else torch.float32
         x = torch.empty((B * Lq, a.dim), dtype=xdt, device=Q.device)
-        ops.gemm(o, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=residual, res_rows=res_rows)
-        return _mlp_residual(P, self.norm2, self.mlp, x)
+        fold = LNFold(x) if LNFold.usable(P, B * Lq, a.dim) else None
+        ops.gemm(o, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=residual, res_rows=res_rows,
+                 **(fold.producer() if fold is not None else {}))
+        _mlp_residual(P, self.norm2, self.mlp, x, fold, feed_next=want_fold)
+        return (x, fold) if want_fold else x
 
     def run(self, P: Prepared, query: torch.Tensor, kv: torch.Tensor, B: int, Lq: int, Lk: int) -> torch.Tensor:
         Q = self.project_q(P, query, B, Lq)

@@ -430,17 +430,29 @@ def test_optimizer_state_roundtrip_resumes_bit_identically(tmp_path):
     assert l3 == l3b
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     assert all(torch.equal(pa[n], pb[n]) for n in pa)
-    # the dict is torch.optim.AdamW's: build the reference's two groups (decay first) and load it
+    # The dict is torch.optim.AdamW's with the numbering of the reference's create_optimizer (utils/training_utils.py:38-52:
+    # named_parameters() order, decay group first) -- although this optimizer's LAYOUT is sorted by gradient-completion
+    # order.  Build torch's optimizer exactly as the reference does (no names involved) and check every tensor's moments
+    # (the trunk blocks have identical shapes: a swapped numbering would pass any shape check).
     sd = torch.load(path, weights_only=True)["optimizer"]
-    decay = [p for n, p in b.named_parameters() if p.requires_grad and p.dim() > 1]
-    nodecay = [p for n, p in b.named_parameters() if p.requires_grad and p.dim() <= 1]
-    by_name = dict(b.named_parameters())
-    ordered = [by_name[n] for n in sd["param_names"]]
-    topt = torch.optim.AdamW([{"params": ordered[:len(decay)], "weight_decay": 0.05},
-                              {"params": ordered[len(decay):], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
+    decay = [p for n, p in b.named_parameters() if p.requires_grad and not (p.dim() == 1 or getattr(p, "_no_weight_decay", False))]
+    nodecay = [p for n, p in b.named_parameters() if p.requires_grad and (p.dim() == 1 or getattr(p, "_no_weight_decay", False))]
+    topt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": nodecay, "weight_decay": 0.0}],
+                             lr=1e-3, betas=(0.9, 0.95))
     topt.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})
-    st = topt.state[ordered[0]]
-    assert float(st["step"]) == 2.0 and st["exp_avg"].shape == ordered[0].shape
+    assert ob.names != ob.ckpt_names                        # the layout really is re-sorted
+    oc = FusedAdamW(b.named_parameters(), lr=1e-3, allowed_gradnorm_factor=1e9, order=backward_completion_order(b), flatten=False)
+    oc.load_state_dict(sd)
+    for p in decay + nodecay:
+        st = topt.state[p]
+        assert float(st["step"]) == 2.0
+        i = oc._index[id(p)]
+        o, n = oc.offsets[i], p.numel()
+        assert torch.equal(st["exp_avg"].reshape(-1), oc.m[o:o + n]) and torch.equal(st["exp_avg_sq"].reshape(-1), oc.v[o:o + n])
+    # and back: a dict written by torch's own AdamW (no names, the reference's numbering) lands on the right tensors
+    od = FusedAdamW(b.named_parameters(), lr=1e-3, allowed_gradnorm_factor=1e9, order=backward_completion_order(b), flatten=False)
+    od.load_state_dict(topt.state_dict())
+    assert od.step_count == 2 and torch.equal(od.m, oc.m) and torch.equal(od.v, oc.v)
 
 
 # ------------------------------------------------------------------------------------------------------ C-ABI collectives

@@ -1,4 +1,5 @@
 """Host-side contract of the drop-in (no GPU): state-dict manifest, module semantics, return type, weight cache."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -183,3 +184,20 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     torch.save(bad, path)
     with pytest.raises(RuntimeError, match="does not match"):
         ck.load_checkpoint(path, dst, "cpu")
+
+
+def test_cosine_schedule_matches_the_reference_scheduler():
+    """optim.cosine_with_warmup against the lr sequence the reference's create_lr_scheduler
+    (transformers.get_cosine_schedule_with_warmup, utils/training_utils.py:73-82) produced for 40 steps of a
+    (base 4e-4, warm-up 5, total 30) run -- stored in tests/golden/train_tiny.npz by make_train_golden.py: warm-up from 0,
+    half cosine down to 0 at `total`, and the rise beyond it that the reference's formula has."""
+    import numpy as np
+    from conftest import GOLDEN
+    from motion324_amd.optim import cosine_with_warmup
+    gold = np.load(os.path.join(GOLDEN, "train_tiny.npz"))
+    seq = gold["sched_lr_base4e-4_warmup5_total30"]
+    got = [cosine_with_warmup(i, 5, 30, 4e-4) for i in range(len(seq))]
+    assert np.allclose(got, seq, rtol=1e-12, atol=1e-18)
+    assert got[0] == 0.0 and got[5] == 4e-4 and got[30] < 1e-18 and got[33] > got[31] > 0.0
+    # the run the goldens' three steps used
+    assert np.allclose([cosine_with_warmup(i, 1, 10, 1e-3) for i in range(3)], gold["lr"], rtol=1e-12)

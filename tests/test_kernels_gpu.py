@@ -756,3 +756,181 @@ def test_mse():
     out = ops.mse(a.to(DEV), b.to(DEV), 0.5)
     assert abs(float(out) - 0.5 * float(((a.double() - b.double()) ** 2).mean())) < 1e-6
 
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm fold
+def _ln_ref(x, w, b, eps):
+    x = x.double()
+    mu = x.mean(dim=1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=1, keepdim=True)
+    y = (x - mu) / torch.sqrt(var + eps) * w.double()
+    return y + b.double() if b is not None else y
+
+
+@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,groups", [(3 * 256, 768, 192, 1), (2 * 230, 192, 256, 2), (513, 576, 128, 1)])
+def test_gemm_ln_fold_producer(tune, variant, out_dtype, M, N, K, groups):
+    """Producer side of the LayerNorm fold: the epilogue that writes the stream x = residual + A W^T + b also leaves the
+    per-64-column-block (sum, M2) of every row (the fp32 values it is about to round) and, next to an fp32 stream, its bf16
+    twin; m324_rowstats_finish merges the blocks into (rstd, -rstd mean).  Checked against fp64 LayerNorm statistics of the
+    exact stream, with a row offset of +30 on some rows (mean >> std: the E[x^2] - mean^2 form would lose 3 digits there)."""
+    ops = _ops()
+    if variant != "v0":
+        tune("M324_GEMM", variant)
+    dtype = torch.bfloat16
+    a, w = _q(_rand((M, K), 201), dtype), _q(_rand((N, K), 202, 0.1), dtype)
+    bias = _rand((N,), 203)
+    res = _rand((M // groups, N), 204)
+    res[::7] += 30.0
+    ad, wd = a.to(dtype).to(DEV), w.to(dtype).to(DEV)
+    exact = a.double() @ w.double().T + bias.double() + res.double().repeat(groups, 1)
+    part = torch.full((N // 64, M, 2), float("nan"), device=DEV)
+    copy = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV) if out_dtype == torch.float32 else None
+    if out_dtype == torch.float32 or groups > 1:
+        out = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
+        ops.gemm(ad, wd, out, bias=bias.to(DEV), residual=res.to(DEV), res_rows=M // groups if groups > 1 else 0,
+                 stats_out=part, copy_out=copy)
+    else:                                                    # the bf16 stream updated in place (the decoder MLP's fc2)
+        out = res.to(dtype).to(DEV)
+        exact = a.double() @ w.double().T + bias.double() + res.to(dtype).double()
+        ops.gemm(ad, wd, out, bias=bias.to(DEV), residual=out, stats_out=part)
+    assert rel_err(out.float(), exact) < (1e-5 if out_dtype == torch.float32 else 4e-3)
+    if copy is not None:
+        assert torch.equal(copy.cpu(), out.cpu().to(torch.bfloat16))         # the twin is the stored value, rounded once
+    p = part.double().cpu()
+    assert torch.isfinite(p).all()
+    blocks = exact.reshape(M, N // 64, 64)
+    assert torch.allclose(p[..., 0].T, blocks.sum(-1), rtol=1e-5, atol=1e-3)
+    m2 = ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1)
+    assert torch.allclose(p[..., 1].T, m2, rtol=1e-4, atol=1e-4)
+    stat = torch.empty((M, 2), device=DEV)
+    ops.rowstats_finish(part, 1e-5, stat)
+    mu = exact.mean(1)
+    rstd = 1.0 / torch.sqrt(exact.var(1, unbiased=False) + 1e-5)
+    s = stat.double().cpu()
+    assert torch.allclose(s[:, 0], rstd, rtol=2e-5) and torch.allclose(s[:, 1], -rstd * mu, rtol=2e-5, atol=1e-5)
+
+
+def test_rowstats_from_stream():
+    ops = _ops()
+    rows, C = 700, 768
+    x = _rand((rows, C), 211)
+    x[::5] += 12.0
+    stat = torch.empty((rows, 2), device=DEV)
+    copy = torch.empty((rows, C), dtype=torch.bfloat16, device=DEV)
+    ops.rowstats(x.to(DEV), 1e-6, stat, copy)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-6)
+    s = stat.double().cpu()
+    assert torch.allclose(s[:, 0], rstd, rtol=1e-5) and torch.allclose(s[:, 1], -rstd * x.double().mean(1), rtol=1e-5, atol=1e-6)
+    assert torch.equal(copy.cpu(), x.to(torch.bfloat16))
+
+
+def _folded(lnw, lnb, w, b):
+    """What Prepared.folded() hands to the kernel, on the CPU: (W' bf16, colsum, bias')."""
+    wf = (w * lnw[None, :]).to(torch.bfloat16)
+    colsum = wf.double().sum(1).float()
+    bias = None
+    if lnb is not None or b is not None:
+        bias = torch.zeros(w.shape[0], dtype=torch.float64)
+        if b is not None:
+            bias += b.double()
+        if lnb is not None:
+            bias += w.double() @ lnb.double()
+        bias = bias.float()
+    return wf, colsum, bias
+
+
+@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("mode", ["plain", "gelu", "f32out"])
+@pytest.mark.parametrize("M,N,K", [(3 * 256, 768, 192), (470, 192, 256), (513, 3072, 768)])
+def test_gemm_ln_fold_consumer(tune, variant, mode, M, N, K):
+    """Consumer side: A = the raw bf16 stream, W' = w_ln W, epilogue rstd (acc - mean colsum) + b' == Linear(LayerNorm(x)).
+    Against fp64 LayerNorm + Linear of the same bf16 stream (rows with mean >> std included: the subtraction in the epilogue
+    cancels there, the band states what is left)."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    if variant != "v0":
+        tune("M324_GEMM", variant)
+    x = _rand((M, K), 221)
+    x[::9] += 3.0                                            # mean = 3 sigma on some rows
+    xb = x.to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * _rand((K,), 222), 0.1 * _rand((K,), 223)
+    w, b = _rand((N, K), 224, 0.05), _rand((N,), 225)
+    wf, colsum, bias = _folded(lnw, lnb, w, b)
+    stat = torch.empty((M, 2), device=DEV)
+    ops.rowstats(xb.float().to(DEV), 1e-5, stat)
+    odt = torch.float32 if mode == "f32out" else torch.bfloat16
+    out = torch.full((M, N), float("nan"), dtype=odt, device=DEV)
+    ops.gemm(xb.to(DEV), wf.to(DEV), out, bias=bias.to(DEV), act=ACT_GELU if mode == "gelu" else 0, ln=(stat, colsum.to(DEV)))
+    ref = _ln_ref(xb.float(), lnw, lnb, 1e-5) @ w.double().T + b.double()
+    if mode == "gelu":
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2.0)))
+    # W' is rounded to bf16 (2^-9 per weight, averaging out over K) and the output once more
+    assert rel_err(out.float(), ref) < (3e-3 if odt == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("L,vt", [(257, False), (324, False), (256, True)])
+def test_gemm_ln_fold_qkv_heads(L, vt):
+    """The fused q|k|v projection epilogue (head-major Q / K / V, RMSNorm, q pre-scale, optional transposed V) behind a folded
+    LayerNorm == the same epilogue fed with the explicitly normalised rows."""
+    ops = _ops()
+    B, H, C = 3, 3, 192
+    M = B * L
+    x = _rand((M, C), 231)
+    xb = x.to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * _rand((C,), 232), 0.1 * _rand((C,), 233)
+    w, b = _rand((3 * C, C), 234, 0.08), _rand((3 * C,), 235, 0.1)
+    qw, kw = 1 + 0.1 * _rand((64,), 236), 1 + 0.1 * _rand((64,), 237)
+    wf, colsum, bias = _folded(lnw, lnb, w, b)
+    stat = torch.empty((M, 2), device=DEV)
+    ops.rowstats(xb.float().to(DEV), 1e-5, stat)
+
+    def run(a, wmat, bvec, ln):
+        Q, K = (torch.full((B, H, L, 64), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        V = torch.full((B, H, 64, L) if vt else (B, H, L, 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a.to(DEV), wmat.to(DEV), None, bias=bvec.to(DEV),
+                 qkv_heads=(Q, K, V, qw.to(DEV), kw.to(DEV), 1e-5, ops.Q_PRESCALE, L, H), ln=ln)
+        return Q.float().cpu(), K.float().cpu(), V.float().cpu()
+    got = run(xb, wf, bias, (stat, colsum.to(DEV)))
+    h = _ln_ref(xb.float(), lnw, lnb, 1e-5).to(torch.bfloat16)
+    want = run(h, w.to(torch.bfloat16), b, None)
+    for g, r in zip(got, want):
+        assert torch.isfinite(g).all() and rel_err(g, r) < 8e-3     # two bf16 roundings apart (h vs W')
+
+
+def test_gemm_ln_fold_n3_head():
+    """M324_AUX_N3 (Linear -> GELU -> Linear(C -> 3) in one epilogue) behind a folded LayerNorm."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    M, C = 1000, 768
+    x = _rand((M, C), 241)
+    xb = x.to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * _rand((C,), 242), 0.1 * _rand((C,), 243)
+    w, b = _rand((C, C), 244, 0.05), _rand((C,), 245, 0.1)
+    w3, b3 = _rand((3, C), 246, 0.1), _rand((3,), 247)
+    wf, colsum, bias = _folded(lnw, lnb, w, b)
+    stat = torch.empty((M, 2), device=DEV)
+    ops.rowstats(xb.float().to(DEV), 1e-5, stat)
+    part = torch.empty((C // 64, M, 3), device=DEV)
+    ops.gemm(xb.to(DEV), wf.to(DEV), None, bias=bias.to(DEV), act=ACT_GELU, n3=(w3.to(DEV), part), ln=(stat, colsum.to(DEV)))
+    out = torch.empty((M, 3), device=DEV)
+    ops.n3_finish(part, b3.to(DEV), out)
+    v = _ln_ref(xb.float(), lnw, lnb, 1e-5) @ w.double().T + b.double()
+    v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+    assert rel_err(out, v @ w3.double().T + b3.double()) < 3e-3
+
+
+def test_gemm_ln_fold_rejects_unsupported_shapes():
+    ops = _ops()
+    from motion324_amd.lib import M324Error
+    a = torch.zeros((64, 128), dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros((128, 128), dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros((64, 128), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(M324Error):                            # M <= 64: the skinny kernel has no fold
+        ops.gemm(a, w, out, ln=(torch.zeros((64, 2), device=DEV), torch.zeros(128, device=DEV)))
+    a = torch.zeros((256, 128), dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros((96, 128), dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros((256, 96), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(M324Error):                            # N % 64 != 0
+        ops.gemm(a, w, out, ln=(torch.zeros((256, 2), device=DEV), torch.zeros(96, device=DEV)))
