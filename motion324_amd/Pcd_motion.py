@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops, parallel
+from . import ops, parallel, switches
 from .easydict import EasyDict as edict
 from .image_encoder import DINO_EPS, DinoEncoder
 from .lib import ACT_GELU, M324Error
@@ -32,11 +32,12 @@ from .prepared import Prepared, bump_generation, compute_dtype, pad_k
 from .timing import span
 from .transformer import LN_EPS, LNFold, QK_Norm_CrossAttentionBlock, QK_Norm_TransformerBlock, init_weights
 
-AUTO_GRAPH = os.environ.get("M324_AUTO_GRAPH", "1") != "0"          # forward(): graph replay for repeated inference shapes
-FUSE_HEAD_N3 = os.environ.get("M324_FUSE_HEAD", "1") != "0"        # A/B switch: head fc1 + GELU + 768 -> 3 in one GEMM epilogue (bf16 inference)
-BF16_DECODER_STREAM = os.environ.get("M324_BF16_DECODER", "1") != "0"   # A/B switch: the decoder's residual stream in bf16 (bf16 inference only)
-HOIST_DECODER_Q = os.environ.get("M324_HOIST_Q", "1") != "0"    # A/B switch of the hoisted decoder q projection (forward())
-DECODE_ROWS = int(os.environ.get("M324_DECODE_ROWS", 1 << 17))     # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
+# A/B switches: one table with defaults and meanings in motion324_amd/switches.py (bench.py echoes non-default values)
+AUTO_GRAPH = switches.flag("M324_AUTO_GRAPH")               # forward(): graph replay for repeated inference shapes
+FUSE_HEAD_N3 = switches.flag("M324_FUSE_HEAD")              # head fc1 + GELU + 768 -> 3 in one GEMM epilogue (bf16 inference)
+BF16_DECODER_STREAM = switches.flag("M324_BF16_DECODER")    # the decoder's residual stream in bf16 (bf16 inference only)
+HOIST_DECODER_Q = switches.flag("M324_HOIST_Q")             # hoisted decoder q projection (graph capture)
+DECODE_ROWS = int(switches.get("M324_DECODE_ROWS"))         # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
 
 
 def _get(cfg, key, default=None):
@@ -79,7 +80,7 @@ def resize_pos_embed(posemb, src_shape, target_shape):
 
 
 # inference only: run the shape encoder on a side stream (M324_OVERLAP=0 disables, for A/B measurements)
-OVERLAP_SHAPE_ENCODER = os.environ.get("M324_OVERLAP", "1") != "0"
+OVERLAP_SHAPE_ENCODER = switches.flag("M324_OVERLAP")
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -258,6 +259,23 @@ class Motion_Latent_Model(nn.Module):
         out = torch.empty((n, C), dtype=torch.float32, device=xyz.device)
         ops.gemm(feat, P.mat(self.point_normal_rgb_proj.weight), out, bias=P.vec(self.point_normal_rgb_proj.bias))
         return out
+
+    def decoder_block(self, P: Prepared, Kd, Vd, pf: torch.Tensor, Q=None):
+        """The decoder cross-attention block on one sample's mesh points (reference transformer.py:365-377 through
+        Pcd_motion.py:556-561): pf fp32 [n, C] point features = the queries, Kd / Vd the T frames' latent keys / values
+        (project_kv).  Returns (x [T * n, C] stream after attention + MLP, its LNFold or None).  Q: an already projected
+        query set (the graph hoists it onto the shape-encoder branch)."""
+        dec = self.decoder_cross_attn
+        n = pf.shape[0]
+        if Q is None:
+            Q = dec.project_q(P, pf, 1, n)
+        return dec.attend(P, Q, Kd, Vd, pf, n, shared_q=True, bf16_stream=BF16_DECODER_STREAM, want_fold=True)
+
+    def decoder_block_flops(self, B: int, T: int, N: int) -> float:
+        """Reference FLOPs of the block (to_q counted once per frame, as the reference computes it)."""
+        C, K = self.embed_dim, self.num_learnable_tokens
+        lin = lambda mm, i, o: 2.0 * mm * i * o
+        return B * T * (2 * lin(N, C, C) + 2 * lin(K, C, C) + 2 * lin(N, C, 4 * C) + 4.0 * (C // 64) * N * K * 64)
 
     def _video_pos(self, P: Prepared, T: int) -> torch.Tensor:
         g = self.latent_size
@@ -451,7 +469,7 @@ class Motion_Latent_Model(nn.Module):
             cap["dino_tokens"], cap["trunk_in"] = dn, tok.clone()
 
         # D. alternating global / local trunk (reference :394-409)
-        if shard is not None and shard[1] > 1:
+        if shard is not None and parallel.collectives_on(shard[1]):
             rank, world, group = shard
             kv_gather = _KVGather(B, T, Lt, parallel.counts(T_full, world), group, dev)
 
@@ -476,9 +494,7 @@ class Motion_Latent_Model(nn.Module):
         w3, b3 = P.f32(head_fc2.weight), P.vec(head_fc2.bias)
         # reference FLOPs of the decoder cross-attention block (to_q counted once per frame as the
         # reference computes it) -- attached to the stage span bench.py reports the 40 % MFMA target on
-        lin = lambda mm, i, o: 2.0 * mm * i * o
-        dec_flops = B * T * (2 * lin(N, C, C) + 2 * lin(K, C, C) + 2 * lin(N, C, 4 * C) + 4.0 * 12 * N * K * 64)
-        with span("stage:decoder_cross_attn_block", dec_flops):
+        with span("stage:decoder_cross_attn_block", self.decoder_block_flops(B, T, N)):
             Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))       # latent tokens 4..4+K of every frame
         nchunk = max(1, min(N, DECODE_ROWS // T))
         pcd, nrm, rgb = (self._f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
@@ -490,10 +506,8 @@ class Motion_Latent_Model(nn.Module):
                 else:
                     pf = self._point_features(P, pcd[b, n0:n1], nrm[b, n0:n1].contiguous(), rgb[b, n0:n1].contiguous())
                 with span("stage:decoder_cross_attn_block", 0.0):
-                    if hoisted is None:
-                        Q = dec.project_q(P, pf, 1, n1 - n0)
-                    x, fold_d = dec.attend(P, Q, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf, n1 - n0, shared_q=True,
-                                           bf16_stream=BF16_DECODER_STREAM, want_fold=True)
+                    x, fold_d = self.decoder_block(P, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf,
+                                                   None if hoisted is None else Q)
                 if cap is not None and n0 == 0 and n1 == N:
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
                 if fold_d is not None:
@@ -521,7 +535,7 @@ class Motion_Latent_Model(nn.Module):
         if cap is not None and "decoder_out_t0" in cap:
             cap["decoder_out_t0"] = torch.stack(cap["decoder_out_t0"], dim=0)
 
-        if shard is not None and shard[1] > 1:
+        if shard is not None and parallel.collectives_on(shard[1]):
             rank, world, group = shard
             frames = parallel.counts(T_full, world)
             buf = torch.zeros((max(frames), B, N, 3), dtype=torch.float32, device=dev)

@@ -33,7 +33,9 @@ _KEYS = ("ref_shape_pcd", "ref_shape_normals", "ref_shape_rgbs", "ref_pcd", "ref
 
 class GraphedForward:
     def __init__(self, model: torch.nn.Module, warmup: int = 2, weak: bool = False, max_graphs: int = 0,
-                 capture_error_mode: str = "global"):
+                 capture_error_mode: str = "global", forward=None):
+        # forward: the callable captured instead of model(sample) -- e.g. model.forward_frame_parallel (its RCCL collectives
+        # are captured with it: torch's NCCL process group is capture-aware)
         # max_graphs > 0: keep at most that many captured shape sets, dropping the least recently used (each graph owns a
         # private memory pool with a clip's activations and its static inputs).  capture_error_mode: torch.cuda.graph's
         # -- "thread_local" lets other threads (a DataLoader's pin-memory thread, another stream's allocation) keep
@@ -44,6 +46,7 @@ class GraphedForward:
         self._model = weakref.ref(model) if weak else (lambda: model)
         self.warmup = warmup
         self.max_graphs = max_graphs
+        self._forward = forward
         self.capture_error_mode = capture_error_mode
         self._graphs: Dict[Tuple, tuple] = {}               # insertion order = recency (re-inserted on every use)
 
@@ -70,6 +73,7 @@ class GraphedForward:
             raise RuntimeError("GraphedForward is an inference helper: call model.eval() first")
         key = self._key(sample)
         entry = self._graphs.get(key)
+        run = self._forward if self._forward is not None else self.model
         if entry is None:
             for stale in [k for k in self._graphs if k[:2] != key[:2]]:   # graphs that point at dropped weight copies
                 del self._graphs[stale]
@@ -84,7 +88,7 @@ class GraphedForward:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(self.warmup):          # populates the Prepared cache and the allocator pools
-                        self.model(static_in)
+                        run(static_in)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
@@ -93,7 +97,7 @@ class GraphedForward:
                 gc.disable()                  # no collector run may free a stream / event / graph while the capture is open
                 try:
                     with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
-                        static_out = self.model(static_in)
+                        static_out = run(static_in)
                 finally:
                     if gc_was_on:
                         gc.enable()

@@ -237,7 +237,8 @@ def rowstats_finish(part: torch.Tensor, eps: float, rowstat: torch.Tensor) -> to
     if (two != 2 or part.dtype != torch.float32 or not part.is_contiguous() or rowstat.dtype != torch.float32
             or not rowstat.is_contiguous() or rowstat.numel() != 2 * M):
         raise L.M324Error("rowstats_finish: part [ncb, M, 2] and rowstat [M, 2] must be contiguous fp32")
-    L.check(L.load().m324_rowstats_finish(_p(part), ncb, M, eps, _p(rowstat), _stream()), "m324_rowstats_finish")
+    with span("hbm_pass", 0.0, 8.0 * (ncb + 1) * M, f"rowstats_finish_kernel | rows={M} blocks={ncb}" if _timing() else ""):
+        L.check(L.load().m324_rowstats_finish(_p(part), ncb, M, eps, _p(rowstat), _stream()), "m324_rowstats_finish")
     return rowstat
 
 
@@ -252,7 +253,8 @@ def rowstats(x: torch.Tensor, eps: float, rowstat: torch.Tensor, copy: Optional[
         if copy.dtype != torch.bfloat16 or copy.shape[0] < rows or copy.shape[1] != Cdim:
             raise L.M324Error("rowstats: copy must be bf16 [rows, C]")
         pc, ldc = _rows(copy, "copy")
-    L.check(L.load().m324_rowstats(px, ldx, rows, Cdim, eps, _p(rowstat), pc, ldc, _stream()), "m324_rowstats")
+    with span("hbm_pass", 0.0, rows * Cdim * (4.0 + (2.0 if copy is not None else 0.0)), f"rowstats_kernel | rows={rows} C={Cdim}" if _timing() else ""):
+        L.check(L.load().m324_rowstats(px, ldx, rows, Cdim, eps, _p(rowstat), pc, ldc, _stream()), "m324_rowstats")
     return rowstat
 
 
@@ -268,12 +270,15 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: 
     need = ((rows - 1) // gin * gout + (rows - 1) % gin + off + 1) if gin > 0 else rows
     if x.shape[0] < need or out.shape[0] < rows or out.shape[1] != Cdim:
         raise L.M324Error("layernorm: shape mismatch")
-    if x.dtype == torch.bfloat16:
-        L.check(L.load().m324_layernorm_in(px, BF16, ldx, _vec(w, Cdim, "w"), _vec(b, Cdim, "b"), eps, py, ldy, code_of(out.dtype),
-                                           rows, Cdim, gin, gout, off, _stream()), "m324_layernorm_in")
-        return out
-    L.check(L.load().m324_layernorm(px, ldx, _vec(w, Cdim, "w"), _vec(b, Cdim, "b"), eps, py, ldy, code_of(out.dtype),
-                                    rows, Cdim, gin, gout, off, _stream()), "m324_layernorm")
+    tag = (f"layernorm_kernel<{'unsigned short' if out.element_size() == 2 else 'float'}, {'unsigned short' if x.element_size() == 2 else 'float'}>"
+           f" | rows={rows} C={Cdim}") if _timing() else ""
+    with span("hbm_pass", 0.0, float(rows) * Cdim * (x.element_size() + out.element_size()), tag):
+        if x.dtype == torch.bfloat16:
+            L.check(L.load().m324_layernorm_in(px, BF16, ldx, _vec(w, Cdim, "w"), _vec(b, Cdim, "b"), eps, py, ldy, code_of(out.dtype),
+                                               rows, Cdim, gin, gout, off, _stream()), "m324_layernorm_in")
+        else:
+            L.check(L.load().m324_layernorm(px, ldx, _vec(w, Cdim, "w"), _vec(b, Cdim, "b"), eps, py, ldy, code_of(out.dtype),
+                                            rows, Cdim, gin, gout, off, _stream()), "m324_layernorm")
     return out
 
 

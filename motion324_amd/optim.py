@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import lib as L
-from . import ops
+from . import ops, parallel
 from .prepared import bump_generation
 
 
@@ -191,7 +191,7 @@ class FusedAdamW:
     def _launch_bucket(self, b: int) -> None:
         world = self._world()
         self._launched[b] = True
-        if world == 1:
+        if not parallel.collectives_on(world):
             return
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.flat_grad.device)
@@ -223,7 +223,7 @@ class FusedAdamW:
             if not self._launched[b]:
                 self._launch_bucket(b)
         world = self._world()
-        if world > 1 and self._works:
+        if self._works:
             comm = self._comm_stream
             with torch.cuda.stream(comm):
                 for work, chunk in self._works:

@@ -14,6 +14,16 @@ import torch
 import torch.distributed as dist
 
 
+# Run the collectives even in a process group of ONE rank (they are identities there).  The `-m gpu` tests set it to take
+# forward_frame_parallel / the bucketed gradient all-reduce / the window gather through torch.distributed's "nccl" backend
+# (= RCCL) on the single GPU of the test box: async work handles, side streams and record_stream as on a full node.
+ALWAYS_COLLECT = False
+
+
+def collectives_on(world: int) -> bool:
+    return world > 1 or (ALWAYS_COLLECT and dist.is_available() and dist.is_initialized())
+
+
 def world_info(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
@@ -49,7 +59,7 @@ def all_gather_items(local: torch.Tensor, n_items: int, group=None) -> torch.Ten
     """local: [n_local, ...] outputs of this rank's shard (partition order).  Returns [n_items, ...] on every
     rank.  Shards may be uneven: each rank pads to the largest shard, one all_gather moves everything."""
     rank, world = world_info(group)
-    if world == 1:
+    if not collectives_on(world):
         assert local.shape[0] == n_items
         return local
     cnt = counts(n_items, world)

@@ -1,0 +1,64 @@
+"""Every environment switch of the package in ONE table (name -> default, meaning), read once at import.
+
+The product path never needs any of them: defaults are what bench.py and the tests measure.  They exist for interleaved
+A/B measurements and for the parity tests that compare a fused path against its unfused form.  ``non_default()`` is what
+bench.py echoes into its JSON line, so that a number measured with a switch flipped says so.
+
+Host switches (Python; the module constants named below are initialised from here -- tests monkeypatch those constants):
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+# name: (default, module constant it initialises, meaning)
+HOST: Dict[str, Tuple[str, str, str]] = {
+    "M324_AUTO_GRAPH": ("1", "Pcd_motion.AUTO_GRAPH", "inference forward(): hipGraph replay from the third call with the same shapes on"),
+    "M324_FUSE_HEAD": ("1", "Pcd_motion.FUSE_HEAD_N3", "bf16 inference: head Linear + GELU + Linear(C -> 3) in one GEMM epilogue (M324_AUX_N3)"),
+    "M324_BF16_DECODER": ("1", "Pcd_motion.BF16_DECODER_STREAM", "bf16 inference: the decoder's two-addition residual stream in bf16 (0: fp32 like the trunk)"),
+    "M324_HOIST_Q": ("1", "Pcd_motion.HOIST_DECODER_Q", "graph capture: decoder point features + q projection on the shape-encoder branch"),
+    "M324_DECODE_ROWS": (str(1 << 17), "Pcd_motion.DECODE_ROWS", "max (frames x points) rows per decoder pass"),
+    "M324_OVERLAP": ("1", "Pcd_motion.OVERLAP_SHAPE_ENCODER", "inference: shape encoder on a second HIP stream under the image encoder"),
+    "M324_FOLD_LN": ("1", "transformer.FOLD_LN", "LayerNorm fold: 0 off, 1 bf16 streams (decoder), 2 every stream (trunk, DINO too)"),
+    "M324_FUSE_QKV": ("1", "transformer.FUSE_QKV", "bf16 inference: q|k|v projection epilogue writes head-major Q / K / V (RMSNorm, pre-scale)"),
+    "M324_FUSE_QKV_VT": ("1", "transformer.FUSE_QKV_VT", "the same for long sequences: the epilogue writes the transposed, key-permuted V"),
+    "M324_PRECISION": ("", "prepared.compute_dtype()", "force bf16 / fp32 (default: follow torch.autocast like the reference)"),
+    "M324_LIB": ("", "lib.LIB_PATH", "path of an alternative libm324.so (lab builds)"),
+}
+# Library switches (C++; read by libm324 once, when it is loaded -- csrc/runtime.hip; m324_set_tunable overrides them)
+LIBRARY: Dict[str, Tuple[str, str]] = {
+    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v7 | v9 | v10 | v11 | v12 | v13); 0 = chooser"),
+    "M324_GEMM_TN": ("0", "128: force the 128 x 128 weight-gradient kernel"),
+    "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges, bit 1 4 x 2 group order for wide weights, bit 2 force it"),
+    "M324_ATTN_NW": ("0", "attention forward: waves per workgroup (4 | 8); 0 = by sequence length"),
+    "M324_ATTN_FLAT": ("1", "global attention on a flat XCD-aware grid"),
+    "M324_ATTN_OCC": ("0", "attention: occupancy hint"),
+    "M324_ATTN_NQ2": ("0", "attention: 64 queries per wave"),
+    "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup"),
+    "M324_ATTN_EXP": ("0", "attention: static priority for the younger half of an 8-wave workgroup"),
+}
+
+
+def get(name: str) -> str:
+    return os.environ.get(name, HOST[name][0])
+
+
+def flag(name: str) -> bool:
+    return get(name) != "0"
+
+
+def non_default() -> Dict[str, str]:
+    """{switch: value} for every switch whose environment value differs from its default (host and library)."""
+    out = {}
+    for name, spec in list(HOST.items()) + list(LIBRARY.items()):
+        v = os.environ.get(name)
+        if v is not None and v.lstrip("vV") != spec[0] and v != spec[0]:
+            out[name] = v
+    return out
+
+
+def table() -> str:
+    rows = ["| switch | default | meaning |", "|---|---|---|"]
+    rows += [f"| `{n}` | {d or '(unset)'} | {doc} (`{const}`) |" for n, (d, const, doc) in HOST.items()]
+    rows += [f"| `{n}` | {d} | libm324: {doc} |" for n, (d, doc) in LIBRARY.items()]
+    return "\n".join(rows)

@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, switches
 from .lib import ACT_GELU
 from .prepared import Prepared
 
@@ -97,9 +97,15 @@ class QK_Norm_CrossAttention(_AttnBase):
 
 # LayerNorm fold (bf16 inference, include/m324.h): the GEMM that writes a residual stream leaves the row statistics of
 # what it stored (and, next to an fp32 stream, its bf16 twin); the GEMM behind the LayerNorm reads that twin with the
-# LayerNorm's scale folded into its weight and applies mean / rstd in its epilogue.  The LayerNorm pass itself -- 6 bytes
-# per element of pure HBM traffic, 85 launches per clip -- disappears.  M324_FOLD_LN=0 restores the separate passes.
-FOLD_LN = os.environ.get("M324_FOLD_LN", "1") != "0"
+# LayerNorm's scale folded into its weight and applies mean / rstd in its epilogue; the LayerNorm pass itself disappears.
+# Measured on the c2 clip (round 3, interleaved A/B, profiles/r03_ln_fold_ab.md):
+#   * bf16 streams (the decoder: 65 536 rows, 8-wave GEMMs, no twin to write): two 46-us passes go for +2.5 us (fc2's
+#     statistics), +4.5 us (fc1's epilogue) and two 4-us merges: decoder block 0.903 -> 0.874 ms.  ON by default.
+#   * fp32 streams (trunk, DINO: 10 368 / 8 224 rows): a 9.6-us pass goes for +4 us in the producer (statistics on a
+#     one-wave-per-SIMD kernel, 50 % more store bytes for the twin), +2 us in the consumer and a 2.5-us merge + its launch
+#     boundary: break-even within +-0.5 % of the clip.  OFF by default; M324_FOLD_LN=2 folds them too (tests do).
+# M324_FOLD_LN=0 restores every separate pass.
+FOLD_LN = int(switches.get("M324_FOLD_LN"))
 
 
 class LNFold:
@@ -117,9 +123,10 @@ class LNFold:
         self.own_copy = x.dtype != torch.bfloat16
 
     @staticmethod
-    def usable(P: Prepared, rows: int, C: int) -> bool:
-        return (FOLD_LN and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64 and C % 64 == 0
-                and not torch.is_grad_enabled())
+    def usable(P: Prepared, rows: int, C: int, bf16_stream: bool = False) -> bool:
+        """bf16_stream: the stream itself is bf16 (level 1 of M324_FOLD_LN folds only those; level 2 every stream)."""
+        return (FOLD_LN >= (1 if bf16_stream else 2) and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64
+                and C % 64 == 0 and not torch.is_grad_enabled())
 
     def from_stream(self, x: torch.Tensor, eps: float) -> "LNFold":
         """Head of a chain: statistics (and the bf16 twin) straight from the fp32 stream."""
@@ -161,8 +168,8 @@ def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor, f
 # Fused q|k|v projection epilogue (m324_gemm M324_AUX_QKV_HEADS + row-major-V attention) for bf16 inference on sequences
 # below 2048 tokens; longer ones keep m324_qkv_split's transposed V, whose 8-wave attention kernel is 9 % faster than
 # its transposing-read variant.  M324_FUSE_QKV=0 disables (A/B measurements).
-FUSE_QKV = os.environ.get("M324_FUSE_QKV", "1") != "0"
-FUSE_QKV_VT = os.environ.get("M324_FUSE_QKV_VT", "1") != "0"     # long sequences: the epilogue writes the transposed V itself
+FUSE_QKV = switches.flag("M324_FUSE_QKV")
+FUSE_QKV_VT = switches.flag("M324_FUSE_QKV_VT")     # long sequences: the epilogue writes the transposed V itself
 
 
 _FUSE_OFF = 0
@@ -313,7 +320,7 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         ops.attention(Q, K, Vt, o, shared_q=shared_q, prescaled=True)
         xdt = torch.bfloat16 if (bf16_stream and P.dtype == torch.bfloat16 and not torch.is_grad_enabled()) else torch.float32
         x = torch.empty((B * Lq, a.dim), dtype=xdt, device=Q.device)
-        fold = LNFold(x) if LNFold.usable(P, B * Lq, a.dim) else None
+        fold = LNFold(x) if LNFold.usable(P, B * Lq, a.dim, bf16_stream=xdt == torch.bfloat16) else None
         ops.gemm(o, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=residual, res_rows=res_rows,
                  **(fold.producer() if fold is not None else {}))
         _mlp_residual(P, self.norm2, self.mlp, x, fold, feed_next=want_fold)

@@ -244,6 +244,103 @@ def test_bucketed_overlapped_allreduce_equals_single_process():
     assert all(torch.equal(a[n], b[n]) for n in a)                       # replicas stay bit-identical after the step
 
 
+# ------------------------------------------------------------------------------------------------------ RCCL, one rank
+def _rccl_worker(rank, port, ret):
+    """torch.distributed backend "nccl" (= RCCL) on the one GPU of this box.  parallel.ALWAYS_COLLECT makes every
+    collective of the multi-GPU paths run in the 1-rank group (identities), so the calls the driver's 8-GPU runs make --
+    all_gather_into_tensor(async_op=True) + work.wait() on a side stream + record_stream, bucketed all_reduce(async_op)
+    launched during the backward, all_gather of the window outputs -- go through RCCL streams here, which gloo never does."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import motion324_amd as m
+        from motion324_amd import inference, parallel, synth, training
+        from motion324_amd.optim import FusedAdamW, backward_completion_order
+        res = {}
+        one = torch.ones(4, device="cuda")
+        dist.all_reduce(one)
+        res["backend"] = dist.get_backend()
+        res["allreduce_ok"] = bool((one == 1).all())
+        # (1) frame-parallel forward: K/V all-gather per global block + final gather, both precisions
+        model, dm = build("tiny")
+        sample = inputs("tiny", with_target=True)
+        for prec in ("fp32", "bf16"):
+            m.set_precision(prec)
+            with torch.no_grad():
+                parallel.ALWAYS_COLLECT = False
+                ref = model.forward_frame_parallel(sample)                 # no collective: plain forward
+                parallel.ALWAYS_COLLECT = True
+                got = model.forward_frame_parallel(sample)
+            torch.cuda.synchronize()
+            # the collective path splits q and k|v (m324_qkv_split instead of the fused epilogue): bf16 rounding apart
+            res[f"fp_{prec}"] = (rel_err(got.pcd_moved, ref.pcd_moved), abs(float(got.loss_metrics.loss) - float(ref.loss_metrics.loss)))
+        m.set_precision(None)
+        # (2) the sliding-window driver: windows gathered with all_gather over RCCL
+        cfg = dict(training=dict(frames=dm.frames, use_amp=True))
+        s = synth.synth_inputs(1, 7, 33, 70, 64, seed=6)
+        video = torch.from_numpy(s["rgb_video"][0]).cuda()
+        data = {k: torch.from_numpy(v).cuda() for k, v in s.items() if k != "rgb_video"}
+        parallel.ALWAYS_COLLECT = False
+        a = inference.run_model_inference(model, data, video, cfg, "cuda")
+        parallel.ALWAYS_COLLECT = True
+        b = inference.run_model_inference(model, data, video, cfg, "cuda")
+        torch.cuda.synchronize()
+        res["windows_equal"] = bool(torch.equal(a, b)) and tuple(b.shape) == (1, 7, 33, 3)
+        # (3) training step: gradients written into the flat buffer, buckets all-reduced on the side stream during the backward
+        def train(always):
+            parallel.ALWAYS_COLLECT = always
+            tm, _ = build("tiny")
+            tm.train()
+            sn = synth.synth_inputs(2, 3, 30, 80, 64, seed=4, with_target=True)
+            smp = {k: torch.from_numpy(v).cuda() for k, v in sn.items()}
+            opt = FusedAdamW(tm.named_parameters(), lr=1e-3, allowed_gradnorm_factor=1e9, order=backward_completion_order(tm),
+                             bucket_mb=0.5)
+            compute = torch.cuda.current_stream().cuda_stream
+            m.set_precision("bf16")
+            try:
+                for _ in range(2):
+                    loss, _, G = training.forward_backward(tm, smp, sink=opt)
+                    early = len(opt.launch_log)
+                    side = all(sid != compute for _, sid in opt.launch_log)
+                    opt.finish_reduce()
+                    info = opt.step()
+                torch.cuda.synchronize()
+            finally:
+                m.set_precision(None)
+            return ({n: p.detach().cpu() for n, p in tm.named_parameters() if p.requires_grad}, float(loss), info["grad_norm"],
+                    early, len(opt.buckets), side)
+        pa, la, na, _, _, _ = train(False)
+        pb, lb, nb, early, nbuckets, side = train(True)
+        res["train_equal"] = all(torch.equal(pa[n], pb[n]) for n in pa) and la == lb and na == nb
+        res["buckets"] = (early, nbuckets, side)
+        ret[0] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multi_gpu_paths_over_rccl_with_one_rank():
+    """The collectives of forward_frame_parallel, run_model_inference and the bucketed gradient all-reduce through
+    torch.distributed "nccl" (RCCL) in a 1-rank group on this box's GPU (gloo never touches
+    all_gather_into_tensor(async_op) + record_stream on RCCL streams).  Values must equal the collective-free runs."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 27000 + (os.getpid() * 3) % 4000
+    mp.spawn(_rccl_worker, args=(port, ret), nprocs=1, join=True)
+    r = ret[0]
+    print(r)
+    assert r["backend"] == "nccl" and r["allreduce_ok"]
+    assert r["fp_fp32"][0] < 5e-6 and r["fp_fp32"][1] < 1e-6
+    assert r["fp_bf16"][0] < BF16_TOL
+    assert r["windows_equal"]
+    assert r["train_equal"]
+    early, nbuckets, side = r["buckets"]
+    assert nbuckets >= 3 and early >= nbuckets - 1 and side
+
+
 def test_torch_ddp_wrapper_runs_the_reference_sequence():
     """`DistributedDataParallel(model)` exactly as train.py:88-89 builds it (find_unused_parameters=False: every
     trainable parameter must receive a gradient in every step), 2 ranks x batch 1: the reducer-averaged .grad equals
