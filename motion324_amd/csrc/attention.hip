@@ -204,11 +204,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-#ifdef M324_ATTN_OLDADDR      // tools/ A/B builds only
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
-#else
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kb * 4096 + (kos ^ (ks << 5)));
-#endif
 #pragma unroll
                 for (int n = 0; n < NQ; ++n)
                     s[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[n][ks], s[n][kb], 0, 0, 0);
@@ -303,11 +299,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
                     const a_s16x8_t v8 = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
                     vf = __builtin_bit_cast(bf16x8, v8);
                 } else {
-#ifdef M324_ATTN_OLDADDR
-                    vf = *reinterpret_cast<const bf16x8*>(sv + k_off(db * 32 + l31, 2 * j + hi));
-#else
                     vf = *reinterpret_cast<const bf16x8*>(smem + 8192 + db * 4096 + (kos ^ (j << 5)));
-#endif
                 }
 #pragma unroll
                 for (int n = 0; n < NQ; ++n)
@@ -753,8 +745,15 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
         dim3 g2(ceil_div(Lq, nq2 ? 2 * QB : (w8 ? 2 * QB : QB)), H, B);
         // XCD-aware flat grid for the 8-wave kernel (M324_ATTN_FLAT=0 keeps the 3-D grid: A/B runs)
+        // The same flat order for the short sequences with several query tiles per (batch, head) -- the per-frame blocks:
+        // 324 / 257 tokens = 3 tiles of 128 queries that walk the SAME K / V.  On the 3-D grid they are consecutive
+        // workgroup ids, i.e. they land on three different XCDs and each pulls the head's K / V through its own L2
+        // (round 2 counters: 111.8 MB moved for 55.8 MB algorithmic); on the flat grid they are neighbours in ONE XCD's
+        // list.  M324_ATTN_FLAT=2 restricts the flat grid to the 8-wave kernel again (A/B runs).
         int nqt = 0;
-        if (w8 && m324::tunable(m324::TUN_ATTN_FLAT) != 0) {
+        const int flat = m324::tunable(m324::TUN_ATTN_FLAT);
+        const bool one_tile = q_prescaled && !w8 && !nq2 && !vrow && Lk <= KV;
+        if (flat != 0 && (w8 || (flat != 2 && !nq2 && !one_tile && g2.x > 1 && (long)g2.x * H * B >= 512))) {
             nqt = (int)g2.x;
             g2 = dim3(g2.x * H * B, 1, 1);
         }
@@ -804,7 +803,9 @@ extern "C" int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int 
     const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
     const long gx = ceil_div(Lq, (nq2 || w8) ? 2 * QB : QB);
     const int nwv = w8 ? 8 : 4;
-    if (w8 && m324::tunable(m324::TUN_ATTN_FLAT) != 0)
+    const int flat = m324::tunable(m324::TUN_ATTN_FLAT);
+    const bool one_tile = ps && !w8 && !nq2 && !vrow && Lk <= KV;
+    if (flat != 0 && (w8 || (flat != 2 && !nq2 && !one_tile && gx > 1 && gx * H * B >= 512)))
         snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s, 3> grid=%ldx1x1", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
                  vrow ? "true" : "false", gx * H * B * nwv * 64);
     else if (ps && !vrow && !w8 && !nq2 && Lk <= KV && m324::tunable(m324::TUN_ATTN_OCC) != 1)

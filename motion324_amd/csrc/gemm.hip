@@ -277,136 +277,8 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
 
 
 // ------------------------------------------------------------------------------------------------
-// 64-byte-row half-tile image shared by the pipelined kernel: one 32 KiB LDS slot = A[256][32] + W[256][32] (bf16),
-// 16-byte chunks swizzled c ^ ((row >> 2) & 3) (applied to the LDS-DMA source address and to the fragment reads).
-constexpr int ROWB6 = 64;                        // bytes of K per LDS row in a half-tile
-constexpr int PART6 = 256 * ROWB6;               // 16 KiB: one operand's half-tile
-constexpr int SLOT6 = 2 * PART6;                 // 32 KiB
-__device__ __forceinline__ int lds_off6(int row, int chunk) { return row * ROWB6 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-
-// ------------------------------------------------------------------------------------------------
-// v7: software-pipelined 256 x 256 kernel (bf16), 8 waves as 2 (M) x 4 (N), each wave a 128 x 64 block = 4 x 2
-// accumulators.  K is streamed in half-tiles of 32 through a 4-slot ring (128 KiB, one workgroup per CU) with ONE
-// barrier per half-tile, and the overlap is done inside each wave: while the 8 MFMAs of a k-step run, the 6 fragment
-// reads of the next k-step and the wave's LDS-DMA pieces of half-tile h+3 are issued between them (pinned with
-// sched_group_barrier), so the matrix pipe is fed without relying on the SIMD partner's phase.
-//   barrier h (top of iteration h): every wave's pieces of half-tile h+1 have landed (counted vmcnt: only the 4 pieces
-//   of h+2 may still fly) and every wave has finished reading half-tile h-1, whose slot now receives half-tile h+3.
-//   Fragments of (h+1, k-step 0) are fetched during (h, k-step 1), i.e. before barrier h+1: MFMAs restart immediately.
-//   The steady state is branch-free: past the end of K the last half-tile is fetched again into a free slot (an L2
-//   hit nobody reads), so the wait is always vmcnt(4); all pieces are drained before the ring becomes epilogue scratch.
-// Measured (tools/gemm_lab, 4096^3): MFMA-only loop 1825 TF/s, + fragment reads 1490, + LDS-DMA issue 1316, all 1190.
-template <typename TOUT, int ACT, int RES>
-__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
-                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
-                                                           int xcd_remap) {
-    constexpr int RING = 4, PPW = 4;             // ring slots; LDS-DMA pieces per wave per half-tile (2 of A, 2 of W)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * SLOT6];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, (M + BM5 - 1) / BM5, ntn, xcd_remap, tm, tn);
-    const int m0 = tm * BM5, n0 = tn * BN5;
-
-    // LDS-DMA: a wave-instruction fills 16 rows x 64 B; wave w moves row groups 2w, 2w+1 of A and of W
-    const bf16_t* ga[2];
-    const bf16_t* gb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 16 + (lane >> 2);
-        const int c = ((lane & 3) ^ ((r >> 2) & 3)) * 8;
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
-    }
-    auto issue_a = [&](int h, int slot) {
-        unsigned char* sa = smem + slot * SLOT6 + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)h * 32), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
-    };
-    auto issue_b = [&](int h, int slot) {
-        unsigned char* sb = smem + slot * SLOT6 + PART6 + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)h * 32), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int NH = K / 32;
-    const int aoff = lds_off6(wm * 128 + l31, hi), boff = PART6 + lds_off6(wn * 64 + l31, hi);
-    bf16x8 fa[2][4], fb[2][2];
-    auto load_frags = [&](int set, int slot, int ks) {
-        const unsigned char* base = smem + slot * SLOT6;
-        const int x = ks << 5;          // k-step 1 = chunk + 2 = byte offset ^ 32 (the swizzle only touches bits 4-5)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(base + ((boff + j * 2048) ^ x));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(base + ((aoff + i * 2048) ^ x));
-    };
-    auto mma8 = [&](int set) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
-    };
-    // k-step schedule (sched_group_barrier: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read): the 6 fragment reads of the next
-    // k-step ride on the first 6 MFMAs (landed when that k-step starts), the 2 LDS-DMA pieces on the last two.  LDS-DMA
-    // instructions also match the DS mask: they come after the reads in program order, so the DS groups take the reads.
-#define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-    auto sched_kstep = [&]() {
-        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
-        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
-        M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
-        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
-    };
-#define M324_WAIT_PIECES(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-
-    const LnPre* const ln_pre_ptr = nullptr;
-    for (int h = 0; h < RING - 1; ++h) {
-        issue_a(h < NH ? h : NH - 1, h);
-        issue_b(h < NH ? h : NH - 1, h);
-    }
-    M324_WAIT_PIECES(2 * PPW);                   // half-tile 0 landed
-    M324_BARRIER();
-    load_frags(0, 0, 0);
-    int slot = 0;                                // h % RING
-    for (int h = 0; h < NH; ++h) {
-        const int nslot = (slot + 1) & 3, fslot = (slot + 3) & 3;
-        const int hn = h + 3 < NH ? h + 3 : NH - 1;
-        M324_WAIT_PIECES(PPW);                   // half-tile h+1 landed (this wave's pieces)
-        M324_BARRIER();
-        load_frags(1, slot, 1);
-        issue_a(hn, fslot);
-        mma8(0);
-        sched_kstep();
-        load_frags(0, nslot, 0);                 // past the end: stale but valid LDS, never used
-        issue_b(hn, fslot);
-        mma8(1);
-        sched_kstep();
-        slot = nslot;
-    }
-    M324_WAIT_PIECES(0);                         // no LDS-DMA may outlive the main loop: the ring becomes scratch
-#undef M324_WAIT_PIECES
-#undef M324_SG
-    M324_BARRIER();
-    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 128,
-                                      n0 + wn * 64, lane, ep, ln_pre_ptr);
-}
-
-// ------------------------------------------------------------------------------------------------
-// v10: the v7 pipeline on whole cache lines.  tools/dma_lab: an LDS-DMA piece that covers 16 rows x 64 B (v7's half-tile
-// rows) costs the texture path 41 cycles per KiB, one that covers 8 rows x 128 B 29-33 -- with 64-byte rows the loads
+// v10: the chunk ring.  A predecessor (v7, retired) streamed K in half-tiles of 32; tools/dma_lab: an LDS-DMA piece that
+// covers 16 rows x 64 B (such half-tile rows) costs the texture path 41 cycles per KiB, one that covers 8 rows x 128 B 29-33 -- with 64-byte rows the loads
 // alone cap a 256 x 256-tile GEMM at ~1700 TF/s, next to an MFMA-only ceiling of 1825.  Here an LDS row holds K = 64
 // (128 B, v2/v5's swizzle) and the 160 KiB of LDS are a ring of FIVE 32-KiB chunks, a chunk being one operand's
 // 256 rows x 64 k of one K-stage: chunk 2s = A of stage s, 2s+1 = W of stage s, chunk q at ring position q % 5, so
@@ -484,25 +356,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
     };
 #define M324_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-#ifndef M324_V10_SCHED
-#define M324_V10_SCHED 0
-#endif
     auto sched_kstep = [&]() {
-#if M324_V10_SCHED == 0
         M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
         M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
         M324_SG(0x008, 1); M324_SG(0x100, 1); M324_SG(0x008, 1); M324_SG(0x100, 1);
         M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
-#elif M324_V10_SCHED == 1
-        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x100, 2);
-        M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 1);
-        M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 3);
-#elif M324_V10_SCHED == 2
-        M324_SG(0x100, 6); M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 4);
-#elif M324_V10_SCHED == 3
-        M324_SG(0x008, 1); M324_SG(0x100, 3); M324_SG(0x008, 1); M324_SG(0x100, 3);
-        M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 2); M324_SG(0x020, 1); M324_SG(0x008, 2);
-#endif
     };
 
     LnPre ln_pre;
@@ -1030,32 +888,34 @@ static int xcd_mode(const m324_gemm_args* a) {
     return 1;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v5|v7|v9|v10|v11|v12|v13 forces a variant (A/B measurements, tests).
+// Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13 forces a variant (A/B measurements, tests).  (v7, the half-tile ring
+// the chunk-ring kernels replaced, was retired in round 3: no shape reaches it -- K is a multiple of 64 for bf16 -- and its
+// A/B tables are kept in profiles/r01_ab_gemm_schedules.md.)
 static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_GEMM at load / m324_set_tunable
 
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
     int f = forced_variant();
-    if ((f == 1 || f == 5 || f == 7 || f == 9) && (a->ln_rowstat || a->ln_stats_out || a->ln_copy_out))
+    if (f == 7) f = 0;                           // retired schedule: the chooser decides
+    if ((f == 1 || f == 5 || f == 9) && (a->ln_rowstat || a->ln_stats_out || a->ln_copy_out))
         f = 0;                                   // the LayerNorm fold is built into v2 / v10 / v11 / v12 / v13 only
     const bool bf16 = a->in_dtype == M324_BF16;
     const bool ring_ok = bf16 && a->K % 64 == 0 && a->K >= 128;      // v10 / v11: K-stages of 64, at least two
     if (f == 1 || f == 2 || f == 5) return f;
-    if (f == 7) return bf16 ? 7 : 5;
-    if (f >= 10 && f <= 13) return ring_ok ? f : (bf16 ? (f == 13 ? 2 : 7) : (f == 13 ? 2 : 5));
+    if (f >= 10 && f <= 13) return ring_ok ? f : (f == 13 ? 2 : 5);
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
     // CU) balance better.  Measured on the c2 shapes (tools/gemm_lab): the chunk-ring kernels win at >= 0.75 fill, v2
     // below; of the two, the 4-wave persistent v11 wins when the output is fp32 (residual epilogues: little VALU work,
     // 1.5x the LDS fragment traffic saved), the 8-wave v10 when it is bf16 (GELU / q|k|v epilogues want two waves per
-    // SIMD).  K that is not a multiple of 64 falls back to the half-tile ring of v7.
+    // SIMD).  K = 64 (a single K-stage) runs on the two-stage 256 x 256 kernel v5.
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
     if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) {
         if (!bf16) return 5;
         if (ring_ok) return a->out_dtype == M324_F32 ? 11 : 10;
-        return a->K >= 96 ? 7 : 5;
+        return 5;
     }
     // narrow outputs with a long contraction (the MLP's fc2 at N = 768, K = 3072): 256 x 128 tiles fill the chip in one
     // round where 256 x 256 tiles cannot, with 3/4 of the 128 x 128 tiles' texture-path traffic (v12: 58 -> 51 us at
@@ -1085,10 +945,7 @@ static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& e
                            ceil_div(a->N, BN5), xcd_mode(a));
         return M324_OK;
     }
-    hipLaunchKernelGGL((gemm_pipe_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
-                       (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
-                       ceil_div(a->N, BN5), xcd_mode(a));
-    return M324_OK;
+    M324_FAIL(M324_ERR_UNSUPPORTED, "m324_gemm: no pipelined kernel for schedule %d", variant);
 }
 
 template <typename TIN, typename TOUT>
@@ -1136,7 +993,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                         : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
 #define M324_GLDS(ACT, RES)                                                                                              \
     do {                                                                                                                 \
-        if (variant == 7 || variant >= 10) {                                                                             \
+        if (variant >= 10) {                                                                             \
             const int rc_ = launch_pipe<TOUT, ACT, RES>(a, s, ep, variant);                                              \
             if (rc_ != M324_OK) return rc_;                                                                              \
         }                                                                                                                \
@@ -1237,7 +1094,6 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
         case 1: wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
         case 2: name = "gemm_glds_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
         case 5: name = "gemm_glds5_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
-        case 7: name = "gemm_pipe_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
         case 9: name = "gemm_skinny_kernel"; wg = ceil_div(a->N, 32); threads = 512; break;
         case 10: name = "gemm_ring_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
         case 11: name = "gemm_ring4_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;

@@ -27,11 +27,11 @@ HOST: Dict[str, Tuple[str, str, str]] = {
 }
 # Library switches (C++; read by libm324 once, when it is loaded -- csrc/runtime.hip; m324_set_tunable overrides them)
 LIBRARY: Dict[str, Tuple[str, str]] = {
-    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v7 | v9 | v10 | v11 | v12 | v13); 0 = chooser"),
+    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13); 0 = chooser"),
     "M324_GEMM_TN": ("0", "128: force the 128 x 128 weight-gradient kernel"),
     "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges, bit 1 4 x 2 group order for wide weights, bit 2 force it"),
     "M324_ATTN_NW": ("0", "attention forward: waves per workgroup (4 | 8); 0 = by sequence length"),
-    "M324_ATTN_FLAT": ("1", "global attention on a flat XCD-aware grid"),
+    "M324_ATTN_FLAT": ("1", "XCD-aware flat grid: 1 = global and per-frame attention, 2 = the 8-wave global attention only, 0 = 3-D grid"),
     "M324_ATTN_OCC": ("0", "attention: occupancy hint"),
     "M324_ATTN_NQ2": ("0", "attention: 64 queries per wave"),
     "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup"),

@@ -62,9 +62,14 @@ class _AttnBase(nn.Module):
             raise NotImplementedError("libm324 attention kernels are specialised for head_dim 64 (config d_head)")
         assert dim % head_dim == 0, f"Token dimension {dim} should be divisible by head dimension {head_dim}"
         self.dim, self.head_dim, self.num_heads, self.use_qk_norm = dim, head_dim, dim // head_dim, use_qk_norm
-        if use_qk_norm:
-            self.q_norm = RMSNorm(head_dim)
-            self.k_norm = RMSNorm(head_dim)
+
+    def _register_qk_norm(self):
+        """Called LAST by the subclasses: the reference registers q_norm / k_norm after its Linear layers
+        (transformer.py:112-122,182-190), and named_parameters() order is what numbers the optimizer state
+        (utils/training_utils.py:38-52) -- checkpoints are exchanged by that number."""
+        if self.use_qk_norm:
+            self.q_norm = RMSNorm(self.head_dim)
+            self.k_norm = RMSNorm(self.head_dim)
 
     def _qk_w(self, P: Prepared):
         if not self.use_qk_norm:
@@ -79,6 +84,7 @@ class QK_Norm_SelfAttention(_AttnBase):
             raise NotImplementedError("attention / projection dropout is 0 everywhere in the reference model")
         self.to_qkv = nn.Linear(dim, 3 * dim, bias=qkv_bias)
         self.fc = nn.Linear(dim, dim, bias=fc_bias)
+        self._register_qk_norm()
 
 
 class QK_Norm_CrossAttention(_AttnBase):
@@ -93,6 +99,7 @@ class QK_Norm_CrossAttention(_AttnBase):
         self.to_k = nn.Linear(kv_dim, dim, bias=qkv_bias)
         self.to_v = nn.Linear(kv_dim, dim, bias=qkv_bias)
         self.fc = nn.Linear(dim, dim, bias=fc_bias)
+        self._register_qk_norm()
 
 
 # LayerNorm fold (bf16 inference, include/m324.h): the GEMM that writes a residual stream leaves the row statistics of

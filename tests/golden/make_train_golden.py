@@ -100,8 +100,11 @@ def run_case(name):
     names = list(optimized.keys())
     assert all(k in optimized for k in SLICE_KEYS), [k for k in SLICE_KEYS if k not in optimized]
     sample = oracle.to_torch(synth.synth_inputs(B, T, N, S, HW, seed=spec["seed"], with_target=True))
+    name_of = {id(p): n for n, p in optimized.items()}
+    numbering = [name_of[id(p)] for g in optimizer.param_groups for p in g["params"]]     # state-dict index -> parameter
     save = {"meta_shape": np.array([B, T, N, S, HW], dtype=np.int64), "slice_n": np.int64(SLICE_N),
-            "param_order": np.array(names)}                  # create_optimizer's numbering: decay group first
+            "param_order": np.array(numbering),              # the optimizer's own numbering: decay group first
+            "named_parameters_order": np.array(names)}
     losses, norms, lrs = [], [], []
     t0 = time.time()
     for step in range(max(1, spec["steps"])):

@@ -201,3 +201,22 @@ def test_cosine_schedule_matches_the_reference_scheduler():
     assert got[0] == 0.0 and got[5] == 4e-4 and got[30] < 1e-18 and got[33] > got[31] > 0.0
     # the run the goldens' three steps used
     assert np.allclose([cosine_with_warmup(i, 1, 10, 1e-3) for i in range(3)], gold["lr"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("case,golden", [("tiny", "train_tiny"), ("c1", "train_c3_b1")])
+def test_parameter_order_is_the_references(case, golden):
+    """named_parameters() order of the trainable tensors == the reference model's (recorded by make_train_golden.py from
+    the imported reference): it numbers the optimizer state that checkpoints exchange (utils/training_utils.py:38-52), and
+    FusedAdamW.ckpt_names (decay group first) == the reference optimizer's own numbering."""
+    import numpy as np
+    from conftest import CASES, GOLDEN
+    import motion324_amd as m
+    gold = np.load(os.path.join(GOLDEN, golden + ".npz"))
+    dm = synth.Dims(**CASES[case]["dims"])
+    cfg = synth.make_config(frames=dm.frames, d=dm.d, d_head=dm.d_head, tokens=dm.tokens, pcd_layers=dm.pcd_layers, n_layer=dm.n_layer)
+    cfg["model"]["dino"] = {"depth": dm.dino_depth}
+    model = m.Motion_Latent_Model(cfg)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    assert [n for n, _ in named] == [str(x) for x in gold["named_parameters_order"]]
+    decay_first = [n for n, p in named if p.dim() > 1] + [n for n, p in named if p.dim() <= 1]
+    assert decay_first == [str(x) for x in gold["param_order"]]

@@ -97,7 +97,7 @@ def test_gemm_inplace_residual(dtype):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
-@pytest.mark.parametrize("variant", ["v0", "v1", "v2", "v7", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("variant", ["v0", "v1", "v2", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("M,N", [(3 * 256, 768), (2 * 230, 328), (40, 192)])
 def test_gemm_bf16_residual_stream(tune, variant, M, N):
     """The decoder's bf16 residual stream (bf16 inference): (1) bf16 output + fp32 residual broadcast over row groups (the
@@ -167,13 +167,13 @@ def test_layernorm_bf16_input(rows, C, with_bias):
         ops.layernorm(x.to(torch.bfloat16).to(DEV), w.to(DEV), None, 1e-5, torch.empty((rows, C), dtype=torch.float32, device=DEV))
 
 
-@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v7", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("K", [64, 192, 832])
 def test_gemm_every_schedule_forced(tune, variant, dtype, K):
     """M324_GEMM=vN (set through m324_set_tunable here) forces one kernel schedule; each must handle ragged M / N tiles, a K shorter than
-    its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v7 / v10 / v11 / v12 to v5, v13 to v2;
-    the chunk-ring kernels v10 - v13 need two K-stages of 64 and hand K = 64 to v7.)"""
+    its prefetch depth, and the whole epilogue chain, with bf16 and fp32 outputs.  (fp32 operands map v10 / v11 / v12 to v5, v13 to v2;
+    the chunk-ring kernels v10 - v13 need two K-stages of 64 and hand K = 64 to v5 / v2.)"""
     ops = _ops()
     from motion324_amd.lib import ACT_GELU
     tune("M324_GEMM", variant)
@@ -234,7 +234,7 @@ def test_gemm_chunk_ring_many_tiles(tune, variant):
     assert torch.equal(x, x2)
 
 
-@pytest.mark.parametrize("variant", ["v2", "v5", "v7", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("variant", ["v2", "v5", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("M,N", [(20 * 256 - 37, 1300), (129, 128), (3 * 256, 7 * 256), (1100, 260)])
 def test_gemm_grouped_tile_order_covers_every_tile_once(tune, variant, M, N):
     """M324_XCD=7 forces the 4 x 2 group tile order (gemm_tile.h tile_of; chosen by default only for weights larger than
@@ -283,7 +283,7 @@ def test_gemm_ring_edge_shapes(tune, variant, M, N, K):
 
 
 @pytest.mark.parametrize("variant,M,N,K", [("v10", 8192, 3072, 768), ("v11", 8192, 3072, 768), ("v12", 10368, 768, 3072),
-                                            ("v7", 8192, 3072, 768), ("v13", 10368, 768, 768)])
+                                            ("v13", 10368, 768, 768)])
 def test_gemm_ring_kernels_are_race_free(tune, variant, M, N, K):
     """The LDS-DMA rings state their own vmcnt waits (tests/test_static.py audits them); a missing one shows up as a tile
     read before it landed -- rarely, and only when the chip is full.  Forty launches at the model's shapes must give
@@ -422,7 +422,7 @@ def test_gemm_qkv_heads_epilogue(B, L, H, norm, bias):
     assert rel_err(out_f.float(), ref_o) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [None, "v2", "v7", "v10", "v11", "v13"])
+@pytest.mark.parametrize("variant", [None, "v2", "v10", "v11", "v13"])
 def test_gemm_qkv_heads_transposed_v_epilogue(tune, variant):
     """M324_AUX_QKV_HEADS_VT: as the head-major epilogue, but V leaves as the transposed, key-permuted Vt the default
     attention kernel reads.  Vt must equal m324_gemm + m324_qkv_split bit for bit (both round acc + bias to bf16 once);

@@ -465,7 +465,9 @@ def test_three_training_steps_match_the_reference_golden(precision):
     assert np.allclose(norms, gold["grad_norm"], rtol=1e-4 if fp32 else 2.5e-2)
     assert len(gerr) == 12 and max(gerr.values()) < (2e-3 if fp32 else 2.5e-2), gerr
     assert max(gn_err.values()) < (1e-4 if fp32 else 2.5e-2), gn_err
-    assert max(perr.values()) < (2e-5 if fp32 else 2e-3), perr
+    # bf16: Adam's update is ~ +-lr per element whatever the gradient's size, so where the gradient is at the bf16 noise level
+    # a flipped sign moves a weight by 2 lr = 10 % of its 0.02 scale: 1.0e-2 measured on the worst slice after two updates
+    assert max(perr.values()) < (2e-5 if fp32 else 3e-2), perr
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
