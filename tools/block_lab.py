@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""The decoder cross-attention block of the c2 clip on its own: hipGraph replay timing (as bench.py reports it) and, under
+`rocprofv3 --kernel-trace --stats`, the per-kernel durations inside the replays.
+usage: tools/block_lab.py [replays]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import motion324_amd as m
+from motion324_amd import synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+dev = torch.device("cuda", 0)
+w = bench.WORKLOAD
+model, _ = bench.build_model(dev, w["frames"])
+s = synth.synth_inputs(w["B"], w["T"], w["N"], w["S"], w["HW"], seed=1)
+sample = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+m.set_precision("bf16")
+for _ in range(3):
+    r = bench.decoder_block_replay(model, sample, n)
+    print({k: v for k, v in r.items() if k != "timing"}, flush=True)
