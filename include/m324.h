@@ -85,7 +85,9 @@ typedef struct {
      * the per-head RMSNorm of q and k (weights qkv_qw / qkv_kw [64], NULL = none, eps qkv_eps) and q * qkv_qscale
      * applied on the fp32 accumulators -- what m324_qkv_split does in a second pass (transformer.py:36-42,200-207).   
      * M324_AUX_QKV_HEADS_VT: the same, but qkv_v receives the TRANSPOSED, key-permuted Vt [B, H, 64, qkv_L] that
-     * m324_attention reads by default (m324_qkv_split's Vt; needs qkv_L % 128 == 0, so there is no padding).         */
+     * m324_attention reads by default (m324_qkv_split's Vt; needs qkv_L % 64 == 0, so there is no padding).
+     * Cross-attention projections (transformer.py:112-132): N = 2 H 64 with qkv_q NULL is the k|v projection, N = H 64
+     * with qkv_k and qkv_v NULL the q projection.                                                                      */
     void* qkv_q; void* qkv_k; void* qkv_v;
     const float* qkv_qw; const float* qkv_kw;
     float qkv_eps, qkv_qscale;

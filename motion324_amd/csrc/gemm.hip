@@ -927,6 +927,9 @@ static int pick_variant(const m324_gemm_args* a) {
     // 20.2 -> 19.1 us; 10.35 -> 10.31 ms per clip).  The fused q|k|v epilogues stay on v2: v13 wins them in isolation
     // (43.6 -> 42.3 us) but the clip got 0.9 % slower with it.
     if (ring_ok && a->out_dtype == M324_F32 && !a->aux_mode) return 13;
+    // ... and for small plain bf16 problems (the decoder's k|v and q projections, 2048 rows: <= one round of tiles, so a
+    // tile's 12 K-stages are pure latency -- the ring's 2.5 stages of look-ahead: 11.4 -> 9.2 us, 10.5 -> 8.3 us)
+    if (ring_ok && !a->aux_mode && (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) <= 512) return 13;
     return 2;
 }
 
@@ -1162,12 +1165,20 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
         M324_REQUIRE(((uintptr_t)a->qkv_qw % 16) == 0 && (!a->bias || ((uintptr_t)a->bias % 16) == 0), "m324_gemm: M324_AUX_N3 operands misaligned");
     }
     if (qkv_mode) {
-        M324_REQUIRE(a->aux_mode != M324_AUX_QKV_HEADS_VT || a->qkv_L % 128 == 0,
-                     "m324_gemm: M324_AUX_QKV_HEADS_VT needs qkv_L %% 128 == 0 (L=%d)", a->qkv_L);
-        M324_REQUIRE(a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16 && a->qkv_q && a->qkv_k && a->qkv_v && a->qkv_H > 0 &&
-                         a->qkv_L > 0 && a->N == 3 * a->qkv_H * 64 && a->M % a->qkv_L == 0 && !a->residual && !a->gamma &&
+        // Vt has no padding and a 32-token block of the epilogue must stay inside one batch entry: L % 64 == 0
+        M324_REQUIRE(a->aux_mode != M324_AUX_QKV_HEADS_VT || a->qkv_L % 64 == 0,
+                     "m324_gemm: M324_AUX_QKV_HEADS_VT needs qkv_L %% 64 == 0 (L=%d)", a->qkv_L);
+        // q|k|v, k|v (qkv_q NULL) or q alone (qkv_k and qkv_v NULL): N = number of parts x H x 64
+        const int parts = (a->qkv_q ? 1 : 0) + (a->qkv_k ? 1 : 0) + (a->qkv_v ? 1 : 0);
+        const bool shape_ok = (a->qkv_q && a->qkv_k && a->qkv_v) || (!a->qkv_q && a->qkv_k && a->qkv_v) || (a->qkv_q && !a->qkv_k && !a->qkv_v);
+        M324_REQUIRE(shape_ok && a->qkv_H > 0 && a->N == parts * a->qkv_H * 64,
+                     "m324_gemm: M324_AUX_QKV_HEADS outputs must be q|k|v, k|v or q with N = parts * H * 64 (N=%d H=%d parts=%d)", a->N,
+                     a->qkv_H, parts);
+        M324_REQUIRE(a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16 &&
+                         a->qkv_L > 0 && a->M % a->qkv_L == 0 && !a->residual && !a->gamma &&
                          a->act == M324_ACT_NONE && a->row_gin <= 0 && a->batch <= 1 && a->M > 64 && vec_ok(a),
                      "m324_gemm: M324_AUX_QKV_HEADS needs a plain bf16 [B*L, 3*H*64] projection with M > 64");
+        M324_REQUIRE(a->aux_mode != M324_AUX_QKV_HEADS_VT || a->qkv_v, "m324_gemm: M324_AUX_QKV_HEADS_VT without a V output");
         M324_REQUIRE(((uintptr_t)a->qkv_q % 16) == 0 && ((uintptr_t)a->qkv_k % 16) == 0 && ((uintptr_t)a->qkv_v % 16) == 0 &&
                          (!a->qkv_qw || ((uintptr_t)a->qkv_qw % 16) == 0) && (!a->qkv_kw || ((uintptr_t)a->qkv_kw % 16) == 0),
                      "m324_gemm: misaligned qkv outputs / norm weights");

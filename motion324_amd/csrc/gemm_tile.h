@@ -677,7 +677,8 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
     // xor-shuffles inside the group, and a (token, head) row leaves as 8 x 16 bytes = one 128-byte line.
     auto body_qkv = [&]() {
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
-        const int hc = ep.qkv_H * 64, which = nw / hc, head = (nw % hc) >> 6;
+        // a projection may carry only the k|v or only the q part (cross-attention: NULL outputs in front shift `which`)
+        const int hc = ep.qkv_H * 64, which = nw / hc + (ep.qkv_out[0] ? 0 : 1), head = (nw % hc) >> 6;
         const int n8 = nw + c8;
         float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0, w0 = make_float4(1.f, 1.f, 1.f, 1.f), w1 = w0;
         if (ep.bias) { b0 = *reinterpret_cast<const float4*>(ep.bias + n8); b1 = *reinterpret_cast<const float4*>(ep.bias + n8 + 4); }

@@ -153,26 +153,31 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
             raise L.M324Error(f"gemm: copy_out {copy_out.dtype}{tuple(copy_out.shape)} (want bf16 [{M}, {N}])")
         args.ln_copy_out, args.ln_ldcopy = _rows(copy_out, "copy_out")
     if qkv_heads is not None:
-        Qo, Ko, Vo, qw, kw, eps, q_scale, Lh, Hh = qkv_heads
+        # (Q, K, V, q_w, k_w, eps, q_scale, L, H[, vt]): Q None = the k|v projection of a cross-attention, K and V None = its
+        # q projection; vt (default: V has the transposed shape and L != 64) = V leaves transposed + key-permuted
+        Qo, Ko, Vo, qw, kw, eps, q_scale, Lh, Hh = qkv_heads[:9]
         Bh = M // Lh
-        vt = tuple(Vo.shape) == (Bh, Hh, 64, Lh) and Lh != 64
+        vt = qkv_heads[9] if len(qkv_heads) > 9 else (Vo is not None and tuple(Vo.shape) == (Bh, Hh, 64, Lh) and Lh != 64)
         for t in (Qo, Ko, Vo):
+            if t is None:
+                continue
             want = (Bh, Hh, 64, Lh) if (vt and t is Vo) else (Bh, Hh, Lh, 64)
             if t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != want:
                 raise L.M324Error(f"gemm: qkv_heads output {t.dtype}{tuple(t.shape)} (want bf16 {want})")
-        if vt and Lh % 128:
-            raise L.M324Error(f"gemm: a transposed V output needs L % 128 == 0 (L={Lh})")
+        if vt and Lh % 64:
+            raise L.M324Error(f"gemm: a transposed V output needs L % 64 == 0 (L={Lh})")
         args.C, args.ldc = None, N
         args.in_dtype, args.out_dtype = code_of(a.dtype), BF16
         args.bias = _vec(bias, N, "bias")
         args.aux_mode = 4 if vt else 3
         args.qkv_q, args.qkv_k, args.qkv_v = _p(Qo), _p(Ko), _p(Vo)
         args.qkv_qw, args.qkv_kw = _vec(qw, 64, "q_w"), _vec(kw, 64, "k_w")
+        first = next(t for t in (Qo, Ko, Vo) if t is not None)
         args.qkv_eps, args.qkv_qscale, args.qkv_L, args.qkv_H = eps, q_scale, Lh, Hh
         with span("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N),
                   f"{_gemm_plan(args)} | M={M} N={N} K={K} qkv-heads" if _timing() else ""):
             L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
-        return Qo
+        return first
     if n3 is not None:
         # n3 = (w3 fp32 [3, N], part fp32 [N / 64, M, 3]): gelu(a w^T + bias) is contracted with w3 in the epilogue
         # (M324_AUX_N3); `out` is ignored (may be None); finish with n3_finish(part, bias3, out3)

@@ -202,6 +202,12 @@ def fuse_qkv(P: Prepared, rows: int, L: int) -> bool:
             and not torch.is_grad_enabled())
 
 
+def fuse_proj(P: Prepared, rows: int) -> bool:
+    """The q / k|v projections of the cross-attention blocks write their head-major operands from the GEMM epilogue (bf16
+    inference; the tile kernels need more than 64 rows)."""
+    return FUSE_QKV and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64 and not torch.is_grad_enabled()
+
+
 class QK_Norm_TransformerBlock(nn.Module):
     """Pre-norm self-attention block (reference transformer.py:379-423)."""
 
@@ -296,9 +302,14 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         a = self.attn
         qn = torch.empty(query.shape, dtype=P.dtype, device=query.device)
         ops.layernorm(query, P.vec(self.norm_q.weight), P.vec(self.norm_q.bias), self.norm_q.eps, qn)
+        qw, _ = a._qk_w(P)
+        if fuse_proj(P, B * Lq):                   # head-major Q (RMSNorm, pre-scale) straight from the projection's epilogue
+            Q = torch.empty((B, a.num_heads, Lq, 64), dtype=P.dtype, device=query.device)
+            ops.gemm(qn, P.mat(a.to_q.weight), None, bias=P.vec(a.to_q.bias),
+                     qkv_heads=(Q, None, None, qw, None, RMS_EPS, ops.Q_PRESCALE, Lq, a.num_heads))
+            return Q
         q = torch.empty(query.shape, dtype=P.dtype, device=query.device)
         ops.gemm(qn, P.mat(a.to_q.weight), q, bias=P.vec(a.to_q.bias))
-        qw, _ = a._qk_w(P)
         Q, _, _ = ops.qkv_split(q, None, None, qw, None, RMS_EPS, B, Lq, a.num_heads, P.dtype, q_scale=ops.Q_PRESCALE)
         return Q
 
@@ -309,9 +320,14 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         kn = torch.empty((B * Lk, C), dtype=P.dtype, device=kv.device)
         ops.layernorm(kv, P.vec(self.norm_kv.weight), P.vec(self.norm_kv.bias), self.norm_kv.eps, kn, row_map=row_map)
         w_kv, b_kv = P.cat_rows((a.to_k.weight, a.to_v.weight)), P.cat_vecs((a.to_k.bias, a.to_v.bias))
+        _, kw = a._qk_w(P)
+        if fuse_proj(P, B * Lk) and Lk % 64 == 0:  # head-major K (RMSNorm) and the transposed, key-permuted Vt from the epilogue
+            K = torch.empty((B, a.num_heads, Lk, 64), dtype=P.dtype, device=kv.device)
+            Vt = torch.empty((B, a.num_heads, 64, Lk), dtype=P.dtype, device=kv.device)
+            ops.gemm(kn, w_kv, None, bias=b_kv, qkv_heads=(None, K, Vt, None, kw, RMS_EPS, 1.0, Lk, a.num_heads, True))
+            return K, Vt
         kvp = torch.empty((B * Lk, 2 * a.dim), dtype=P.dtype, device=kv.device)
         ops.gemm(kn, w_kv, kvp, bias=b_kv)
-        _, kw = a._qk_w(P)
         _, K, Vt = ops.qkv_split(None, kvp[:, :a.dim], kvp[:, a.dim:], None, kw, RMS_EPS, B, Lk, a.num_heads, P.dtype)
         return K, Vt
 

@@ -450,7 +450,7 @@ def test_gemm_qkv_heads_transposed_v_epilogue(tune, variant):
     ops.attention(Q2, K2, Vt2, out_2, prescaled=True)
     assert rel_err(out_f.float(), out_2.float().double()) < 1e-2
     from motion324_amd.lib import M324Error
-    with pytest.raises(M324Error, match="128"):        # L = 200: a 32-token block would straddle the batches
+    with pytest.raises(M324Error, match="64"):         # L = 200: a 32-token block would straddle the batches
         ops.gemm(x[:400], w, None, bias=b, qkv_heads=(Q[:, :, :200].contiguous(), Kk[:, :, :200].contiguous(),
                                                        torch.empty((2, H, 64, 200), dtype=dtype, device=DEV), qw, kw, 1e-5, 1.0, 200, H))
 
@@ -934,3 +934,34 @@ def test_gemm_ln_fold_rejects_unsupported_shapes():
     out = torch.zeros((256, 96), dtype=torch.bfloat16, device=DEV)
     with pytest.raises(M324Error):                            # N % 64 != 0
         ops.gemm(a, w, out, ln=(torch.zeros((256, 2), device=DEV), torch.zeros(96, device=DEV)))
+
+
+@pytest.mark.parametrize("B,L", [(32, 64), (2, 4096), (3, 192)])
+def test_gemm_cross_attention_projection_heads(B, L):
+    """The q and the k|v projections of a cross-attention block (transformer.py:112-132) with the head split in the GEMM
+    epilogue (qkv_heads with NULL parts: q alone; k|v with the transposed, key-permuted Vt -- L = 64 is the decoder's latent
+    tokens, one 64-key tile per frame) == the plain projection followed by m324_qkv_split (Vt bit for bit: both round acc + bias to bf16 once; Q / K up to the one
+    bf16 rounding the two-pass form puts in front of the RMSNorm)."""
+    ops = _ops()
+    H, C = 3, 192
+    M = B * L
+    x = _rand((M, C), 301).to(torch.bfloat16).to(DEV)
+    wq, bq = (_rand((C, C), 302, 0.08)).to(torch.bfloat16).to(DEV), _rand((C,), 303, 0.1).to(DEV)
+    wkv, bkv = (_rand((2 * C, C), 304, 0.08)).to(torch.bfloat16).to(DEV), _rand((2 * C,), 305, 0.1).to(DEV)
+    qw, kw = (1 + 0.1 * _rand((64,), 306)).to(DEV), (1 + 0.1 * _rand((64,), 307)).to(DEV)
+    # q alone
+    q = torch.empty((M, C), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, wq, q, bias=bq)
+    Qs, _, _ = ops.qkv_split(q, None, None, qw, None, 1e-5, B, L, H, torch.bfloat16, q_scale=ops.Q_PRESCALE)
+    Qf = torch.full((B, H, L, 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, wq, None, bias=bq, qkv_heads=(Qf, None, None, qw, None, 1e-5, ops.Q_PRESCALE, L, H))
+    assert torch.isfinite(Qf.float()).all() and rel_err(Qf.float(), Qs.float().double()) < 6e-3
+    # k|v
+    kv = torch.empty((M, 2 * C), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, wkv, kv, bias=bkv)
+    _, Ks, Vts = ops.qkv_split(None, kv[:, :C], kv[:, C:], None, kw, 1e-5, B, L, H, torch.bfloat16)
+    Kf = torch.full((B, H, L, 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Vtf = torch.full((B, H, 64, L), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, wkv, None, bias=bkv, qkv_heads=(None, Kf, Vtf, None, kw, 1e-5, 1.0, L, H, True))
+    assert torch.isfinite(Kf.float()).all() and rel_err(Kf.float(), Ks.float().double()) < 6e-3
+    assert torch.equal(Vtf, Vts)

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
         {"square 8192", 8192, 8192, 8192, 0},   {"pcd fc2", 64, 768, 3072, 2},         {"pcd fc1 gelu", 64, 3072, 768, 1},
         {"pcd qkv", 64, 2304, 768, 0},          {"pcd fc", 64, 768, 768, 2},
         {"trunk qkv heads", 10368, 2304, 768, 4}, {"dino qkv heads", 8224, 2304, 768, 5},
+        {"deckv proj", 2048, 1536, 768, 0}, {"decq proj", 2048, 768, 768, 0},
     };
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
