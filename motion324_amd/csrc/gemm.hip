@@ -929,7 +929,8 @@ static int pick_variant(const m324_gemm_args* a) {
     if (ring_ok && a->out_dtype == M324_F32 && !a->aux_mode) return 13;
     // ... and for small plain bf16 problems (the decoder's k|v and q projections, 2048 rows: <= one round of tiles, so a
     // tile's 12 K-stages are pure latency -- the ring's 2.5 stages of look-ahead: 11.4 -> 9.2 us, 10.5 -> 8.3 us)
-    if (ring_ok && !a->aux_mode && (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) <= 512) return 13;
+    const bool heads = a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT;   // cross-attention q / k|v
+    if (ring_ok && (!a->aux_mode || heads) && (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) <= 512) return 13;
     return 2;
 }
 
