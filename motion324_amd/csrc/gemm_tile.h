@@ -761,7 +761,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 float rs = post;
                 if (norm) {
                     float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w + y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
-                    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                    ss = group8_sum(ss);                      // DPP adds (no LDS crossbar): the 8 lanes of the row
                     rs *= rsqrtf(ss * (1.0f / 64.0f) + ep.qkv_eps);
                 }
                 x.x *= rs * w0.x; x.y *= rs * w0.y; x.z *= rs * w0.z; x.w *= rs * w0.w;
@@ -825,10 +825,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 for (int j = 0; j < 3; ++j) {
                     float t = x.x * w0[j].x + x.y * w0[j].y + x.z * w0[j].z + x.w * w0[j].w + y.x * w1[j].x + y.y * w1[j].y +
                               y.z * w1[j].z + y.w * w1[j].w;
-                    t += __shfl_xor(t, 1, 64);
-                    t += __shfl_xor(t, 2, 64);
-                    t += __shfl_xor(t, 4, 64);
-                    sj[j] = t;
+                    sj[j] = group8_sum(t);
                 }
                 const long m = mw + i * 32 + p * 8 + r8;
                 if ((lane & 7) == 0 && m < M && nw + 64 <= N) {
