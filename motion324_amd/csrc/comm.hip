@@ -6,14 +6,26 @@
 // repo issues them through torch.distributed (backend "nccl" = RCCL), which owns the process group the reference's
 // setup.py:134-140 creates; a host that binds libm324 WITHOUT torch gets the same two collectives here.
 //
-// libm324.so does not link RCCL: the library is resolved at m324_comm_init time -- first among the symbols already
-// loaded into the process (a torch process carries its own copy; two RCCL instances must not be mixed), then
-// librccl.so from the loader path -- so that the kernels stay loadable on a box without RCCL.
+// libm324.so neither links RCCL nor needs its headers: the library is resolved at m324_comm_init time, in this order:
+// (1) the path in M324_RCCL_LIB, (2) a copy ALREADY LOADED into the process -- global symbols first, then
+// dlopen(RTLD_NOLOAD), which also finds the librccl.so a torch process loaded with RTLD_LOCAL (two RCCL instances must
+// not be mixed) --, (3) librccl.so from the loader path.  The handful of RCCL types and enum values used here are
+// restated below (they are RCCL's ABI: nccl.h of RCCL 2.x), so the kernels build and load on a box without RCCL.
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
-#include <rccl/rccl.h>
 #include "common.h"
+
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat64 = 8, ncclBfloat16 = 9 } ncclDataType_t;
+}
 
 struct m324_comm {
     ncclComm_t comm;
@@ -34,8 +46,13 @@ struct Rccl {
 const Rccl* rccl() {
     static const Rccl r = [] {
         Rccl x{};
-        void* h = dlsym(RTLD_DEFAULT, "ncclCommInitRank") ? RTLD_DEFAULT : dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        void* h = nullptr;
+        if (const char* forced = getenv("M324_RCCL_LIB")) h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        if (!h && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) h = RTLD_DEFAULT;
+        for (const char* name : {"librccl.so", "librccl.so.1"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);         // already mapped (e.g. by torch, RTLD_LOCAL): reuse THAT copy
+        for (const char* name : {"librccl.so", "librccl.so.1"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (!h) return x;
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(h, "ncclCommInitRank");

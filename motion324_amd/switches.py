@@ -24,6 +24,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_FUSE_QKV_VT": ("1", "transformer.FUSE_QKV_VT", "the same for long sequences: the epilogue writes the transposed, key-permuted V"),
     "M324_PRECISION": ("", "prepared.compute_dtype()", "force bf16 / fp32 (default: follow torch.autocast like the reference)"),
     "M324_LIB": ("", "lib.LIB_PATH", "path of an alternative libm324.so (lab builds)"),
+    "M324_RCCL_LIB": ("", "csrc/comm.hip", "m324_comm_*: path of the RCCL library to bind (default: the copy already loaded, else librccl.so)"),
 }
 # Library switches (C++; read by libm324 once, when it is loaded -- csrc/runtime.hip; m324_set_tunable overrides them)
 LIBRARY: Dict[str, Tuple[str, str]] = {
