@@ -34,7 +34,7 @@ void m324_set_error(const char* fmt, ...);
 // path calls getenv().
 namespace m324 {
 enum Tunable { TUN_GEMM = 0, TUN_GEMM_TN, TUN_XCD, TUN_ATTN_NW, TUN_ATTN_FLAT, TUN_ATTN_OCC, TUN_ATTN_NQ2, TUN_ATTN_BWD_NW,
-               TUN_ATTN_EXP, TUN_COUNT };
+               TUN_ATTN_EXP, TUN_LN_ROWS, TUN_COUNT };
 int tunable(int which);          // 0 = "not set" for every switch except TUN_XCD (default 3) / TUN_ATTN_FLAT (default 1)
 }  // namespace m324
 
@@ -83,10 +83,34 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 // exact (erf) GELU, nn.GELU() default -- reference model/transformer.py:58
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Sum over the 64 lanes, delivered to every lane.  The four steps inside a row of 16 lanes are DPP adds (v_add_f32 with a
+// quad_perm / row_half_mirror / row_mirror operand: no LDS crossbar, ~1 issue slot each); only the two steps across rows go
+// through ds_bpermute.  A butterfly like the xor shuffles it replaces (every lane ends with the same, fixed-order sum:
+// neighbours first, then quads, halves, rows), six dependent LDS round trips shorter.
+template <int CTRL>
+__device__ __forceinline__ float m324_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += m324_dpp<0xB1>(v);          // quad_perm [1, 0, 3, 2]   (lane ^ 1)
+    v += m324_dpp<0x4E>(v);          // quad_perm [2, 3, 0, 1]   (lane ^ 2)
+    v += m324_dpp<0x141>(v);         // row_half_mirror          (the other quad of the 8)
+    v += m324_dpp<0x140>(v);         // row_mirror               (the other half of the 16)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+// two independent sums at once: the steps of both butterflies interleave, so one's shuffle latency hides the other's
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+    a += m324_dpp<0xB1>(a);  b += m324_dpp<0xB1>(b);
+    a += m324_dpp<0x4E>(a);  b += m324_dpp<0x4E>(b);
+    a += m324_dpp<0x141>(a); b += m324_dpp<0x141>(b);
+    a += m324_dpp<0x140>(a); b += m324_dpp<0x140>(b);
+    const float a16 = __shfl_xor(a, 16, 64), b16 = __shfl_xor(b, 16, 64);
+    a += a16; b += b16;
+    const float a32 = __shfl_xor(a, 32, 64), b32 = __shfl_xor(b, 32, 64);
+    a += a32; b += b32;
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -53,10 +53,13 @@ __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
 }
 
 // ----------------------------------------------------------------------------------- layernorm
+// A wave normalises TWO rows at a time (rows 2w, 2w + 1 of the workgroup's eight): the pass is a chain of dependent steps
+// -- load, mean butterfly, variance butterfly, store -- and two independent chains per wave overlap each other's shuffle
+// and memory latency (same two-pass statistics per row as before: bit-identical results).
 template <typename T, typename TX = float>
-__global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
-                                                        int rows, int C, int gin, int gout, int off) {
+__global__ __launch_bounds__(256) void layernorm1_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
+                                                         int rows, int C, int gin, int gout, int off) {   // one row per wave (M324_LN_ROWS=1: A/B)
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -71,6 +74,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x
         float4 bb = b ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         store4<T>(yr + c, (v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
                   (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+    }
+}
+
+template <typename T, typename TX = float>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
+                                                        int rows, int C, int gin, int gout, int off) {
+    const int lane = threadIdx.x & 63;
+    const long row0 = (long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2;
+    if (row0 >= rows) return;
+    const bool two = row0 + 1 < rows;
+    const long row1 = two ? row0 + 1 : row0;                 // a lone last row is simply done twice (same values stored twice)
+    const TX* xa = x + remap_row(row0, gin, gout, off) * ldx;
+    const TX* xb = x + remap_row(row1, gin, gout, off) * ldx;
+    float4 va[LN_MAXV], vb[LN_MAXV];
+    LN_FOR(i, c) { va[i] = load4<TX>(xa + c); vb[i] = load4<TX>(xb + c); }
+    float sa = 0.f, sb = 0.f;
+    LN_FOR(i, c) { sa += va[i].x + va[i].y + va[i].z + va[i].w; sb += vb[i].x + vb[i].y + vb[i].z + vb[i].w; }
+    wave_sum2(sa, sb);
+    const float ma = sa / (float)C, mb = sb / (float)C;
+    float qa = 0.f, qb = 0.f;
+    LN_FOR(i, c) {
+        float p = va[i].x - ma, q = va[i].y - ma, r = va[i].z - ma, t = va[i].w - ma;
+        qa += p * p + q * q + r * r + t * t;
+        p = vb[i].x - mb, q = vb[i].y - mb, r = vb[i].z - mb, t = vb[i].w - mb;
+        qb += p * p + q * q + r * r + t * t;
+    }
+    wave_sum2(qa, qb);
+    const float ra = rsqrtf(qa / (float)C + eps), rb = rsqrtf(qb / (float)C + eps);
+    T* ya = y + row0 * ldy;
+    T* yb = y + row1 * ldy;
+    LN_FOR(i, c) {
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        const float4 bb = b ? *reinterpret_cast<const float4*>(b + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        store4<T>(ya + c, (va[i].x - ma) * ra * ww.x + bb.x, (va[i].y - ma) * ra * ww.y + bb.y,
+                  (va[i].z - ma) * ra * ww.z + bb.z, (va[i].w - ma) * ra * ww.w + bb.w);
+        store4<T>(yb + c, (vb[i].x - mb) * rb * ww.x + bb.x, (vb[i].y - mb) * rb * ww.y + bb.y,
+                  (vb[i].z - mb) * rb * ww.z + bb.z, (vb[i].w - mb) * rb * ww.w + bb.w);
     }
 }
 
@@ -717,7 +758,11 @@ extern "C" int m324_layernorm_in(const void* x, int x_dtype, long ldx, const flo
     M324_REQUIRE(x_dtype == M324_BF16 && out_dtype == M324_BF16, "m324_layernorm_in: a bf16 input needs a bf16 output");
     M324_REQUIRE(rows > 0 && C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV && ldx % 4 == 0 && ldy % 4 == 0,
                  "m324_layernorm_in: rows=%d C=%d ldx=%ld ldy=%ld unsupported", rows, C, ldx, ldy);
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+    if (m324::tunable(m324::TUN_LN_ROWS) == 1)
+        hipLaunchKernelGGL((layernorm1_kernel<bf16_t, bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, ldx, w, b, eps, (bf16_t*)y, ldy, rows, C, gin, gout, off);
+    else
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(ceil_div(rows, 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, ldx, w, b, eps, (bf16_t*)y, ldy, rows, C, gin, gout, off);
     M324_CHECK_LAUNCH("m324_layernorm_in");
     return M324_OK;
@@ -730,9 +775,15 @@ extern "C" int m324_layernorm(const float* x, long ldx, const float* w, const fl
     M324_REQUIRE(C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV, "m324_layernorm: C=%d unsupported", C);
     M324_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "m324_layernorm: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_DTYPE(out_dtype, "m324_layernorm",
-                   hipLaunchKernelGGL(layernorm_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, w, b, eps,
-                                      (T*)y, ldy, rows, C, gin, gout, off));
+    if (m324::tunable(m324::TUN_LN_ROWS) == 1) {
+        DISPATCH_DTYPE(out_dtype, "m324_layernorm",
+                       hipLaunchKernelGGL(layernorm1_kernel<T>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, w, b, eps,
+                                          (T*)y, ldy, rows, C, gin, gout, off));
+    } else {
+        DISPATCH_DTYPE(out_dtype, "m324_layernorm",
+                       hipLaunchKernelGGL(layernorm_kernel<T>, dim3(ceil_div(rows, 8)), dim3(256), 0, s, x, ldx, w, b, eps,
+                                          (T*)y, ldy, rows, C, gin, gout, off));
+    }
     M324_CHECK_LAUNCH("m324_layernorm");
     return M324_OK;
 }

@@ -37,6 +37,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_ATTN_NQ2": ("0", "attention: 64 queries per wave"),
     "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup"),
     "M324_ATTN_EXP": ("0", "attention: static priority for the younger half of an 8-wave workgroup"),
+    "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
 }
 
 
