@@ -83,7 +83,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long ldo, int H, int Lq, int Lk,
                                                         int Lkp, float scale_log2e, float* __restrict__ lse, int nqt, int xflags) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ASTAGE];   // [stage][K | Vt]
+    // [stage][K | Vt]; the one-tile form appends a wave-private 4-KiB block per wave for the whole-row output stores (its only
+    // stage is still being read by the slower waves when the first one is done; 32 KiB keeps four workgroups per CU)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ASTAGE + (NST == 1 ? NWV * 4096 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
         // writes 8 whole 128-byte rows instead of 32 quarter rows (partial-line writes were what the short attentions --
         // one to six K / V tiles per workgroup -- spent their time on: decoder 48 us with 8-byte stores, 32 with 16-byte).
         // The block lives in ring stages no tile occupies any more (tiles nt and nt + 1 were never issued); the one-stage
-        // form has no such stage and stores its 16-byte chunks directly.
-        unsigned char* scr = smem + ((nt + (wave >> 2)) % NST) * ASTAGE + (wave & 3) * 4096;
+        // form has no such stage and owns a 4-KiB block per wave behind its only stage.
+        unsigned char* scr = NST == 1 ? smem + ASTAGE + wave * 4096 : smem + ((nt + (wave >> 2)) % NST) * ASTAGE + (wave & 3) * 4096;
         if (n > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // NQ = 2: the block is reused per query block
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -340,13 +342,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
                     c[k] = sw[1];
                 }
                 const int chunk = db * 4 + 2 * gp + hi;
-                if constexpr (NST == 1) {        // no free stage, and a barrier costs this one-tile kernel more than quarter rows do
+                if (NST == 1 && (xflags & 2)) {  // A/B (M324_ATTN_EXP bit 1): round 2's direct 16-byte stores of the one-tile form
                     if (q < Lq) *reinterpret_cast<uint4*>(O + ((long)b * Lq + q) * ldo + h * 64 + chunk * 8) = make_uint4(a[0], a[1], c[0], c[1]);
                 } else {
                     *reinterpret_cast<uint4*>(scr + l31 * 128 + ((chunk ^ (l31 & 7)) << 4)) = make_uint4(a[0], a[1], c[0], c[1]);
                 }
             }
-        if constexpr (NST != 1) {
+        if (!(NST == 1 && (xflags & 2))) {
             const int r8 = lane >> 3, c8 = lane & 7;
             bf16_t* obase = O + ((long)b * Lq + q0 + n * QW) * ldo + h * 64 + c8 * 8;
 #pragma unroll
