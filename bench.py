@@ -506,7 +506,22 @@ def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
         del cm, fast, smp
         return res
 
+    def resized():
+        """the released checkpoint's setting (scripts/4D_from_existing.sh: a model trained with training.frames = 12 run on a
+        32-frame clip): the 3-D position table is resized 12 -> 32 frames (Pcd_motion.py:221-228), cached per clip length"""
+        rm, _ = build_model(dev, 12)
+        fast = m.GraphedForward(rm, warmup=1)
+        with torch.no_grad():
+            clip = fast.static_inputs(sample)
+            fast(clip)
+            ms = _event_time_ms(lambda: fast(clip), 10)
+            fin = bool(torch.isfinite(fast(clip).pcd_moved).all())
+        del rm, fast
+        return {"value": round(w["B"] * w["T"] / ms * 1e3, 2), "unit": "frames/s", "ms_per_step": round(ms, 3), "finite": fin,
+                "note": "training.frames = 12, clip of 32 frames (parity of the resize: goldens tiny_resize and c1)"}
+
     guarded("headline_without_precision_shortcuts", strict)
+    guarded("c2_with_training_frames_12_pos_embed_resized", resized)
     guarded("fp32_parity_mode_c2", fp32)
     guarded("h2d", h2d)
     guarded("train_c3", train_c3)

@@ -629,6 +629,47 @@ def test_autograd_wrapper_and_three_optimizer_steps_match_torch_on_oracle():
     assert losses[2] < losses[0]
 
 
+def test_gradient_accumulation_equals_the_whole_batch():
+    """train.py:159-162 with grad_accum_steps = 2: two micro-batches, each back-propagating loss / 2, accumulate into .grad and
+    ONE optimizer step follows.  Native form: forward_backward(..., grad_scale = 1/2) twice + FusedAdamW.load_grads(accumulate =
+    True on the second) == one forward_backward over the concatenated batch (the loss is a mean over the batch), and the
+    optimizer step that follows moves the parameters identically (fp32 parity kernels: summation order only)."""
+    import motion324_amd as m
+    from motion324_amd import synth, training
+    from motion324_amd.optim import FusedAdamW
+    s_np = synth.synth_inputs(2, 3, 30, 80, 64, seed=7, with_target=True)
+    whole = {k: torch.from_numpy(v).cuda() for k, v in s_np.items()}
+    halves = [{k: v[i:i + 1].contiguous() for k, v in whole.items()} for i in range(2)]
+    m.set_precision("fp32")
+    try:
+        results = []
+        for mode in ("whole", "accumulated"):
+            model, dm = build("tiny")
+            model.train()
+            model.drop_rate = 0.0
+            opt = FusedAdamW(model.named_parameters(), lr=1e-3, allowed_gradnorm_factor=1e9)
+            if mode == "whole":
+                loss, _, G = training.forward_backward(model, whole)
+                opt.load_grads(G)
+                losses = [float(loss)]
+            else:
+                losses = []
+                for i, part in enumerate(halves):
+                    loss, _, G = training.forward_backward(model, part, grad_scale=0.5)
+                    opt.load_grads(G, accumulate=i > 0)
+                    losses.append(float(loss))
+            grad = opt.flat_grad.clone()
+            info = opt.step()
+            torch.cuda.synchronize()
+            results.append((losses, grad, info["grad_norm"], torch.cat([p.detach().reshape(-1) for p in opt.params]).clone()))
+    finally:
+        m.set_precision(None)
+    (lw, gw, nw, pw), (la, ga, na, pa) = results
+    assert lw[0] == pytest.approx(sum(la) / 2, rel=1e-6)
+    assert rel_err(ga, gw) < 1e-5 and na == pytest.approx(nw, rel=1e-5)
+    assert rel_err(pa, pw) < 1e-6
+
+
 def _ddp_worker(rank, world, port, ret):
     import os
     import torch.distributed as dist

@@ -18,3 +18,17 @@ m.set_precision("bf16")
 for _ in range(3):
     r = bench.decoder_block_replay(model, sample, n)
     print({k: v for k, v in r.items() if k != "timing"}, flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "burn":
+    # does the block slow down behind a few seconds of clip replays (clock / power state) or only inside bench.py's process state?
+    fast = m.GraphedForward(model)
+    with torch.no_grad():
+        clip = fast.static_inputs(sample)
+        import time
+        t0 = time.time()
+        while time.time() - t0 < 4.0:
+            for _ in range(32):
+                fast(clip)
+            torch.cuda.synchronize()
+    for _ in range(3):
+        r = bench.decoder_block_replay(model, sample, n)
+        print("after 4 s of clip replays:", {k: v for k, v in r.items() if k != "timing"}, flush=True)
