@@ -38,6 +38,28 @@ typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef __attribute__((address_space(1))) const void glb_ptr_t;
 constexpr int ASTAGE = 16384;   // K tile (8 KiB) + Vt tile (8 KiB)
 
+// Lab builds only (tools/build_attn_lab.sh trace -DM324_ATTN_TRACE, tools/attn_trace.py): the first wave of each half of one
+// workgroup in the middle of the grid stamps the shader clock at its phase boundaries of key tiles 60-75 into the LSE buffer.
+#ifdef M324_ATTN_TRACE
+#define ATRACE_DECL                                                                                                     \
+    const bool tr_on = lse && blockIdx.x == (gridDim.x >> 1) + 3 && (wave & 3) == 0;                                     \
+    long long* tbuf = reinterpret_cast<long long*>(lse) + (wave >> 2) * 1024;
+#define ATRACE(t, slot)                                                                                                 \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (tr_on && (t) >= 60 && (t) < 76) {                                                                           \
+            const long long c_ = __builtin_readcyclecounter();                                                          \
+            if (lane == 0) tbuf[((t) - 60) * 8 + (slot)] = c_;                                                          \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#define ATRACE_LSE(x)
+#else
+#define ATRACE_DECL
+#define ATRACE(t, slot)
+#define ATRACE_LSE(x) x
+#endif
+
 // A row of an O^T-style accumulator pair (lanes l and l + 32 hold alternating 4-value groups of row l & 31, 16 values per
 // 32-column block db): v_permlane32_swap trades the odd groups of the lower lanes for the even groups of the upper ones, so
 // each lane stores two whole 16-byte chunks per block instead of four 8-byte pieces.  chunk index = db * 4 + 2 gp + hi.
@@ -168,6 +190,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
     bool first = true;
 
     const int nt = (Lk + KV - 1) / KV;
+    ATRACE_DECL
     issue_tile(0);
     if (nt > 1) issue_tile(1);
     // Static priority for the second-dispatched half of an 8-wave workgroup (experiment switch M324_ATTN_EXP bit 0): the
@@ -183,10 +206,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
     for (int t = 0; t < nt; ++t) {
         // tile t landed (this wave's 4 pieces; tile t+1's may still fly), then the barrier publishes every
         // wave's pieces and retires all reads of the stage that tile t+2 is about to overwrite
+        ATRACE(t, 0);
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ATRACE(t, 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        ATRACE(t, 2);
         if (t + 2 < nt) issue_tile(t + 2);
         const unsigned char* sk = smem + (t % NST) * ASTAGE;
         const unsigned char* sv = sk + 8192;
@@ -202,6 +228,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[n][kb][r] = init;
         }
+        if constexpr (NQ == 1 && !VROW && NWV == 8) {
+            // all eight K fragments in flight before the first MFMA (the compiler's order -- two reads, wait, two MFMAs -- waits
+            // out an LDS round trip four times per tile; in-kernel stamps, tools/attn_trace.py)
+            bf16x8 kfa[8];          // in MFMA order: (kb, ks) = (i & 1, i >> 1)
+            auto rd = [&](int i) { kfa[i] = *reinterpret_cast<const bf16x8*>(smem + (i & 1) * 4096 + (kos ^ ((i >> 1) << 5))); };
+            rd(0); rd(1); rd(2); rd(3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s[0][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[i], qf[0][i >> 1], s[0][i & 1], 0, 0, 0);
+                if (i + 4 < 8) rd(i + 4);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i + 4 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        } else {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -211,6 +252,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
                 for (int n = 0; n < NQ; ++n)
                     s[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[n][ks], s[n][kb], 0, 0, 0);
             }
+        }
         if (!PRESCALED) {
 #pragma unroll
             for (int n = 0; n < NQ; ++n)
@@ -220,6 +262,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
                     for (int r = 0; r < 16; ++r) s[n][kb][r] *= scale_log2e;
         }
         const int kv0 = t * KV;
+        ATRACE(t, 3);
         if (kv0 + KV > Lk) {   // ragged last tile: mask keys >= Lk (wave-uniform branch)
 #pragma unroll
             for (int n = 0; n < NQ; ++n)
@@ -263,6 +306,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
             }
             first = false;
         }
+        ATRACE(t, 4);
         bf16x8 pf[NQ][4];   // P^T fragments, k-step j = kb*2 + (r>>3)
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
@@ -283,6 +327,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
             l_run[n] += rs2[0] + rs2[1];
         }
 
+        ATRACE(t, 5);
         // ---- O^T += Vt P^T.  k-step j contracts keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}: with the permuted
         //      key order of Vt that is the single 16-byte chunk 2j + hi of row d
 #pragma unroll
@@ -317,7 +362,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
         const float l_tot = l_run[n] + __shfl_xor(l_run[n], 32, 64);
         const float inv = 1.0f / l_tot;
         const int q = q0 + n * QW + l31;
-        if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_ref[n] + log2f(l_tot);   // log2-domain LSE
+        ATRACE_LSE(if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_ref[n] + log2f(l_tot);)   // log2-domain LSE
         // The two lanes of a query (l, l + 32) hold alternating 4-value groups of its row.  v_permlane32_swap trades the
         // odd groups of the lower lanes for the even groups of the upper ones, so every lane has whole 8-value (16-byte)
         // chunks; those bounce through a wave-private, XOR-swizzled 32 x 128-byte LDS block so that a store instruction
@@ -361,6 +406,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
     }
 }
 
+// Two other forms of the eight-wave kernel were built and measured in round 3 and are not kept (DESIGN.md section 6,
+// "what limits the global attention"; tools/coissue_lab, tools/attn_trace.py):
+//  * ping-pong: matrix phase {P.V of tile t, S of tile t + 1} / vector phase {softmax}, waves 4-7 one phase behind waves 0-3,
+//    four ring stages, two barriers per tile: 365-380 us against 330-345.  On gfx950 a plain VALU instruction of one wave does
+//    not issue while another wave of the SIMD has an MFMA pending (coissue_lab: v_fma_f32 next to an MFMA stream 34 cycles
+//    per instruction instead of 2.3), so the two phases serialise instead of overlapping.
+//  * half tiles: a lazy-reference check per 32 keys, the exponentials of one half between the MFMAs of the next step (only
+//    v_exp_f32 runs in an MFMA's shadow: two per MFMA are free), fragments read one block ahead: 339-383 us against 319-358.
+//    The compiler's schedule of the kernel above already puts two thirds of a tile's exponentials between its P.V MFMAs; the
+//    second check, the extra branches and the shorter MFMA runs cost more than the remaining third buys.
 
 // =====================================================================================================
 // Backward (bf16 MFMA).  Same swapped formulation and LDS tile images as the forward:
