@@ -18,7 +18,13 @@ SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "attention.hip", "elemen
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(HERE, "..", "include", "m324.h")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified 512-entry file), which removes the
 # v_accvgpr_read/write shuffling around every softmax / epilogue access of an accumulator
-BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32.  Next to a DPP reduction that turns
+# `v += dpp(v)` (one v_add_f32_dpp) into v_mov_b32_dpp + v_pk_add_f32, and THAT pair returned wrong sums on MI355X whenever a
+# chunk-ring GEMM (v10 / v13) ran on the same CUs from a second stream or graph branch: 39 of 200 LayerNorm launches off by an
+# ulp-sized statistic, 23 of 40 graph replays of the two-branch image encoder (round 3; tools/ln_stress.py reproduces it,
+# tools/audit_dpp.py scans the compiled code for the pattern).  Packed fp32 buys nothing here anyway: v_pk_add_f32 issues at
+# 4.5 cycles, two v_add_f32 at 2.3 each (tools/valu_lab); the hand-written f32x2 code (GELU polynomial) is not affected.
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 # gemm_ring4.hip: 256 accumulators per wave -> they must stay in the AGPR half (see the file header)
 FLAGS_OF = {"gemm_ring4.hip": BASE_FLAGS}
@@ -47,7 +53,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):      # the flags live in this file
             jobs.append([hipcc] + FLAGS_OF.get(src, FLAGS) + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dq_mfma_kernel(const bf16_t
 }
 
 template <int NWV>
-__global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ Qst,
+__global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ Qst,
                                                                 long q_bstride, long qt_bstride, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                                 const bf16_t* __restrict__ dOt, const float* __restrict__ lse,
@@ -588,39 +588,66 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_mfma_kernel(const bf16_
 #pragma unroll
         for (int r = 0; r < 16; ++r) ak[i][r] = 0.f, av[i][r] = 0.f;
     const int nt = (Lq + KV - 1) / KV;
+#ifdef M324_ATTN_TRACE
+    // lab builds: stamps of query tiles 20-35 of one workgroup's first wave go behind the dV tensor (tools/attn_bwd_lab.py)
+    const bool tr_on = blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == (gridDim.z >> 1) && wave == 0;
+    long long* tbuf = reinterpret_cast<long long*>(dV + (long)gridDim.z * H * Lk * 64);
+#define BTRACE(t, slot)                                                                                                 \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if (tr_on && (t) >= 20 && (t) < 36) {                                                                           \
+            const long long c_ = __builtin_readcyclecounter();                                                          \
+            if (lane == 0) tbuf[((t) - 20) * 8 + (slot)] = c_;                                                          \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#else
+#define BTRACE(t, slot)
+#endif
     issue(0);
     for (int t = 0; t < nt; ++t) {
         // the LDS-DMA of tile t must have landed: stated explicitly -- __syncthreads() alone is compiled to
         // `s_waitcnt lgkmcnt(0); s_barrier` here (no vmcnt), which let a workgroup read a stage that was still in flight
+        BTRACE(t, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BTRACE(t, 1);
         __syncthreads();
+        BTRACE(t, 2);
         if (t + 1 < nt) issue(t + 1);
+        BTRACE(t, 3);
         const unsigned char* sq = smem + (t & 1) * 32768;
         const unsigned char* sdo = sq + 8192;
         const unsigned char* sqt = sq + 16384;
         const unsigned char* sdot = sq + 24576;
         const int q0 = t * KV;
-        f32x16 s[2], dp[2];
+        // The rows of S / dP (queries) run along the registers, so lse[q] and D[q] are 2 x 16 values per lane and tile.  They are
+        // REQUESTED here and USED behind the 16 MFMAs (S and dP start from the inline constant 0): as initial values of the
+        // accumulators -- round 2 -- the first MFMA of every tile waited out their whole L2 round trip, with two waves per SIMD
+        // to cover it.  Same instruction count: a subtraction per value instead of a negated move.
+        f32x16 s[2], dp[2], lv[2], dv[2];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            // accumulator rows are queries q0 + qb*32 + (r & 3) + 8 (r >> 2) + 4 hi: start from -lse[q] / -D[q]
+        for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int qq = q0 + qb * 32 + 8 * g + 4 * hi;
-                if (qq + 3 < Lq && (Lq & 3) == 0) {                             // aligned run of 4 queries: one 16-byte load each
+                const int qq = q0 + qb * 32 + 8 * g + 4 * hi;      // rows (r & 3) + 8 (r >> 2) + 4 hi of the accumulator
+                if (qq + 3 < Lq && (Lq & 3) == 0) {                 // aligned run of 4 queries: one 16-byte load each
                     const float4 l4 = *reinterpret_cast<const float4*>(lseh + qq);
                     const float4 d4 = *reinterpret_cast<const float4*>(Dh + qq);
-                    s[qb][g * 4 + 0] = -l4.x; s[qb][g * 4 + 1] = -l4.y; s[qb][g * 4 + 2] = -l4.z; s[qb][g * 4 + 3] = -l4.w;
-                    dp[qb][g * 4 + 0] = -d4.x; dp[qb][g * 4 + 1] = -d4.y; dp[qb][g * 4 + 2] = -d4.z; dp[qb][g * 4 + 3] = -d4.w;
+                    lv[qb][g * 4 + 0] = l4.x; lv[qb][g * 4 + 1] = l4.y; lv[qb][g * 4 + 2] = l4.z; lv[qb][g * 4 + 3] = l4.w;
+                    dv[qb][g * 4 + 0] = d4.x; dv[qb][g * 4 + 1] = d4.y; dv[qb][g * 4 + 2] = d4.z; dv[qb][g * 4 + 3] = d4.w;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const bool ok = qq + e < Lq;
-                        s[qb][g * 4 + e] = ok ? -lseh[qq + e] : -INFINITY;      // query past the end: P = exp2(-inf) = 0
-                        dp[qb][g * 4 + e] = ok ? -Dh[qq + e] : 0.f;
+                        lv[qb][g * 4 + e] = ok ? lseh[qq + e] : INFINITY;        // query past the end: P = exp2(-inf) = 0
+                        dv[qb][g * 4 + e] = ok ? Dh[qq + e] : 0.f;
                     }
                 }
             }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[qb][r] = 0.f, dp[qb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(sq + k_off(qb * 32 + l31, ks * 2 + hi));
@@ -629,17 +656,19 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dkv_mfma_kernel(const bf16_
                 dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], dp[qb], 0, 0, 0);
             }
         }
+        BTRACE(t, 4);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[qb][r]);
+                const float p = __builtin_amdgcn_exp2f(s[qb][r] - lv[qb][r]);
                 s[qb][r] = p;
-                dp[qb][r] = p * dp[qb][r];
+                dp[qb][r] = p * (dp[qb][r] - dv[qb][r]);
             }
         bf16x8 pf[4], dsf[4];
         pack_frags(s, pf);
         pack_frags(dp, dsf);
+        BTRACE(t, 5);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Attention backward (bf16 MFMA kernels) alone, at the training step's shapes: time of the dQ + dK/dV pair per call, A/B of
+M324_ATTN_BWD_NW, and -- with a lab build (tools/build_attn_lab.sh trace -DM324_ATTN_TRACE; M324_LIB=...) -- the dK/dV
+kernel's own timeline (s_memtime stamps of one wave, query tiles 20-35):
+    0 tile body done | 1 LDS-DMA landed | 2 barrier passed | 3 next tile's LDS-DMA issued | 4 S / dP MFMAs issued |
+    5 exp / products / packs done | (next 0) dV / dK MFMAs issued
+usage: tools/attn_bwd_lab.py [--B 8] [--L 3888] [--trace]"""
+import argparse, ctypes as C, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from motion324_amd import lib, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=8)
+ap.add_argument("--L", type=int, default=3888)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--trace", action="store_true")
+a = ap.parse_args()
+dev, dt = "cuda", torch.bfloat16
+B, H, L = a.B, 12, a.L
+Lp = (L + 63) // 64 * 64
+g = torch.Generator(device=dev).manual_seed(0)
+r = lambda *sh: (torch.randn(*sh, device=dev, generator=g)).to(dt)
+Qs, K, V, dO = r(B, H, L, 64) * 0.18, r(B, H, L, 64), r(B, H, L, 64), r(B, H, L, 64)
+tr = lambda x: torch.nn.functional.pad(x.transpose(2, 3), (0, Lp - L)).contiguous()      # [B,H,64,Lp] (key order irrelevant for timing)
+Qst, Kt, dOt = tr(Qs), tr(K), tr(dO)
+lse = torch.full((B, H, L), 9.0, dtype=torch.float32, device=dev)
+D = torch.zeros((B, H, L), dtype=torch.float32, device=dev)
+dQ = torch.empty((B, H, L, 64), dtype=dt, device=dev)
+dK = torch.empty((B, H, L, 64), dtype=dt, device=dev)
+dV = torch.empty((B * H * L * 64 + 8192,), dtype=dt, device=dev)                              # + room for the stamps
+P = lambda t: C.c_void_p(t.data_ptr())
+Lb = lib.load()
+
+
+def call():
+    lib.check(Lb.m324_attention_bwd_mfma(P(Qs), P(Qst), H * L * 64, H * 64 * Lp, P(K), P(Kt), P(V), P(dO), P(dOt), P(lse), P(D), P(dQ), P(dK),
+                                         P(dV), B, H, L, L, 0.125, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "bwd")
+
+
+def timeit():
+    for _ in range(2):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.iters
+
+
+flops = 7 * 2.0 * B * H * L * L * 64        # dQ kernel 3 GEMMs, dK/dV kernel 4
+for nw in (0, 8):
+    lib.set_tunable("M324_ATTN_BWD_NW", nw)
+    ms = timeit()
+    print(f"B={B} H={H} L={L} M324_ATTN_BWD_NW={nw}: dQ + dK/dV {ms * 1e3:.1f} us per call = {flops / ms / 1e9:.0f} TF/s", flush=True)
+lib.set_tunable("M324_ATTN_BWD_NW", 0)
+if a.trace:
+    call()
+    torch.cuda.synchronize()
+    tb = dV[B * H * L * 64:].view(torch.int64).cpu()[:128].reshape(16, 8).tolist()
+    NS = 6
+    seq = [tb[t][s] for t in range(16) for s in range(NS)]
+    d = {s: [] for s in range(NS)}
+    for i in range(len(seq) - 1):
+        d[i % NS].append(seq[i + 1] - seq[i])
+    med = {s: sorted(v)[len(v) // 2] for s, v in d.items() if v}
+    print("dK/dV kernel, wave 0 of one workgroup: " + "  ".join(f"{s}->{(s + 1) % NS}: {med[s]}" for s in range(NS)) + f"   period {sum(med.values())} cycles")

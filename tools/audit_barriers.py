@@ -11,7 +11,7 @@ for src in ("gemm.hip", "gemm_ring4.hip", "attention.hip"):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         form = [] if src == "gemm_ring4.hip" else ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # as motion324_amd/build.py
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + form + ["--cuda-device-only", "-S", "-o", out, os.path.join(root, "motion324_amd", "csrc", src)],
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"] + form + ["--cuda-device-only", "-S", "-o", out, os.path.join(root, "motion324_amd", "csrc", src)],
                        check=True, stderr=subprocess.DEVNULL)
         kernels, name = {}, None
         for line in open(out):

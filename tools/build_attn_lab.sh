@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/lablibs
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form "$@" \
     -c ${ATTN_SRC:-motion324_amd/csrc/attention.hip} -o tools/lablibs/attn_$name.o
 b=motion324_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lablibs/libm324_$name.so tools/lablibs/attn_$name.o \

@@ -12,7 +12,7 @@ cd $d/motion324_amd/csrc
 objs=()
 for src in *.hip; do
     flags="-mllvm -amdgpu-mfma-vgpr-form"; [ "$src" = gemm_ring4.hip ] && flags=""
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $flags -c $src -o ${src%.hip}.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-slp-vectorize $flags -c $src -o ${src%.hip}.o &
     objs+=(${src%.hip}.o)
 done
 wait

@@ -5,9 +5,9 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/lablibs
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form "$@" \
     -c motion324_amd/csrc/gemm.hip -o tools/lablibs/gemm_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-slp-vectorize "$@" \
     -c motion324_amd/csrc/gemm_ring4.hip -o tools/lablibs/gemm_ring4_$name.o
 b=motion324_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lablibs/libm324_$name.so tools/lablibs/gemm_$name.o \
