@@ -71,5 +71,26 @@ def build(verbose: bool = False, force: bool = False) -> str:
     return LIB
 
 
+def assembly(sources=None) -> dict:
+    """Device assembly (.s) of the given translation units with the build's flags, for the static audits under tools/:
+    csrc/build/asm/<name>.s, rebuilt only when stale, four compilations at a time."""
+    adir = os.path.join(OBJ, "asm")
+    os.makedirs(adir, exist_ok=True)
+    hipcc = _hipcc()
+    out, jobs = {}, []
+    for src in (sources or SOURCES):
+        s = os.path.join(CSRC, src)
+        a = os.path.join(adir, src.replace(".hip", ".s"))
+        out[src] = a
+        if _stale(a, [s, os.path.abspath(__file__)] + HEADERS):
+            flags = [f for f in FLAGS_OF.get(src, FLAGS) if f not in ("-fPIC", "-Wall")]
+            jobs.append([hipcc] + flags + ["--cuda-device-only", "-S", "-o", a, s])
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+            if r.returncode != 0:
+                raise RuntimeError("hipcc -S failed:\n" + r.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build(verbose=True, force="--force" in sys.argv))

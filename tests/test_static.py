@@ -14,3 +14,13 @@ def test_lds_dma_kernels_wait_for_their_tiles_before_every_barrier():
     tiles by LDS-DMA needs an explicit vmcnt wait (tools/audit_barriers.py reads the generated assembly)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_barriers.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_no_packed_fp32_instruction_consumes_a_fresh_dpp_move():
+    """v_mov_b32_dpp + v_pk_add_f32 (what the SLP vectoriser makes of two interleaved `v += dpp(v)` butterflies) returned wrong
+    sums on MI355X beside a chunk-ring GEMM on the same CUs (round 3); the build's -fno-slp-vectorize keeps
+    every step one v_add_f32_dpp.  tools/audit_dpp.py compiles every translation unit with the build's flags and scans for the pair."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_dpp.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from motion324_amd import build
+    assert "-fno-slp-vectorize" in build.FLAGS and "-fno-slp-vectorize" in build.FLAGS_OF["gemm_ring4.hip"]

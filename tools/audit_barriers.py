@@ -2,17 +2,19 @@
 """Static check of the compiled kernels: every s_barrier of a kernel that stages tiles by LDS-DMA (global_load_lds) must
 have a vmcnt wait in the 14 instructions before it -- __syncthreads() alone does NOT make the compiler wait for an
 in-flight LDS-DMA (round 1: the attention dQ kernel read a stage that had not landed).
-usage: tools/audit_barriers.py   (compiles motion324_amd/csrc/{gemm,gemm_ring4,attention}.hip to assembly with hipcc)"""
-import os, re, subprocess, sys, tempfile
+usage: tools/audit_barriers.py   (reads the assembly motion324_amd.build.assembly() keeps under csrc/build/asm)"""
+import os, re, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from motion324_amd import build as B
+
 bad_total = 0
-for src in ("gemm.hip", "gemm_ring4.hip", "attention.hip"):
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        form = [] if src == "gemm_ring4.hip" else ["-mllvm", "-amdgpu-mfma-vgpr-form"]     # as motion324_amd/build.py
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize"] + form + ["--cuda-device-only", "-S", "-o", out, os.path.join(root, "motion324_amd", "csrc", src)],
-                       check=True, stderr=subprocess.DEVNULL)
+SRCS = ("gemm.hip", "gemm_ring4.hip", "attention.hip")
+asm = B.assembly(SRCS)
+for src in SRCS:
+    if True:
+        out = asm[src]
         kernels, name = {}, None
         for line in open(out):
             m = re.match(r"^(_ZN\S+):", line)

@@ -3,8 +3,8 @@
 GEMM on the same CUs (round 3): a packed-fp32 instruction (v_pk_*_f32) that reads a register a DPP
 move (v_mov_b32_dpp) wrote within the last few instructions.  `v += dpp(v)` must compile to ONE v_add_f32_dpp; the build's
 -fno-slp-vectorize keeps the compiler from splitting it.
-usage: tools/audit_dpp.py   (compiles every csrc/*.hip to assembly with the flags of motion324_amd/build.py)"""
-import os, re, subprocess, sys, tempfile
+usage: tools/audit_dpp.py   (reads the assembly motion324_amd.build.assembly() keeps under csrc/build/asm)"""
+import os, re, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -12,12 +12,10 @@ from motion324_amd import build as B
 
 WINDOW = 6
 bad_total = 0
+asm = B.assembly()
 for src in B.SOURCES:
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        flags = [f for f in B.FLAGS_OF.get(src, B.FLAGS) if f not in ("-fPIC", "-Wall")]
-        subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-S", "-o", out, os.path.join(B.CSRC, src)], check=True,
-                       stderr=subprocess.DEVNULL)
+    if True:
+        out = asm[src]
         name, recent, n_pk, n_dppmov = None, [], 0, 0
         for line in open(out):
             m = re.match(r"^(_Z\S+):", line)
