@@ -505,18 +505,38 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dq_mfma_kernel(const bf16_t
         const unsigned char* sk = smem + (t & 1) * 24576;
         const unsigned char* sv = sk + 8192;
         const unsigned char* skt = sk + 16384;
+        // eight waves (one workgroup per CU): all fragments of a phase in flight before its first MFMA, as in the dK / dV kernel
+        constexpr bool PRE = NWV == 8;
         f32x16 s[2], dp[2];
+        bf16x8 fr[16], ft[8];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                fr[i] = *reinterpret_cast<const bf16x8*>((i & 1 ? sv : sk) + k_off((i >> 3) * 32 + l31, ((i >> 1) & 3) * 2 + hi));
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = -l2, dp[kb][r] = -dl;      // S - lse and dP - D straight from the MFMA
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + k_off(kb * 32 + l31, ks * 2 + hi));
+                bf16x8 kf, vf;
+                if constexpr (PRE) {
+                    kf = fr[kb * 8 + ks * 2], vf = fr[kb * 8 + ks * 2 + 1];
+                } else {
+                    kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
+                    vf = *reinterpret_cast<const bf16x8*>(sv + k_off(kb * 32 + l31, ks * 2 + hi));
+                }
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
                 dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kb], 0, 0, 0);
             }
+        }
+        if constexpr (PRE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ft[i] = *reinterpret_cast<const bf16x8*>(skt + k_off((i & 1) * 32 + l31, 2 * (i >> 1) + hi));
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int kv0 = t * KV;
         const bool ragged = kv0 + KV > Lk;
@@ -534,7 +554,9 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dq_mfma_kernel(const bf16_t
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(skt + k_off(db * 32 + l31, 2 * j + hi));
+                bf16x8 ktf;
+                if constexpr (PRE) ktf = ft[j * 2 + db];
+                else ktf = *reinterpret_cast<const bf16x8*>(skt + k_off(db * 32 + l31, 2 * j + hi));
                 acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[j], acc[db], 0, 0, 0);
             }
     }
@@ -551,7 +573,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
                                                                 const bf16_t* __restrict__ dOt, const float* __restrict__ lse,
                                                                 const float* __restrict__ D, bf16_t* __restrict__ dK,
                                                                 bf16_t* __restrict__ dV, int H, int Lq, int Lk, int Lqp) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * 8192];   // [stage][Qs | dO | Qst | dOt]
+    // [stage][Qs | dO | Qst | dOt], then [stage][lse of the tile's 64 queries | D]: the two row vectors ride with the tile
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 4 * 8192 + 2 * 512];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -581,6 +604,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
         dma_rows<NWV>(st + 8192, dOh, 64, t * KV, Lq - 1, 0, wave, lane);
         dma_rows<NWV>(st + 16384, Qth, Lqp, 0, 63, (long)t * KV, wave, lane);
         dma_rows<NWV>(st + 24576, dOth, Lqp, 0, 63, (long)t * KV, wave, lane);
+        // lse / D of the tile's queries: one 4-byte-per-lane LDS-DMA each (256 B), by waves 0 and 1; queries past the end are
+        // clamped here and masked where they are used
+        if (wave < 2) {
+            const float* src = (wave == 0 ? lseh : Dh) + min(t * KV + lane, Lq - 1);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)src, (lds_ptr_t*)(smem + 65536 + (t & 1) * 512 + wave * 256), 4, 0, 0);
+        }
     };
     f32x16 ak[2], av[2];
 #pragma unroll
@@ -620,50 +649,65 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
         const unsigned char* sqt = sq + 16384;
         const unsigned char* sdot = sq + 24576;
         const int q0 = t * KV;
-        // The rows of S / dP (queries) run along the registers, so lse[q] and D[q] are 2 x 16 values per lane and tile.  They are
-        // REQUESTED here and USED behind the 16 MFMAs (S and dP start from the inline constant 0): as initial values of the
-        // accumulators -- round 2 -- the first MFMA of every tile waited out their whole L2 round trip, with two waves per SIMD
-        // to cover it.  Same instruction count: a subtraction per value instead of a negated move.
-        f32x16 s[2], dp[2], lv[2], dv[2];
+        // The rows of S / dP (queries) run along the registers, so lse[q] and D[q] are 2 x 16 values per lane and tile.  Round 2
+        // loaded them from global memory as the accumulators' initial values: the first MFMA of every tile waited out 16 L2
+        // round trips (in-kernel stamps, tools/attn_bwd_lab.py --trace: 6600 of a tile's 9500 cycles).  Now they arrive with
+        // the tile by LDS-DMA, S and dP start from the inline constant 0, and the two vectors are read (broadcast reads, 16
+        // bytes per lane) behind the 16 MFMAs -- a subtraction per value instead of a negated move, no register held across.
+        // Eight waves (one workgroup per CU, 256 registers per wave): all 16 fragments of a phase are in flight before its
+        // first MFMA, and the second phase's fragments are requested before the exponentials.  Read where the compiler puts
+        // them -- in front of each MFMA pair -- the 16 MFMAs of the dV / dK phase took 2200 cycles (stamps).
+        constexpr bool PRE = NWV == 8;
+        f32x16 s[2], dp[2];
+        bf16x8 fr[16], ft[16];
+        if constexpr (PRE) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int qq = q0 + qb * 32 + 8 * g + 4 * hi;      // rows (r & 3) + 8 (r >> 2) + 4 hi of the accumulator
-                if (qq + 3 < Lq && (Lq & 3) == 0) {                 // aligned run of 4 queries: one 16-byte load each
-                    const float4 l4 = *reinterpret_cast<const float4*>(lseh + qq);
-                    const float4 d4 = *reinterpret_cast<const float4*>(Dh + qq);
-                    lv[qb][g * 4 + 0] = l4.x; lv[qb][g * 4 + 1] = l4.y; lv[qb][g * 4 + 2] = l4.z; lv[qb][g * 4 + 3] = l4.w;
-                    dv[qb][g * 4 + 0] = d4.x; dv[qb][g * 4 + 1] = d4.y; dv[qb][g * 4 + 2] = d4.z; dv[qb][g * 4 + 3] = d4.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool ok = qq + e < Lq;
-                        lv[qb][g * 4 + e] = ok ? lseh[qq + e] : INFINITY;        // query past the end: P = exp2(-inf) = 0
-                        dv[qb][g * 4 + e] = ok ? Dh[qq + e] : 0.f;
-                    }
-                }
-            }
+            for (int i = 0; i < 16; ++i)
+                fr[i] = *reinterpret_cast<const bf16x8*>((i & 1 ? sdo : sq) + k_off((i >> 3) * 32 + l31, ((i >> 1) & 3) * 2 + hi));
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[qb][r] = 0.f, dp[qb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(sq + k_off(qb * 32 + l31, ks * 2 + hi));
-                const bf16x8 dfr = *reinterpret_cast<const bf16x8*>(sdo + k_off(qb * 32 + l31, ks * 2 + hi));
+                bf16x8 qfr, dfr;
+                if constexpr (PRE) {
+                    qfr = fr[qb * 8 + ks * 2], dfr = fr[qb * 8 + ks * 2 + 1];
+                } else {
+                    qfr = *reinterpret_cast<const bf16x8*>(sq + k_off(qb * 32 + l31, ks * 2 + hi));
+                    dfr = *reinterpret_cast<const bf16x8*>(sdo + k_off(qb * 32 + l31, ks * 2 + hi));
+                }
                 s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], s[qb], 0, 0, 0);
                 dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr, vf[ks], dp[qb], 0, 0, 0);
             }
         }
+        if constexpr (PRE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)          // order of use: (j, db, dOt | Qst)
+                ft[i] = *reinterpret_cast<const bf16x8*>((i & 1 ? sqt : sdot) + k_off(((i >> 1) & 1) * 32 + l31, 2 * (i >> 2) + hi));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         BTRACE(t, 4);
+        const float* rowv = reinterpret_cast<const float*>(smem + 65536 + (t & 1) * 512);
+        const bool ragged = q0 + KV > Lq;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[qb][r] - lv[qb][r]);
-                s[qb][r] = p;
-                dp[qb][r] = p * (dp[qb][r] - dv[qb][r]);
+            for (int g = 0; g < 4; ++g) {
+                const int qi = qb * 32 + 8 * g + 4 * hi;             // accumulator rows (r & 3) + 8 (r >> 2) + 4 hi
+                const float4 l4 = *reinterpret_cast<const float4*>(rowv + qi);
+                const float4 d4 = *reinterpret_cast<const float4*>(rowv + 64 + qi);
+                const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float p = __builtin_amdgcn_exp2f(s[qb][g * 4 + e] - lq[e]);
+                    if (ragged && q0 + qi + e >= Lq) p = 0.f;       // query past the end (wave-uniform outer condition)
+                    s[qb][g * 4 + e] = p;
+                    dp[qb][g * 4 + e] = p * (dp[qb][g * 4 + e] - dq[e]);
+                }
             }
         bf16x8 pf[4], dsf[4];
         pack_frags(s, pf);
@@ -673,8 +717,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const bf16x8 dotf = *reinterpret_cast<const bf16x8*>(sdot + k_off(db * 32 + l31, 2 * j + hi));
-                const bf16x8 qtf = *reinterpret_cast<const bf16x8*>(sqt + k_off(db * 32 + l31, 2 * j + hi));
+                bf16x8 dotf, qtf;
+                if constexpr (PRE) {
+                    dotf = ft[j * 4 + db * 2], qtf = ft[j * 4 + db * 2 + 1];
+                } else {
+                    dotf = *reinterpret_cast<const bf16x8*>(sdot + k_off(db * 32 + l31, 2 * j + hi));
+                    qtf = *reinterpret_cast<const bf16x8*>(sqt + k_off(db * 32 + l31, 2 * j + hi));
+                }
                 av[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf[j], av[db], 0, 0, 0);
                 ak[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[j], ak[db], 0, 0, 0);
             }
@@ -910,10 +959,14 @@ extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_b
     M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && H <= 65535 && B <= 65535, "m324_attention_bwd_mfma: bad sizes");
     const int Lkp = (Lk + 63) / 64 * 64, Lqp = (Lq + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
-    // M324_ATTN_BWD_NW=8 (read per call) selects eight waves per workgroup: every staged tile then feeds 256 instead of
-    // 128 rows (half the LDS-DMA pieces per FLOP).  Unlike the forward it measured 0.7 % SLOWER on the training step
-    // (B = 8, L = 3888), so four waves stay the default.
-    const bool w8 = m324::tunable(m324::TUN_ATTN_BWD_NW) == 8;
+    // Eight waves per workgroup for key sets of 1024 and more (the per-frame blocks' 324 keys would leave most of a second
+    // 256-key workgroup idle: the whole step measured 1 % slower with it) (M324_ATTN_BWD_NW=4|8 forces one form: A/B runs, tests): every
+    // staged tile then feeds 256 instead of 128 rows -- half the LDS-DMA pieces per wave and tile, which cost ~70 cycles of issue
+    // each (stamps: 660 cycles for a wave's nine pieces) -- and the dK / dV kernel, alone on its CU with 256 registers per wave,
+    // keeps all 16 fragments of a phase in flight.  Round 2 measured the 8-wave form 0.7 % slower; that was while every tile
+    // waited ~6600 cycles for its lse / D loads.  Now: dQ + dK/dV at B = 8, L = 3888: 1552 us against 1724 (round 2: 2270).
+    const int fbw = m324::tunable(m324::TUN_ATTN_BWD_NW);
+    const bool w8 = fbw ? fbw == 8 : Lk >= 1024;
     if (w8) {
         hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<8>, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
                            q_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D,

@@ -35,7 +35,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_ATTN_FLAT": ("1", "XCD-aware flat grid: 1 = global and per-frame attention, 2 = the 8-wave global attention only, 0 = 3-D grid"),
     "M324_ATTN_OCC": ("0", "attention: occupancy hint"),
     "M324_ATTN_NQ2": ("0", "attention: 64 queries per wave"),
-    "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup"),
+    "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup (4 | 8); 0 = 8 from 256 keys on"),
     "M324_ATTN_EXP": ("0", "attention: static priority for the younger half of an 8-wave workgroup"),
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
 }

@@ -281,7 +281,7 @@ def test_cross_attn_block_backward_vs_oracle_autograd(dtype, shared):
                                                (1, 12, 324, 324, False), (1, 2, 700, 129, False)])
 def test_attention_backward_mfma_against_autograd(tune, nw, B, H, Lq, Lk, shared):
     """bf16 MFMA backward kernels (through qkv_split's train outputs) vs fp64 autograd and vs the reference kernels;
-    both workgroup sizes (M324_ATTN_BWD_NW; 4 waves is the default)."""
+    both workgroup sizes (M324_ATTN_BWD_NW; default: 8 waves from 256 keys on)."""
     from motion324_amd import ops
     tune("M324_ATTN_BWD_NW", nw)
     dtype = torch.bfloat16
