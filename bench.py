@@ -476,13 +476,17 @@ def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 5 * 1e3
         fwd = algorithmic_flops(Bt, T, N, N)
-        # executed FLOPs of a step ~ forward + recompute of the trainable part + 2 x its backward (DINO: forward only)
+        # executed FLOPs of a step = forward + 2 x backward of the trainable part (its internals are kept, not recomputed:
+        # motion324_amd/training.py, M324_TRAIN_STORE; with =0 a fourth, recompute pass runs) + the frozen DINO forward
         dino = algorithmic_flops(Bt, T, N, N) - algorithmic_flops(Bt, T, N, N, dino_depth=0)
-        step_flops = dino + 4.0 * (fwd - dino)
+        kept = training.TRAIN_STORE != "0"
+        step_flops = dino + (3.0 if kept else 4.0) * (fwd - dino)
         res = {"value": round(Bt / ms * 1e3, 2), "unit": "samples/s", "ms_per_step": round(ms, 2), "batch_size_per_gpu": Bt,
                "forward_tflop_per_step": round(fwd / 1e12, 2), "tflops": round(step_flops / ms / 1e9, 1),
                "frac_of_bf16_peak": round(step_flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
-               "flop_model": "DINO forward + 4 x trainable forward (forward, recompute, 2 x backward)",
+               "flop_model": ("DINO forward + 3 x trainable forward (forward with kept internals, 2 x backward)" if kept else
+                              "DINO forward + 4 x trainable forward (forward, recompute, 2 x backward)"),
+               "activations": "kept in HBM while they fit half of the free memory" if kept else "checkpoint per block + recompute",
                "loss": round(float(losses[-1]), 6), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
         del tm, opt, smp
         return res
@@ -762,8 +766,10 @@ def run_train(args, D: Dist):
                 "losses": [round(float(x), 6) for x in losses[-min(6, len(losses)):]],
                 "grad_norm": round(infos[-1]["grad_norm"], 4), "skipped_steps": sum(1 for i in infos if i["skipped"]),
                 "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                "activations": ("block internals kept in HBM while they fit half of the free memory (M324_TRAIN_STORE=1)"
+                                if training.TRAIN_STORE != "0" else "checkpoint per block + recompute (M324_TRAIN_STORE=0)"),
                 "roofline": roofline_from(rec, 1, args.precision, "HIP events around every GEMM / attention-forward launch of one extra "
-                                          "training step (forward, recompute, dgrad, wgrad; the attention backward kernels are "
+                                          "training step (forward, dgrad, wgrad; the attention backward kernels are "
                                           f"not in the classes); symbols as in profiles/{PROFILE_ROUND}_p3_train_kernel_stats.md"),
                 "cpu_baseline": None}
     return line

@@ -1,7 +1,8 @@
 """Backward passes of the blocks, built from libm324 kernels (no torch autograd inside).
 
-Every function takes the block's saved INPUT (fp32 residual stream), recomputes the block's internal activations
-(the reference trains with activation checkpointing per block, Pcd_motion.py:375-448 -- same memory policy) and
+Every function takes the block's saved INPUT (fp32 residual stream) and either the block's internal activations kept by
+the forward or nothing -- then it recomputes them (the reference trains with activation checkpointing per block,
+Pcd_motion.py:375-448: a memory policy for 40-80 GB devices; training.py keeps the internals when they fit) -- and
 returns the gradient w.r.t. the input; parameter gradients are accumulated into a GradStore in fp32.
 
 Backward GEMMs reuse m324_gemm on transposed operands (include/m324.h "Training-side entry points"):
@@ -128,15 +129,25 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
     return da
 
 
-def mlp_residual_bwd(P: Prepared, G: GradStore, norm2, mlp, x_mid: torch.Tensor, dx: torch.Tensor) -> None:
-    """x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))).  dx (fp32): grad w.r.t. x_out on entry, w.r.t. x_mid on exit."""
+def mlp_internals(P: Prepared, norm2, mlp, x_mid: torch.Tensor) -> dict:
+    """h2 = LN2(x_mid), z = fc1(h2) + b, g = gelu(z): what the MLP half's backward reads (one LayerNorm, one GEMM launch)."""
     rows, C = x_mid.shape
-    fc1, fc2 = mlp.mlp[0], mlp.mlp[2]
-    h2 = torch.empty((rows, C), dtype=P.dtype, device=dx.device)
+    fc1 = mlp.mlp[0]
+    h2 = torch.empty((rows, C), dtype=P.dtype, device=x_mid.device)
     ops.layernorm(x_mid, P.vec(norm2.weight), P.vec(norm2.bias), norm2.eps, h2)
-    z = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=dx.device)
+    z = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=x_mid.device)
     g = torch.empty_like(z)
     ops.gemm(h2, P.mat(fc1.weight), g, bias=P.vec(fc1.bias), act=ACT_GELU, preact_out=z)     # g = gelu(z) and z in one launch
+    return dict(h2=h2, z=z, g=g)
+
+
+def mlp_residual_bwd(P: Prepared, G: GradStore, norm2, mlp, x_mid: torch.Tensor, dx: torch.Tensor,
+                     saved: Optional[dict] = None) -> None:
+    """x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))).  dx (fp32): grad w.r.t. x_out on entry, w.r.t. x_mid on exit.
+    saved: mlp_internals() of the forward (None: recomputed here)."""
+    fc1, fc2 = mlp.mlp[0], mlp.mlp[2]
+    m = saved if saved is not None else mlp_internals(P, norm2, mlp, x_mid)
+    h2, z, g = m["h2"], m["z"], m["g"]
     dxT = ops.cast(dx, P.dtype)
     dz = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT, gelu_grad_of=z)                      # (dxT W2) * gelu'(z)
     dh2 = linear_bwd(P, G, fc1.weight, fc1.bias, h2, dz)
@@ -145,13 +156,15 @@ def mlp_residual_bwd(P: Prepared, G: GradStore, norm2, mlp, x_mid: torch.Tensor,
     G.add(norm2.bias, db)
 
 
-def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: torch.Tensor, B: int, L: int) -> None:
-    """Backward of QK_Norm_TransformerBlock.run.  dx: grad w.r.t. the block output on entry, w.r.t. x_in on exit."""
+def self_attn_block_internals(blk, P: Prepared, x_in: torch.Tensor, B: int, L: int, x_out: Optional[torch.Tensor] = None) -> dict:
+    """Everything the backward of QK_Norm_TransformerBlock reads, computed from the block's input (fp32 residual stream).
+    Two uses: the backward's recompute (x_out None: the last GEMM, fc2, is not needed), and -- when memory allows, which on
+    288 GB it does -- the training FORWARD itself (x_out: fp32 buffer for the block's output), so that the backward finds the
+    internals in HBM instead of computing them a second time (training.py, M324_TRAIN_STORE)."""
     rows, C = x_in.shape
     a = blk.attn
     H = a.num_heads
-    dev = dx.device
-    # ---- recompute the attention half
+    dev = x_in.device
     h1 = torch.empty((rows, C), dtype=P.dtype, device=dev)
     ops.layernorm(x_in, P.vec(blk.norm1.weight), P.vec(blk.norm1.bias), blk.norm1.eps, h1)
     qkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=dev)
@@ -164,8 +177,27 @@ def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: 
     ops.attention(sp["Q"], sp["K"], sp["Vt"], o, prescaled=True, lse=lse)
     x_mid = torch.empty((rows, C), dtype=torch.float32, device=dev)
     ops.gemm(o, P.mat(a.fc.weight), x_mid, bias=P.vec(a.fc.bias), residual=x_in)
+    m = mlp_internals(P, blk.norm2, blk.mlp, x_mid)
+    if x_out is not None:
+        fc2 = blk.mlp.mlp[2]
+        ops.gemm(m["g"], P.mat(fc2.weight), x_out, bias=P.vec(fc2.bias), residual=x_mid)
+    return dict(h1=h1, qkv=qkv, sp=sp, o=o, lse=lse, x_mid=x_mid, mlp=m)
+
+
+def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: torch.Tensor, B: int, L: int,
+                        saved: Optional[dict] = None) -> None:
+    """Backward of QK_Norm_TransformerBlock.run.  dx: grad w.r.t. the block output on entry, w.r.t. x_in on exit.
+    saved: self_attn_block_internals() of the forward (None: recomputed from x_in, the reference's checkpoint policy)."""
+    rows, C = x_in.shape
+    a = blk.attn
+    H = a.num_heads
+    dev = dx.device
+    s = saved if saved is not None else self_attn_block_internals(blk, P, x_in, B, L)
+    h1, qkv, sp, o, lse, x_mid = s["h1"], s["qkv"], s["sp"], s["o"], s["lse"], s["x_mid"]
+    qw, kw = a._qk_w(P)
     # ---- MLP half
-    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx)                     # dx = d x_mid
+    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx, saved=s["mlp"])     # dx = d x_mid
+    s["mlp"] = None
     # ---- attention half
     dxT = ops.cast(dx, P.dtype)
     do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)
@@ -183,20 +215,14 @@ def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: 
     G.add(blk.norm1.bias, db)
 
 
-def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv: torch.Tensor, dx: torch.Tensor, B: int,
-                         Lq: int, Lk: int, kv_row_map=(0, 0, 0), shared_q: bool = False, d_kv: Optional[torch.Tensor] = None,
-                         need_dquery: bool = True) -> Optional[torch.Tensor]:
-    """Backward of QK_Norm_CrossAttentionBlock (project_q + project_kv + attend).
-
-    query fp32 [Bq*Lq, C] (Bq = 1 when shared_q: one query set for all B key/value batches, the decoder case);
-    kv fp32 rows read through kv_row_map; dx fp32 [B*Lq, C] = grad w.r.t. the block output (consumed).
-    d_kv: fp32 buffer shaped like kv that receives (+=) the gradient of the key/value rows (None: not needed).
-    Returns the gradient w.r.t. query (fp32 [Bq*Lq, C]) or None."""
+def cross_attn_block_internals(blk, P: Prepared, query: torch.Tensor, kv: torch.Tensor, B: int, Lq: int, Lk: int,
+                                kv_row_map=(0, 0, 0), shared_q: bool = False, x_out: Optional[torch.Tensor] = None) -> dict:
+    """Everything the backward of QK_Norm_CrossAttentionBlock reads, from the block's inputs (see
+    self_attn_block_internals: the backward's recompute, or -- with x_out -- the training forward that keeps it)."""
     a = blk.attn
     C, H = a.dim, a.num_heads
-    dev = dx.device
+    dev = query.device
     Bq = 1 if shared_q else B
-    # ---- recompute
     qn = torch.empty((Bq * Lq, C), dtype=P.dtype, device=dev)
     ops.layernorm(query, P.vec(blk.norm_q.weight), P.vec(blk.norm_q.bias), blk.norm_q.eps, qn)
     qp = torch.empty((Bq * Lq, C), dtype=P.dtype, device=dev)
@@ -214,8 +240,34 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
     ops.attention(spq["Q"], spk["K"], spk["Vt"], o, shared_q=shared_q, prescaled=True, lse=lse)
     x_mid = torch.empty((B * Lq, C), dtype=torch.float32, device=dev)
     ops.gemm(o, P.mat(a.fc.weight), x_mid, bias=P.vec(a.fc.bias), residual=query, res_rows=Lq if shared_q else 0)
+    m = mlp_internals(P, blk.norm2, blk.mlp, x_mid)
+    if x_out is not None:
+        fc2 = blk.mlp.mlp[2]
+        ops.gemm(m["g"], P.mat(fc2.weight), x_out, bias=P.vec(fc2.bias), residual=x_mid)
+    return dict(qn=qn, qp=qp, spq=spq, kn=kn, kvp=kvp, spk=spk, o=o, lse=lse, x_mid=x_mid, mlp=m)
+
+
+def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv: torch.Tensor, dx: torch.Tensor, B: int,
+                         Lq: int, Lk: int, kv_row_map=(0, 0, 0), shared_q: bool = False, d_kv: Optional[torch.Tensor] = None,
+                         need_dquery: bool = True, saved: Optional[dict] = None) -> Optional[torch.Tensor]:
+    """Backward of QK_Norm_CrossAttentionBlock (project_q + project_kv + attend).
+
+    query fp32 [Bq*Lq, C] (Bq = 1 when shared_q: one query set for all B key/value batches, the decoder case);
+    kv fp32 rows read through kv_row_map; dx fp32 [B*Lq, C] = grad w.r.t. the block output (consumed).
+    d_kv: fp32 buffer shaped like kv that receives (+=) the gradient of the key/value rows (None: not needed).
+    saved: cross_attn_block_internals() of the forward (None: recomputed here).
+    Returns the gradient w.r.t. query (fp32 [Bq*Lq, C]) or None."""
+    a = blk.attn
+    C, H = a.dim, a.num_heads
+    dev = dx.device
+    Bq = 1 if shared_q else B
+    s = saved if saved is not None else cross_attn_block_internals(blk, P, query, kv, B, Lq, Lk, kv_row_map, shared_q)
+    qn, qp, spq, kn, kvp, spk, o, lse, x_mid = (s[k] for k in ("qn", "qp", "spq", "kn", "kvp", "spk", "o", "lse", "x_mid"))
+    qw, kw = a._qk_w(P)
+    w_kv = P.cat_rows((a.to_k.weight, a.to_v.weight))
     # ---- MLP half
-    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx)                     # dx = d x_mid  [B*Lq, C]
+    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx, saved=s["mlp"])     # dx = d x_mid  [B*Lq, C]
+    s["mlp"] = None
     # ---- attention half
     dxT = ops.cast(dx, P.dtype)
     do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)

@@ -15,6 +15,7 @@ import torch
 
 from . import backward as bw
 from . import ops
+from . import switches
 from .image_encoder import DINO_EPS
 from .lib import ACT_GELU, M324Error
 from .prepared import Prepared, compute_dtype, pad_k
@@ -43,6 +44,19 @@ def _point_features_bwd(model, P: Prepared, G: bw.GradStore, enc, feat, d_pf: to
                           ops.cast(d_pf, P.dtype))
     demb = ops.cast(dfeat[:, :C], P.dtype)                     # contiguous copy of the embedding columns
     bw.linear_bwd(P, G, model.point_embed.mlp.weight, model.point_embed.mlp.bias, enc, demb, need_da=False)
+
+
+TRAIN_STORE = switches.get("M324_TRAIN_STORE")             # "1": keep block internals while they fit, "0": always recompute
+
+
+def _store_budget(dev: torch.device) -> int:
+    """Bytes the forward may spend on kept block internals: half of what is free now (the backward's own work buffers,
+    the decoder and the gradient buckets need the rest); 0 with M324_TRAIN_STORE=0."""
+    if TRAIN_STORE == "0":
+        return 0
+    free, _ = torch.cuda.mem_get_info(dev)
+    reserved_free = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # cached by torch's allocator
+    return int(0.5 * (free + reserved_free))
 
 
 def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None,
@@ -100,12 +114,26 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     ln_in = model.transformer_input_layernorm
     tok = ops.assemble_tokens(dino_x, P.vec(enc_m.norm.weight), P.vec(enc_m.norm.bias), DINO_EPS, pos, sp0, spr, mesh,
                               P.vec(ln_in.weight), ln_in.eps, B, T, K, Pn, drop_p, drop_seed)
-    trunk_in = []
+    # Trunk: the reference checkpoints every block (its memory policy on 40-80 GB devices) and pays a second forward in the
+    # backward.  With 288 GB the forward keeps each block's internals instead (bw.self_attn_block_internals: LN outputs,
+    # q|k|v in both layouts, attention output + LSE, MLP pre-activation: ~37 KB per token and block = 1.15 GB per block at
+    # B = 8, 28 GB for the 24 trunk blocks) while they fit a budget; blocks past the budget fall back to the checkpoint.
+    trunk_in, trunk_saved = [], []
+    rows_tok = tok.shape[0]
+    per_block = rows_tok * C * 50                            # bytes, upper bound of one block's kept tensors
+    budget = _store_budget(dev)
     for gblk, lblk in zip(model.global_transformer_blocks, model.local_transformer_blocks):
-        trunk_in.append(tok.clone())
-        gblk.run(P, tok, B, T * Lt)
-        trunk_in.append(tok.clone())
-        lblk.run(P, tok, B * T, Lt)
+        for blk, (Bb, Lb) in ((gblk, (B, T * Lt)), (lblk, (B * T, Lt))):
+            if budget >= per_block:
+                budget -= per_block
+                nxt = torch.empty_like(tok)
+                trunk_saved.append(bw.self_attn_block_internals(blk, P, tok, Bb, Lb, x_out=nxt))
+                trunk_in.append(tok)
+                tok = nxt
+            else:
+                trunk_saved.append(None)
+                trunk_in.append(tok.clone())
+                blk.run(P, tok, Bb, Lb)
 
     dec = model.decoder_cross_attn
     head_ln, head_fc1, head_fc2 = model.shared_mlp_output[0], model.shared_mlp_output[1], model.shared_mlp_output[3]
@@ -113,18 +141,32 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     out = torch.empty((B, T, N, 3), dtype=torch.float32, device=dev)
     pcd, nrm, rgb = (_f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
     dec_saved = []
+    per_dec = T * N * C * 30                                  # bytes kept per sample: decoder block internals + head
     for b in range(B):
         pf, enc_p, feat_p = _point_features_train(model, P, pcd[b], nrm[b].contiguous(), rgb[b].contiguous())
         tok_b = tok[b * T * Lt:(b + 1) * T * Lt]
-        Q = dec.project_q(P, pf, 1, N)
-        Kd, Vd = dec.project_kv(P, tok_b, T, K, row_map=(K, Lt, 4))
-        x = dec.attend(P, Q, Kd, Vd, pf, N, shared_q=True)                            # fp32 [T*N, C]
+        keep = budget >= per_dec
+        if keep:                                              # same policy as the trunk: internals kept while they fit
+            budget -= per_dec
+            x = torch.empty((T * N, C), dtype=torch.float32, device=dev)
+            sv = bw.cross_attn_block_internals(dec, P, pf, tok_b, T, N, K, kv_row_map=(K, Lt, 4), shared_q=True, x_out=x)
+        else:
+            Q = dec.project_q(P, pf, 1, N)
+            Kd, Vd = dec.project_kv(P, tok_b, T, K, row_map=(K, Lt, 4))
+            x = dec.attend(P, Q, Kd, Vd, pf, N, shared_q=True)                        # fp32 [T*N, C]
+            sv = None
         h = torch.empty(x.shape, dtype=P.dtype, device=dev)
         ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
         h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
-        ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
+        if keep:
+            z2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
+            ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU, preact_out=z2)
+            head = (h, z2, h2)
+        else:
+            ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
+            head = None
         ops.linear_n3(h2, w3, b3, out[b])
-        dec_saved.append((pf, enc_p, feat_p, x))
+        dec_saved.append((pf, enc_p, feat_p, x, sv, head))
     target = _f32c(sample["point_clouds"])
     mse = ops.mse(out, target, 1.0)
     loss = mse * weight
@@ -133,14 +175,17 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     d_out = ops.mse_bwd(out, target, weight * grad_scale)                             # [B,T,N,3]
     d_tok = torch.zeros((B * T * Lt, C), dtype=torch.float32, device=dev)
     for b in range(B):
-        pf, enc_p, feat_p, x = dec_saved[b]
+        pf, enc_p, feat_p, x, sv, head = dec_saved[b]
         tok_b = tok[b * T * Lt:(b + 1) * T * Lt]
         # head: LN -> Linear -> GELU -> Linear(3)
-        h = torch.empty(x.shape, dtype=P.dtype, device=dev)
-        ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
-        z2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
-        ops.gemm(h, P.mat(head_fc1.weight), z2, bias=P.vec(head_fc1.bias))
-        h2 = ops.gelu(z2)
+        if head is not None:
+            h, z2, h2 = head
+        else:
+            h = torch.empty(x.shape, dtype=P.dtype, device=dev)
+            ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
+            z2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
+            ops.gemm(h, P.mat(head_fc1.weight), z2, bias=P.vec(head_fc1.bias))
+            h2 = ops.gelu(z2)
         dh2, dW3, db3 = ops.linear_n3_bwd(h2, w3, d_out[b])
         G.add(head_fc2.weight, dW3)
         G.add(head_fc2.bias, db3)
@@ -151,18 +196,22 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
         G.add(head_ln.weight, dw)
         G.add(head_ln.bias, db)
         d_pf = bw.cross_attn_block_bwd(dec, P, G, pf, tok_b, dx, T, N, K, kv_row_map=(K, Lt, 4), shared_q=True,
-                                       d_kv=d_tok[b * T * Lt:(b + 1) * T * Lt])
+                                       d_kv=d_tok[b * T * Lt:(b + 1) * T * Lt], saved=sv)
+        sv = head = None
         _point_features_bwd(model, P, G, enc_p, feat_p, d_pf)
         dec_saved[b] = None
     G.done(list(model.shared_mlp_output.parameters()) + list(dec.parameters()))
 
     n_pairs = len(model.global_transformer_blocks)
     for i in reversed(range(n_pairs)):
-        bw.self_attn_block_bwd(model.local_transformer_blocks[i], P, G, trunk_in[2 * i + 1], d_tok, B * T, Lt)
+        bw.self_attn_block_bwd(model.local_transformer_blocks[i], P, G, trunk_in[2 * i + 1], d_tok, B * T, Lt,
+                               saved=trunk_saved[2 * i + 1])
         G.done(model.local_transformer_blocks[i].parameters())
-        bw.self_attn_block_bwd(model.global_transformer_blocks[i], P, G, trunk_in[2 * i], d_tok, B, T * Lt)
+        trunk_saved[2 * i + 1] = None
+        bw.self_attn_block_bwd(model.global_transformer_blocks[i], P, G, trunk_in[2 * i], d_tok, B, T * Lt,
+                               saved=trunk_saved[2 * i])
         G.done(model.global_transformer_blocks[i].parameters())
-        trunk_in[2 * i + 1] = trunk_in[2 * i] = None
+        trunk_in[2 * i + 1] = trunk_in[2 * i] = trunk_saved[2 * i] = None
 
     # token assembly + input LayerNorm: recompute the un-normalised concatenation, LN backward over every row (the LN
     # weight sees the video rows too), then fold the rows that carry parameters / the mesh latents

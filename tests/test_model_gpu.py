@@ -546,6 +546,43 @@ def test_training_gradients_match_oracle_autograd(precision, tol, drop):
     assert worst[0][1] < tol, worst
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_kept_internals_and_recompute_give_the_same_step(precision, monkeypatch):
+    """The training forward keeps every block's internals while they fit its memory budget (training.py, M324_TRAIN_STORE;
+    97.8 ms per step at dyscene.yaml shapes against 115 ms with the reference's checkpoint-and-recompute policy); a block past
+    the budget is checkpointed and recomputed in the backward.  All three forms -- everything kept, nothing kept, a budget that
+    runs out in the middle of the trunk -- must deliver the same loss, outputs and gradients (same kernels on the same
+    inputs; only the GELU of the kept forward comes from the fp32 accumulator instead of the rounded pre-activation)."""
+    import motion324_amd as m
+    from motion324_amd import synth, training
+    model, dm = build("tiny")
+    model.train()
+    model.drop_rate = 0.0
+    B, T, N, S, HW = 2, 3, 40, 100, 64
+    s_np = synth.synth_inputs(B, T, N, S, HW, seed=1, with_target=True)
+    sample = {k: torch.from_numpy(v).cuda() for k, v in s_np.items()}
+    runs = {}
+    m.set_precision(precision)
+    try:
+        for mode in ("keep", "recompute", "half"):
+            monkeypatch.setattr(training, "TRAIN_STORE", "0" if mode == "recompute" else "1")
+            if mode == "half":                                # budget for three trunk blocks only, none for the decoder
+                Lt = 4 + model.num_learnable_tokens + model.num_patches_h * model.num_patches_w
+                monkeypatch.setattr(training, "_store_budget", lambda dev: 3 * B * T * Lt * model.embed_dim * 50 + 1)
+            loss, out, G = training.forward_backward(model, sample)
+            torch.cuda.synchronize()
+            runs[mode] = (float(loss), out.clone(), {n: G.get(p).clone() for n, p in model.named_parameters() if p.requires_grad})
+    finally:
+        m.set_precision(None)
+    tol = 1e-6 if precision == "fp32" else 6e-3
+    for mode in ("recompute", "half"):
+        assert abs(runs[mode][0] - runs["keep"][0]) <= tol * abs(runs["keep"][0])
+        assert rel_err(runs[mode][1], runs["keep"][1]) <= tol
+        worst = max(rel_err(g, runs["keep"][2][n]) for n, g in runs[mode][2].items())
+        assert worst <= (1e-5 if precision == "fp32" else 2e-2), (mode, worst)
+    assert len(runs["keep"][2]) == len(runs["recompute"][2]) >= 60
+
+
 def test_training_mode_dropout_is_seeded_by_torch_and_off_in_eval():
     """pos_drop: p = transformer.drop_rate in train(), identity in eval(); the mask follows torch.manual_seed."""
     from motion324_amd import synth
