@@ -546,6 +546,41 @@ def test_training_gradients_match_oracle_autograd(precision, tol, drop):
     assert worst[0][1] < tol, worst
 
 
+def test_two_clips_in_flight_reproduce_the_solo_result_bit_for_bit():
+    """Whatever shares the CUs, a kernel must compute what it computes alone.  Round 3 found a violation (a DPP move feeding a
+    packed-fp32 add beside a chunk-ring GEMM: DESIGN.md section 6, tools/ln_stress.py); this is the model-level guard: the
+    full-size c1 clip as two hipGraphs replayed at the same time on two streams, 12 rounds, every output compared with the
+    graph's own solo replay.  (Kernels of the two clips interleave on the chip in ever different ways.)"""
+    import motion324_amd as m
+    model, dm = build("c1")
+    sample = inputs("c1", with_target=False)
+    m.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            fa, fb = m.GraphedForward(model, warmup=1), m.GraphedForward(model, warmup=1)
+            ca, cb = fa.static_inputs(sample), fb.static_inputs(sample)
+            solo_a = fa(ca)["pcd_moved"].clone()
+            solo_b = fb(cb)["pcd_moved"].clone()
+            torch.cuda.synchronize()
+            assert torch.equal(solo_a, solo_b)
+            sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+            bad = 0
+            for rnd in range(12):
+                sa.wait_stream(torch.cuda.current_stream())
+                sb.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(sa):
+                    oa = fa(ca)["pcd_moved"]
+                with torch.cuda.stream(sb):
+                    ob = fb(cb)["pcd_moved"]
+                torch.cuda.current_stream().wait_stream(sa)
+                torch.cuda.current_stream().wait_stream(sb)
+                torch.cuda.synchronize()
+                bad += int(not torch.equal(oa, solo_a)) + int(not torch.equal(ob, solo_a))
+    finally:
+        m.set_precision(None)
+    assert bad == 0, f"{bad} of 24 concurrent replays differ from the solo replay"
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_kept_internals_and_recompute_give_the_same_step(precision, monkeypatch):
     """The training forward keeps every block's internals while they fit its memory budget (training.py, M324_TRAIN_STORE;
