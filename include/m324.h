@@ -47,7 +47,7 @@ int m324_last_error(char* buf, int n);
 int m324_device_info(char* name, int n);
 /* Lab / test hook (not used by the product path): the kernel choosers' A/B switches -- "M324_GEMM" (forced schedule
  * number, 0 = automatic), "M324_GEMM_TN", "M324_XCD", "M324_ATTN_NW", "M324_ATTN_FLAT", "M324_ATTN_OCC", "M324_ATTN_NQ2",
- * "M324_ATTN_BWD_NW", "M324_ATTN_EXP", "M324_LN_ROWS" -- are read from the environment ONCE, when the library is loaded; this call
+ * "M324_ATTN_BWD_NW", "M324_ATTN_EXP", "M324_LN_ROWS", "M324_GEMM_PERSIST" -- are read from the environment ONCE, when the library is loaded; this call
  * overrides one of them afterwards (value INT_MIN restores the default).  No launch path calls getenv(). */
 int m324_set_tunable(const char* name, int value);
 

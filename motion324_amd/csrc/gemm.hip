@@ -325,20 +325,29 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
-    int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, (M + BM5 - 1) / BM5, ntn, xcd_remap, tm, tn);
-    const int m0 = tm * BM5, n0 = tn * BN5;
-
+    // Persistent: one workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8
+    // or the tile count itself, so a workgroup's tiles stay on its XCD's share of the XCD-aware order).  Stamps of a K = 768
+    // tile (tools/gemm_trace.py): 4300 cycles of prologue -- texture-path time of the 160 pieces that fill the ring --
+    // before the first MFMA, and an epilogue of 5-14 k cycles during which the texture path idles.  The next tile's first two
+    // chunks (A_0, W_0) are therefore issued in front of the epilogue, whose scratch lives in chunks 2-4.
+    const int ntm = (M + BM5 - 1) / BM5, ntiles = ntm * ntn;
+    int m0 = 0, n0 = 0;
     // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
     const bf16_t* ga[4];
     const bf16_t* gb[4];
+    auto tile_setup = [&](int t) {
+        int tm, tn;
+        tile_of(t, ntiles, ntm, ntn, xcd_remap, tm, tn);
+        m0 = tm * BM5, n0 = tn * BN5;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3);
-        const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 8 + (lane >> 3);
+            const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+            ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
+            gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
+        }
+    };
+    tile_setup(blockIdx.x);
     auto issue2 = [&](const bf16_t* const (&g)[4], int i0, int st, int pos) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
@@ -347,22 +356,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     };
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int NS = K / 64;
     // fragment of k-step ks: chunk 2 ks + hi of the lane's row; the swizzle only touches chunk bits, so k-step ks is the
     // k-step-0 offset ^ (ks << 5)
     const int aoff = lds_off(wm * 128 + l31, hi), boff = lds_off(wn * 64 + l31, hi);
     bf16x8 fa[2][4], fb[2][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[1][i] = (bf16x8)(0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) fb[1][j] = (bf16x8)(0);
     auto load_frags = [&](int set, int pa, int pw, int ks) {
         const unsigned char* ba = smem + pa * CHUNK10;
         const unsigned char* bw = smem + pw * CHUNK10;
@@ -389,10 +388,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
 
     GTRACE_DECL
     GTRACE();                                               // 0: kernel entry (after address set-up)
-    LnPre ln_pre;
-    ln_prefetch<ACT, 4>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, ln_pre);
-    // prologue: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile (12 in all at
-    // K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue and is peeled
+    // prologue of the FIRST tile: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile
+    // (12 in all at K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue
     {
         const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
         issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
@@ -437,16 +434,52 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
         pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
     };
-    stage(0, std::false_type{});
-    for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
-    mma8(1);                                                // (NS-1, k-step 3)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may outlive the main loop: the ring becomes scratch
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int mt = m0, nt = n0;                         // this tile's origin (m0 / n0 move on in front of the epilogue)
+        const bool more = t + (int)gridDim.x < ntiles;
+        LnPre ln_pre;
+        ln_prefetch<ACT, 4>(ep, M, N, mt + wm * 128, nt + wn * 64, lane, ln_pre);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[1][i] = (bf16x8)(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[1][j] = (bf16x8)(0);
+        pa = 0, pw = 1;
+        if (t == (int)blockIdx.x) {
+            stage(0, std::false_type{});                    // the first tile found the whole ring issued
+        } else {
+            // later tiles: A_0, W_0 arrived under the previous epilogue; A_1 goes out first, W_1 and A_2 with the stage
+            const int s1 = NS > 1 ? 1 : 0;
+            issue2(ga, 0, s1, 2); issue2(ga, 2, s1, 2);
+            stage(0, std::true_type{});
+        }
+        for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
+        mma8(1);                                            // (NS-1, k-step 3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the main loop: the ring becomes scratch
+        M324_BARRIER();
+        GTRACE();                                           // 4 + 3 NS: last k-step issued, ring drained, barrier passed
+        if (more) {                                         // the next tile's first chunks land under this tile's epilogue
+            tile_setup(t + gridDim.x);
+            issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
+            issue2(gb, 0, 0, 1); issue2(gb, 2, 0, 1);
+        }
+        store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem + 2 * CHUNK10) + wave * ep_wave_floats(ACT), C, ldc, M, N,
+                                          mt + wm * 128, nt + wn * 64, lane, ep, &ln_pre);
+        GTRACE();                                           // 5 + 3 NS: epilogue done
+        if (more) {
+            // everything this wave has in flight -- the two prefetched chunks and the epilogue's stores (loads and stores share
+            // vmcnt and may retire out of order with respect to each other) -- must be done before the next tile starts.  The
+            // builtin, not inline asm: hipcc's own wait-count pass must see the drain (gemm_ring4.hip has the story).
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+            M324_BARRIER();
+        }
+    }
 #undef M324_SG
-    M324_BARRIER();
-    GTRACE();                                               // 4 + 3 NS: last k-step issued, ring drained, barrier passed
-    store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 128,
-                                      n0 + wn * 64, lane, ep, &ln_pre);
-    GTRACE();                                               // 5 + 3 NS: epilogue done
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -927,6 +960,18 @@ static int xcd_mode(const m324_gemm_args* a) {
 // A/B tables are kept in profiles/r01_ab_gemm_schedules.md.)
 static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_GEMM at load / m324_set_tunable
 
+// v10 is persistent: one 8-wave workgroup per CU (160 KiB of LDS each); M324_GEMM_PERSIST=0: one workgroup per tile (A/B)
+static int ring_grid(long ntiles) {
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n - (n & 7);                                 // a multiple of 8: tile t and t + grid share an XCD
+    }();
+    if (m324::tunable(m324::TUN_GEMM_PERSIST) == 0 || n_cu <= 0) return (int)ntiles;
+    return (int)(ntiles < n_cu ? ntiles : n_cu);
+}
+
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
     int f = forced_variant();
@@ -978,7 +1023,7 @@ static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& e
         return M324_OK;
     }
     if (variant == 10) {
-        hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+        hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ring_grid(ceil_div(a->N, BN5) * ceil_div(a->M, BM5))), dim3(512), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
                            ceil_div(a->N, BN5), xcd_mode(a));
         return M324_OK;
@@ -1002,11 +1047,11 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
     if (a->aux_mode == M324_AUX_N3) {              // one schedule only: the 256 x 256 chunk ring (host-checked shape)
         if constexpr (sizeof(TOUT) == 2 && sizeof(TIN) == 2) {
             if (lnf)
-                hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 13, 0>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+                hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 13, 0>), dim3(ring_grid(ceil_div(a->N, BN5) * ceil_div(a->M, BM5))), dim3(512), 0, s,
                                    (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (bf16_t*)a->C, a->ldc, a->M, a->N, a->K, ep,
                                    ceil_div(a->N, BN5), xcd_mode(a));
             else
-                hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 5, 0>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s,
+                hipLaunchKernelGGL((gemm_ring_kernel<bf16_t, 5, 0>), dim3(ring_grid(ceil_div(a->N, BN5) * ceil_div(a->M, BM5))), dim3(512), 0, s,
                                    (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (bf16_t*)a->C, a->ldc, a->M, a->N, a->K, ep,
                                    ceil_div(a->N, BN5), xcd_mode(a));
             M324_CHECK_LAUNCH("m324_gemm");
@@ -1037,7 +1082,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
         }                                                                                                                \
         else if (variant == 5)                                                                                           \
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
-                               dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
+                               dim3(ring_grid(ceil_div(a->N, BN5) * ceil_div(a->M, BM5))), dim3(512), 0, s, (const TIN*)a->A,       \
                                a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,              \
                                ceil_div(a->N, BN5), xcd_mode(a));                                                        \
         else                                                                                                             \
@@ -1056,7 +1101,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                                (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M,      \
                                a->N, a->K, ep, (int)grid.x, xcd_mode(a));                                                \
         else if (variant == 10)                                                                                          \
-            hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)),      \
+            hipLaunchKernelGGL((gemm_ring_kernel<TOUT, ACT, RES>), dim3(ring_grid(ceil_div(a->N, BN5) * ceil_div(a->M, BM5))),      \
                                dim3(512), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C,   \
                                a->ldc, a->M, a->N, a->K, ep, ceil_div(a->N, BN5), xcd_mode(a));                          \
         else                                                                                                             \
@@ -1110,7 +1155,7 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
     const bool lnf = a->ln_rowstat || a->ln_stats_out || a->ln_copy_out;
     if (a->aux_mode == M324_AUX_N3) {
         snprintf(buf, (size_t)n, "gemm_ring_kernel<unsigned short, %d, 0> grid=%ldx1x1", lnf ? 13 : 5,
-                 (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5) * 512);
+                 (long)ring_grid((long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5)) * 512);
         return 10;
     }
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
@@ -1133,7 +1178,7 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
         case 2: name = "gemm_glds_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
         case 5: name = "gemm_glds5_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
         case 9: name = "gemm_skinny_kernel"; wg = ceil_div(a->N, 32); threads = 512; break;
-        case 10: name = "gemm_ring_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); threads = 512; break;
+        case 10: name = "gemm_ring_kernel"; wg = ring_grid((long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5)); threads = 512; break;
         case 11: name = "gemm_ring4_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;
         case 12: name = "gemm_ring3_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); break;
         case 13: name = "gemm_ring2_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
