@@ -299,6 +299,13 @@ int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, vo
 int m324_layernorm_bwd(const float* x, long ldx, const float* w, float eps, const void* dy, long ldy, int dy_dtype,
                        float* dx, long lddx, int accumulate, float* partial, int n_partial, int rows, int C,
                        int gin, int gout, int off, void* stream);
+/* The same, and in the same pass: dx_bf16[in_row(r)] = the resulting dx row rounded to bf16 (what the backward GEMMs behind it
+ * read -- the reference's autograd hands the fp32 gradient to a bf16 autocast Linear the same way), and partial gets a THIRD
+ * block: partial[n_partial][3C] = dy*xhat | dy | column sums of the rounded dx (the bias gradient of the Linear whose output
+ * gradient this dx is).  Replaces m324_cast + m324_colsum over the tensor after every LayerNorm backward of the training step. */
+int m324_layernorm_bwd_cast(const float* x, long ldx, const float* w, float eps, const void* dy, long ldy, int dy_dtype,
+                            float* dx, long lddx, int accumulate, float* partial, int n_partial, int rows, int C,
+                            int gin, int gout, int off, void* dx_bf16, long ldc, void* stream);
 
 /* out = in converted between fp32 / bf16 (rows x cols, leading dims in elements). */
 int m324_cast(const void* in, long ld_in, int in_dtype, void* out, long ld_out, int out_dtype, int rows, int cols,

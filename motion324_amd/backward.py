@@ -110,12 +110,13 @@ def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
 
 
 def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: torch.Tensor, need_da: bool = True,
-               gelu_grad_of: Optional[torch.Tensor] = None):
+               gelu_grad_of: Optional[torch.Tensor] = None, dy_colsum: Optional[torch.Tensor] = None):
     """y = a W^T + b.  a [M, Ka] and dy [M, N] in the compute dtype.  Returns da [M, Ka] (compute dtype) or None.
-    gelu_grad_of = z with a = gelu(z): the returned tensor is dz = da * gelu'(z) (fused into the dgrad GEMM's epilogue)."""
+    gelu_grad_of = z with a = gelu(z): the returned tensor is dz = da * gelu'(z) (fused into the dgrad GEMM's epilogue).
+    dy_colsum: the column sums of dy when the kernel that produced dy delivered them (Carry), else computed here."""
     M, N = dy.shape
     if bias is not None:
-        G.add(bias, ops.colsum(dy))
+        G.add(bias, dy_colsum if dy_colsum is not None else ops.colsum(dy))
     dW = weight_grad(dy, a)
     k_true = weight[0].numel()
     G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
@@ -127,6 +128,35 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
     da = torch.empty((M, Wt.shape[0]), dtype=dy.dtype, device=dy.device)
     ops.gemm(dy, Wt, da, gelu_grad_of=gelu_grad_of)
     return da
+
+
+class Carry:
+    """The residual-stream gradient dx in the form the next backward GEMMs read it: its bf16 copy and that copy's column sums
+    (= the bias gradient of the Linear in front).  Every LayerNorm backward that finishes a dx delivers both in the same pass
+    (m324_layernorm_bwd_cast); a consumer that finds no carry (first block of a chain, fp32 parity mode) computes them itself."""
+
+    def __init__(self):
+        self.dx = None          # the fp32 tensor the copy belongs to (identity + version are checked)
+        self.bf16 = None
+        self.colsum = None
+        self.version = -1
+
+    def take(self, P: Prepared, dx: torch.Tensor):
+        """(dx in the compute dtype, its column sums or None)."""
+        if self.dx is dx and self.bf16 is not None and self.version == dx._version and P.dtype == torch.bfloat16:
+            out = (self.bf16, self.colsum)
+            self.dx = self.bf16 = self.colsum = None
+            return out
+        return ops.cast(dx, P.dtype), None
+
+    def ln_bwd(self, P: Prepared, x, w, eps, dy, dx, accumulate=True, row_map=(0, 0, 0)):
+        """ops.layernorm_bwd that also fills the carry for dx (bf16 mode); returns (dw, db)."""
+        if P.dtype != torch.bfloat16:
+            return ops.layernorm_bwd(x, w, eps, dy, dx, accumulate=accumulate, row_map=row_map)
+        c = torch.empty(dx.shape, dtype=torch.bfloat16, device=dx.device)
+        dw, db, cs = ops.layernorm_bwd(x, w, eps, dy, dx, accumulate=accumulate, row_map=row_map, cast_out=c)
+        self.dx, self.bf16, self.colsum, self.version = dx, c, cs, dx._version
+        return dw, db
 
 
 def mlp_internals(P: Prepared, norm2, mlp, x_mid: torch.Tensor) -> dict:
@@ -142,16 +172,17 @@ def mlp_internals(P: Prepared, norm2, mlp, x_mid: torch.Tensor) -> dict:
 
 
 def mlp_residual_bwd(P: Prepared, G: GradStore, norm2, mlp, x_mid: torch.Tensor, dx: torch.Tensor,
-                     saved: Optional[dict] = None) -> None:
+                     saved: Optional[dict] = None, carry: Optional[Carry] = None) -> None:
     """x_out = x_mid + fc2(gelu(fc1(LN2(x_mid)))).  dx (fp32): grad w.r.t. x_out on entry, w.r.t. x_mid on exit.
-    saved: mlp_internals() of the forward (None: recomputed here)."""
+    saved: mlp_internals() of the forward (None: recomputed here).  carry: see Carry (in: dx's bf16 form; out: the new dx's)."""
     fc1, fc2 = mlp.mlp[0], mlp.mlp[2]
+    carry = carry if carry is not None else Carry()
     m = saved if saved is not None else mlp_internals(P, norm2, mlp, x_mid)
     h2, z, g = m["h2"], m["z"], m["g"]
-    dxT = ops.cast(dx, P.dtype)
-    dz = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT, gelu_grad_of=z)                      # (dxT W2) * gelu'(z)
+    dxT, dsum = carry.take(P, dx)
+    dz = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT, gelu_grad_of=z, dy_colsum=dsum)      # (dxT W2) * gelu'(z)
     dh2 = linear_bwd(P, G, fc1.weight, fc1.bias, h2, dz)
-    dw, db = ops.layernorm_bwd(x_mid, P.vec(norm2.weight), norm2.eps, dh2, dx, accumulate=True)
+    dw, db = carry.ln_bwd(P, x_mid, P.vec(norm2.weight), norm2.eps, dh2, dx, accumulate=True)
     G.add(norm2.weight, dw)
     G.add(norm2.bias, db)
 
@@ -185,9 +216,11 @@ def self_attn_block_internals(blk, P: Prepared, x_in: torch.Tensor, B: int, L: i
 
 
 def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: torch.Tensor, B: int, L: int,
-                        saved: Optional[dict] = None) -> None:
+                        saved: Optional[dict] = None, carry: Optional[Carry] = None) -> None:
     """Backward of QK_Norm_TransformerBlock.run.  dx: grad w.r.t. the block output on entry, w.r.t. x_in on exit.
-    saved: self_attn_block_internals() of the forward (None: recomputed from x_in, the reference's checkpoint policy)."""
+    saved: self_attn_block_internals() of the forward (None: recomputed from x_in, the reference's checkpoint policy).
+    carry: a Carry shared by the blocks of a chain (the bf16 form of dx travels from LayerNorm backward to the next GEMMs)."""
+    carry = carry if carry is not None else Carry()
     rows, C = x_in.shape
     a = blk.attn
     H = a.num_heads
@@ -196,11 +229,11 @@ def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: 
     h1, qkv, sp, o, lse, x_mid = s["h1"], s["qkv"], s["sp"], s["o"], s["lse"], s["x_mid"]
     qw, kw = a._qk_w(P)
     # ---- MLP half
-    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx, saved=s["mlp"])     # dx = d x_mid
+    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx, saved=s["mlp"], carry=carry)     # dx = d x_mid
     s["mlp"] = None
     # ---- attention half
-    dxT = ops.cast(dx, P.dtype)
-    do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)
+    dxT, dsum = carry.take(P, dx)
+    do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT, dy_colsum=dsum)
     D = ops.attention_delta(o, do, B, H, L)
     dQ, dK, dV = _attention_bwd(P, sp, sp, do, lse, D, B, L, H, shared_q=False)
     dqkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=dev)
@@ -210,7 +243,7 @@ def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: 
         G.add(a.q_norm.weight, dqw)
         G.add(a.k_norm.weight, dkw)
     dh1 = linear_bwd(P, G, a.to_qkv.weight, a.to_qkv.bias, h1, dqkv)
-    dw, db = ops.layernorm_bwd(x_in, P.vec(blk.norm1.weight), blk.norm1.eps, dh1, dx, accumulate=True)
+    dw, db = carry.ln_bwd(P, x_in, P.vec(blk.norm1.weight), blk.norm1.eps, dh1, dx, accumulate=True)
     G.add(blk.norm1.weight, dw)
     G.add(blk.norm1.bias, db)
 
@@ -266,11 +299,12 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
     qw, kw = a._qk_w(P)
     w_kv = P.cat_rows((a.to_k.weight, a.to_v.weight))
     # ---- MLP half
-    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx, saved=s["mlp"])     # dx = d x_mid  [B*Lq, C]
+    carry = Carry()
+    mlp_residual_bwd(P, G, blk.norm2, blk.mlp, x_mid, dx, saved=s["mlp"], carry=carry)     # dx = d x_mid  [B*Lq, C]
     s["mlp"] = None
     # ---- attention half
-    dxT = ops.cast(dx, P.dtype)
-    do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT)
+    dxT, dsum = carry.take(P, dx)
+    do = linear_bwd(P, G, a.fc.weight, a.fc.bias, o, dxT, dy_colsum=dsum)
     D = ops.attention_delta(o, do, B, H, Lq)
     dQ, dK, dV = _attention_bwd(P, spq, spk, do, lse, D, B, Lq, H, shared_q=shared_q)
     # key / value path

@@ -655,17 +655,21 @@ __global__ __launch_bounds__(256) void gelu_bwd8_kernel(const T* __restrict__ z,
 //   waves: the row loop is a chain of dependent loads, and the 1024 waves of the first version left it latency-bound (110 us for
 //   24 672 rows x 768; the per-wave partials then cost m324_colsum another 58 us).
 constexpr int LNB_WAVES = 8;
-template <typename T>
+// CAST: the bf16 copy of the resulting dx row (what the next backward GEMMs read: saves the cast pass that followed every call) and,
+// as a third block of the partials, the column sums of that ROUNDED copy (the bias gradient of the Linear in front: saves its
+// m324_colsum pass over the tensor).
+template <typename T, bool CAST>
 __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                             float eps, const T* __restrict__ dy, long ldy,
                                                             float* __restrict__ dx, long lddx, int accumulate,
                                                             float* __restrict__ partial, int rows, int C, int gin, int gout,
-                                                            int off) {
+                                                            int off, bf16_t* __restrict__ dxc, long ldc) {
+    constexpr int NB = CAST ? 3 : 2;
     extern __shared__ float lnb_red[];                        // [LNB_WAVES][2 C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * LNB_WAVES + wave, nw = gridDim.x * LNB_WAVES;
-    float4 pw[LN_MAXV], pb[LN_MAXV];
-    LN_FOR(i, c) { pw[i] = make_float4(0.f, 0.f, 0.f, 0.f); pb[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    float4 pw[LN_MAXV], pb[LN_MAXV], pc[CAST ? LN_MAXV : 1];
+    LN_FOR(i, c) { pw[i] = make_float4(0.f, 0.f, 0.f, 0.f); pb[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (CAST) pc[i] = pw[i]; }
     for (long row = gw; row < rows; row += nw) {
         const long xr = remap_row(row, gin, gout, off);
         float4 v[LN_MAXV];
@@ -696,6 +700,12 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const flo
                 o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
             }
             *reinterpret_cast<float4*>(dr + c) = o;
+            if constexpr (CAST) {
+                const uint32_t lo = pack_bf16x2(o.x, o.y), hi2 = pack_bf16x2(o.z, o.w);
+                *reinterpret_cast<uint2*>(dxc + xr * ldc + c) = make_uint2(lo, hi2);
+                pc[i].x += __uint_as_float(lo << 16); pc[i].y += __uint_as_float(lo & 0xFFFF0000u);
+                pc[i].z += __uint_as_float(hi2 << 16); pc[i].w += __uint_as_float(hi2 & 0xFFFF0000u);
+            }
         }
     }
     float* mine = lnb_red + wave * 2 * C;
@@ -704,12 +714,23 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void layernorm_bwd_kernel(const flo
         *reinterpret_cast<float4*>(mine + C + c) = pb[i];
     }
     __syncthreads();
-    float* pr = partial + (long)blockIdx.x * 2 * C;
+    float* pr = partial + (long)blockIdx.x * NB * C;
     for (int c = threadIdx.x; c < 2 * C; c += 64 * LNB_WAVES) {
         float a = lnb_red[c];
 #pragma unroll
         for (int w = 1; w < LNB_WAVES; ++w) a += lnb_red[w * 2 * C + c];
         pr[c] = a;
+    }
+    if constexpr (CAST) {                                     // third block through the same LDS (the 2 C layout keeps it at 48 KiB)
+        __syncthreads();
+        LN_FOR(i, c) *reinterpret_cast<float4*>(mine + c) = pc[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 64 * LNB_WAVES) {
+            float a = lnb_red[c];
+#pragma unroll
+            for (int w = 1; w < LNB_WAVES; ++w) a += lnb_red[w * 2 * C + c];
+            pr[2 * C + c] = a;
+        }
     }
 }
 
@@ -1025,8 +1046,25 @@ extern "C" int m324_layernorm_bwd(const float* x, long ldx, const float* w, floa
     M324_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0, "m324_layernorm_bwd: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_DTYPE(dy_dtype, "m324_layernorm_bwd",
-                   hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(n_partial), dim3(64 * LNB_WAVES), (size_t)LNB_WAVES * 2 * C * 4, s, x,
-                                      ldx, w, eps, (const T*)dy, ldy, dx, lddx, accumulate, partial, rows, C, gin, gout, off));
+                   hipLaunchKernelGGL((layernorm_bwd_kernel<T, false>), dim3(n_partial), dim3(64 * LNB_WAVES), (size_t)LNB_WAVES * 2 * C * 4, s, x,
+                                      ldx, w, eps, (const T*)dy, ldy, dx, lddx, accumulate, partial, rows, C, gin, gout, off,
+                                      (bf16_t*)nullptr, 0l));
     M324_CHECK_LAUNCH("m324_layernorm_bwd");
+    return M324_OK;
+}
+
+extern "C" int m324_layernorm_bwd_cast(const float* x, long ldx, const float* w, float eps, const void* dy, long ldy, int dy_dtype,
+                                       float* dx, long lddx, int accumulate, float* partial, int n_partial, int rows, int C, int gin,
+                                       int gout, int off, void* dx_bf16, long ldc, void* stream) {
+    M324_REQUIRE(x && w && dy && dx && partial && dx_bf16, "m324_layernorm_bwd_cast: null pointer");
+    M324_REQUIRE(rows > 0 && C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV, "m324_layernorm_bwd_cast: rows=%d C=%d unsupported", rows, C);
+    M324_REQUIRE(n_partial > 0 && n_partial <= 4096, "m324_layernorm_bwd_cast: n_partial = %d (1 .. 4096 workgroups)", n_partial);
+    M324_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0 && ldc % 4 == 0, "m324_layernorm_bwd_cast: leading dims must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dy_dtype, "m324_layernorm_bwd_cast",
+                   hipLaunchKernelGGL((layernorm_bwd_kernel<T, true>), dim3(n_partial), dim3(64 * LNB_WAVES), (size_t)LNB_WAVES * 2 * C * 4, s, x,
+                                      ldx, w, eps, (const T*)dy, ldy, dx, lddx, accumulate, partial, rows, C, gin, gout, off,
+                                      (bf16_t*)dx_bf16, ldc));
+    M324_CHECK_LAUNCH("m324_layernorm_bwd_cast");
     return M324_OK;
 }

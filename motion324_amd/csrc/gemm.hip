@@ -1082,7 +1082,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
         }                                                                                                                \
         else if (variant == 5)                                                                                           \
             hipLaunchKernelGGL((gemm_glds5_kernel<TIN, TOUT, ACT, RES>),                                                 \
-                               dim3(ring_grid(ceil_div(a->N, BN5) * ceil_div(a->M, BM5))), dim3(512), 0, s, (const TIN*)a->A,       \
+                               dim3(ceil_div(a->N, BN5) * ceil_div(a->M, BM5)), dim3(512), 0, s, (const TIN*)a->A,       \
                                a->lda, (const TIN*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,              \
                                ceil_div(a->N, BN5), xcd_mode(a));                                                        \
         else                                                                                                             \

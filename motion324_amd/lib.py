@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class M324Error(RuntimeError):
@@ -95,6 +95,7 @@ SIGNATURES = {
     "m324_comm_allgather": [_P, _P, _P, _L, _I, _P],
     "m324_comm_destroy": [_P],
     "m324_layernorm_bwd": [_P, _L, _P, _F, _P, _L, _I, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m324_layernorm_bwd_cast": [_P, _L, _P, _F, _P, _L, _I, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
 }
 
 _lib = None

@@ -533,8 +533,10 @@ def gelu_bwd(z: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
 
 
 def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool,
-                  row_map=(0, 0, 0)):
-    """dx[in_row(r)] (+)= LN backward of row r; returns (dw [C], db [C]) fp32.  x, dx fp32; dy in the compute dtype."""
+                  row_map=(0, 0, 0), cast_out: Optional[torch.Tensor] = None):
+    """dx[in_row(r)] (+)= LN backward of row r; returns (dw [C], db [C]) fp32.  x, dx fp32; dy in the compute dtype.
+    cast_out (bf16, shaped like dx): also receives the resulting dx rounded to bf16, and a third vector is returned: the
+    column sums of that rounded copy (m324_layernorm_bwd_cast: one pass instead of LayerNorm backward + cast + column sum)."""
     if x.dtype != torch.float32 or dx.dtype != torch.float32:
         raise L.M324Error("layernorm_bwd: x and dx must be fp32")
     rows, Cdim = dy.shape
@@ -542,13 +544,23 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     pdy, ldy = _rows(dy, "dy")
     pdx, lddx = _rows(dx, "dx")
     n_partial = min(512, (rows + 7) // 8)               # workgroups of 8 waves, one row per wave at a time
-    partial = torch.empty((n_partial, 2 * Cdim), dtype=torch.float32, device=x.device)
+    nb = 2 if cast_out is None else 3
+    partial = torch.empty((n_partial, nb * Cdim), dtype=torch.float32, device=x.device)
     gin, gout, off = row_map
-    L.check(L.load().m324_layernorm_bwd(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
-                                        int(accumulate), _p(partial), n_partial, rows, Cdim, gin, gout, off, _stream()),
-            "m324_layernorm_bwd")
-    both = colsum(partial)
-    return both[:Cdim], both[Cdim:]
+    if cast_out is None:
+        L.check(L.load().m324_layernorm_bwd(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
+                                            int(accumulate), _p(partial), n_partial, rows, Cdim, gin, gout, off, _stream()),
+                "m324_layernorm_bwd")
+        both = colsum(partial)
+        return both[:Cdim], both[Cdim:]
+    if cast_out.dtype != torch.bfloat16 or cast_out.shape != dx.shape:
+        raise L.M324Error("layernorm_bwd: cast_out must be a bf16 tensor shaped like dx")
+    pc, ldc = _rows(cast_out, "cast_out")
+    L.check(L.load().m324_layernorm_bwd_cast(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
+                                             int(accumulate), _p(partial), n_partial, rows, Cdim, gin, gout, off, pc, ldc,
+                                             _stream()), "m324_layernorm_bwd_cast")
+    three = colsum(partial)
+    return three[:Cdim], three[Cdim:2 * Cdim], three[2 * Cdim:]
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -203,13 +203,14 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     G.done(list(model.shared_mlp_output.parameters()) + list(dec.parameters()))
 
     n_pairs = len(model.global_transformer_blocks)
+    carry = bw.Carry()                                       # d_tok's bf16 form + column sums travel from block to block
     for i in reversed(range(n_pairs)):
         bw.self_attn_block_bwd(model.local_transformer_blocks[i], P, G, trunk_in[2 * i + 1], d_tok, B * T, Lt,
-                               saved=trunk_saved[2 * i + 1])
+                               saved=trunk_saved[2 * i + 1], carry=carry)
         G.done(model.local_transformer_blocks[i].parameters())
         trunk_saved[2 * i + 1] = None
         bw.self_attn_block_bwd(model.global_transformer_blocks[i], P, G, trunk_in[2 * i], d_tok, B, T * Lt,
-                               saved=trunk_saved[2 * i])
+                               saved=trunk_saved[2 * i], carry=carry)
         G.done(model.global_transformer_blocks[i].parameters())
         trunk_in[2 * i + 1] = trunk_in[2 * i] = trunk_saved[2 * i] = None
 
@@ -230,8 +231,9 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     for b in range(B):
         d_mesh[b * K:(b + 1) * K] = ops.colsum(d4[b, :, 4:4 + K].reshape(T, K * C).contiguous()).reshape(K, C)
 
+    carry = bw.Carry()
     for i in reversed(range(len(model.points_transformer_blocks))):
-        bw.self_attn_block_bwd(model.points_transformer_blocks[i], P, G, mesh_in[i], d_mesh, B, K)
+        bw.self_attn_block_bwd(model.points_transformer_blocks[i], P, G, mesh_in[i], d_mesh, B, K, carry=carry)
         G.done(model.points_transformer_blocks[i].parameters())
     d_pts = torch.zeros((B * S, C), dtype=torch.float32, device=dev)
     d_query = bw.cross_attn_block_bwd(model.encoder_cross_attn, P, G, query, pts, d_mesh, B, K, S, d_kv=d_pts)

@@ -75,6 +75,32 @@ def test_layernorm_backward(dtype, rows, C):
     assert rel_err(dx2, xt.grad) < 2e-6
 
 
+@pytest.mark.parametrize("rows,C,row_map", [(517, 768, (0, 0, 0)), (64, 192, (0, 0, 0)), (3 * 8, 768, (8, 40, 4)), (4100, 768, (0, 0, 0))])
+def test_layernorm_backward_with_bf16_copy_and_column_sums(rows, C, row_map):
+    """m324_layernorm_bwd_cast = m324_layernorm_bwd + m324_cast + m324_colsum in one pass: the same dx / dw / db bit for bit, the
+    bf16 copy equal to the cast of the resulting dx, the third vector equal to the column sums of that copy (to the order of an
+    fp32 sum).  Also with accumulate and with a row map (the decoder's k|v rows inside the trunk's token matrix)."""
+    from motion324_amd import ops
+    gin, gout, off = row_map
+    xrows = rows if not gin else (rows // gin) * gout
+    x = (_rand((xrows, C), 5) * 2 + 0.3).to(DEV)
+    w = (1 + 0.1 * _rand((C,), 6)).to(DEV)
+    dy = _q(_rand((rows, C), 7), torch.bfloat16).to(torch.bfloat16).to(DEV)
+    dx0 = _rand((xrows, C), 8).to(DEV)
+    a, b = dx0.clone(), dx0.clone()
+    dw0, db0 = ops.layernorm_bwd(x, w, 1e-5, dy, a, accumulate=True, row_map=row_map)
+    copy = torch.full((xrows, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dw1, db1, cs = ops.layernorm_bwd(x, w, 1e-5, dy, b, accumulate=True, row_map=row_map, cast_out=copy)
+    assert torch.equal(a, b) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    touched = torch.zeros(xrows, dtype=torch.bool, device=DEV)
+    r = torch.arange(rows, device=DEV)
+    touched[(r // gin) * gout + r % gin + off if gin else r] = True
+    assert torch.equal(copy[touched], b[touched].to(torch.bfloat16))
+    assert bool(torch.isnan(copy[~touched].float()).all()) or not bool((~touched).any())
+    ref = copy[touched].double().sum(0)
+    assert float((cs.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max() + 1)
+
+
 def _head_major(t, B, L, H):
     return t.reshape(B, L, H, 64).permute(0, 2, 1, 3).contiguous()
 

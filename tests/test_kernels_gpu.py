@@ -205,15 +205,17 @@ def test_gemm_every_schedule_forced(tune, variant, dtype, K):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
-@pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("variant", ["v5", "v10", "v11", "v12", "v13"])
 def test_gemm_chunk_ring_many_tiles(tune, variant):
-    """The chunk-ring kernels on a grid with more tiles than CUs (20 x 16 = 320 tiles of 256 x 256, ragged last row of
-    tiles): the persistent v11 walks 1-2 tiles per workgroup with the next tile's first chunks prefetched under the
-    epilogue; bias + GELU into bf16, then the in-place fp32 residual stream.  The default choice must agree bit for bit
-    with the forced schedule's summation order (same k order in every tile kernel)."""
+    """The 256-wide kernels on a grid with more tiles than CUs (20 x 16 = 320 tiles of 256 x 256, ragged last row of
+    tiles): the persistent v10 / v11 walk 1-2 tiles per workgroup with the next tile's first chunks prefetched under the
+    epilogue; bias + GELU into the operand dtype, then the in-place fp32 residual stream.  The default choice must agree bit
+    for bit with the forced schedule's summation order (same k order in every tile kernel).  v5 (fp32 operands: the parity
+    mode's kernel) is NOT persistent and must get one workgroup per tile: round 3 once launched it on the persistent grid
+    and the fp32 parity mode lost every tile past the 256th -- only the full-size golden test noticed."""
     ops = _ops()
     from motion324_amd.lib import ACT_GELU
-    dtype = torch.bfloat16
+    dtype = torch.float32 if variant == "v5" else torch.bfloat16
     M, N, K = 20 * 256 - 37, 4096, 192
     a, w = _q(_rand((M, K), 31), dtype), _q(_rand((N, K), 32, 0.1), dtype)
     bias = _rand((N,), 33)
