@@ -220,3 +220,14 @@ def test_parameter_order_is_the_references(case, golden):
     assert [n for n, _ in named] == [str(x) for x in gold["named_parameters_order"]]
     decay_first = [n for n, p in named if p.dim() > 1] + [n for n, p in named if p.dim() <= 1]
     assert decay_first == [str(x) for x in gold["param_order"]]
+
+
+def test_the_switch_table_in_design_md_is_the_one_in_switches_py():
+    """DESIGN.md 7c prints motion324_amd.switches.table(); a switch added to the code must show up there (and vice versa)."""
+    from motion324_amd import switches
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "DESIGN.md")).read()
+    assert switches.table() in text
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "motion324_amd", "csrc", "runtime.hip")).read()
+    lib_names = set(re.findall(r'\{"(M324_[A-Z0-9_]+)",', src))
+    assert lib_names == set(switches.LIBRARY), (lib_names ^ set(switches.LIBRARY))
