@@ -16,10 +16,12 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from . import switches
 from .lib import ACT_GELU
 from .prepared import Prepared
 
 RMS_EPS = 1e-5
+DIRECT_GRADS = switches.get("M324_DIRECT_GRADS") != "0"
 
 
 class GradStore:
@@ -52,6 +54,18 @@ class GradStore:
         else:
             self.grads[k] = g.float().clone() if g.dtype != torch.float32 or not g.is_contiguous() else g.clone()
         self.params[k] = param
+
+    def target(self, param: Optional[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+        """Where the FIRST gradient of `param` may be written directly: its slice of the optimizer's flat gradient buffer
+        (None: no sink, not owned, or the parameter already holds a gradient -- then add() accumulates).  A kernel that
+        wrote there reports with wrote(); 284 device copies per training step went away this way (round 3)."""
+        if not DIRECT_GRADS or param is None or not param.requires_grad or self.sink is None or id(param) in self.grads or not self.sink.owns(param):
+            return None
+        return self.sink.grad_of(param)
+
+    def wrote(self, param: torch.nn.Parameter, view: torch.Tensor) -> None:
+        self.grads[id(param)] = view
+        self.params[id(param)] = param
 
     def get(self, param) -> Optional[torch.Tensor]:
         return self.grads.get(id(param))
@@ -89,9 +103,10 @@ def _wgrad(dYt: torch.Tensor, At: torch.Tensor) -> torch.Tensor:
     return ops.gemm_splitk(dYt, At, slices)
 
 
-def weight_grad(dy: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+def weight_grad(dy: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW [N, Ka] fp32 = dy[M, N]^T a[M, Ka].  bf16: m324_gemm_tn straight from the token-major operands (transposing LDS
-    reads); fp32 parity mode: two transposed copies + the NN kernel with split-K."""
+    reads); fp32 parity mode: two transposed copies + the NN kernel with split-K.  out (bf16 path): see ops.gemm_tn; the
+    returned tensor IS out when it was used."""
     M, N = dy.shape
     Ka = a.shape[1]
     if dy.dtype == torch.bfloat16 and N % 8 == 0 and Ka % 8 == 0:
@@ -100,7 +115,7 @@ def weight_grad(dy: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
         else:                                                    # 128 x 128 tiles, two workgroups per CU
             tiles = ((N + 127) // 128) * ((Ka + 127) // 128)
             slices = max(1, min(32, (640 + tiles - 1) // tiles, M // 512))
-        return ops.gemm_tn(dy, a, slices)
+        return ops.gemm_tn(dy, a, slices, out=out)
     return _wgrad(ops.transpose(dy), ops.transpose(a))
 
 
@@ -116,10 +131,19 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
     dy_colsum: the column sums of dy when the kernel that produced dy delivered them (Carry), else computed here."""
     M, N = dy.shape
     if bias is not None:
-        G.add(bias, dy_colsum if dy_colsum is not None else ops.colsum(dy))
-    dW = weight_grad(dy, a)
+        tb = G.target(bias) if dy_colsum is None else None
+        if tb is not None:                                    # column sums straight into the flat gradient buffer
+            ops.colsum(dy, out=tb.view(-1))
+            G.wrote(bias, tb)
+        else:
+            G.add(bias, dy_colsum if dy_colsum is not None else ops.colsum(dy))
     k_true = weight[0].numel()
-    G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
+    tw = G.target(weight) if k_true == a.shape[1] else None
+    dW = weight_grad(dy, a, out=tw)
+    if tw is not None and dW is tw:
+        G.wrote(weight, tw)
+    else:
+        G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
     if not need_da:
         return None
     Wt = _wt(P, weight)                                       # [Kp, N_pad]

@@ -23,6 +23,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_FUSE_QKV": ("1", "transformer.FUSE_QKV", "bf16 inference: q|k|v projection epilogue writes head-major Q / K / V (RMSNorm, pre-scale)"),
     "M324_FUSE_QKV_VT": ("1", "transformer.FUSE_QKV_VT", "the same for long sequences: the epilogue writes the transposed, key-permuted V"),
     "M324_TRAIN_STORE": ("1", "training.TRAIN_STORE", "training: the forward keeps block internals while they fit half of the free HBM (0: always recompute, the reference's checkpoint policy)"),
+    "M324_DIRECT_GRADS": ("1", "backward.DIRECT_GRADS", "training: weight / bias gradients are written straight into the optimizer's flat gradient buffer (0: temporary + copy)"),
     "M324_PRECISION": ("", "prepared.compute_dtype()", "force bf16 / fp32 (default: follow torch.autocast like the reference)"),
     "M324_LIB": ("", "lib.LIB_PATH", "path of an alternative libm324.so (lab builds)"),
     "M324_RCCL_LIB": ("", "csrc/comm.hip", "m324_comm_*: path of the RCCL library to bind (default: the copy already loaded, else librccl.so)"),
