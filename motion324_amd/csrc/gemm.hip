@@ -429,7 +429,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         GTRACE();                                           // 4 + 3 s: the stage's 32 MFMAs issued
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         GTRACE();                                           // 5 + 3 s: own LDS-DMA pieces of the next stage landed
+#ifndef M324_LAB_NO_STAGE_BARRIER                          // lab only (WRONG results): what do the stage barriers cost?
         M324_BARRIER();
+#endif
         GTRACE();                                           // 6 + 3 s: barrier passed
         pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
         pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
