@@ -332,9 +332,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     // chunks (A_0, W_0) are therefore issued in front of the epilogue, whose scratch lives in chunks 2-4.
     const int ntm = (M + BM5 - 1) / BM5, ntiles = ntm * ntn;
     int m0 = 0, n0 = 0;
-    // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
-    const bf16_t* ga[4];
-    const bf16_t* gb[4];
+    // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W.
+    // As BUFFER loads (resource = the tile's first row, 32-bit per-lane byte offset, the K-stage as the scalar offset):
+    // tools/coissue_lab measured what a piece costs a SIMD that is streaming MFMAs -- global_load_lds (per-lane 64-bit
+    // addresses) ~65 cycles, buffer_load ... lds ~5.  The stage of this kernel carried 16 pieces per SIMD: 750 of its 2800 cycles.
+    unsigned va[4], vb[4];                                  // byte offsets of the lane's 16 bytes inside the tile's row panel
+    __amdgpu_buffer_rsrc_t ra, rb;
     auto tile_setup = [&](int t) {
         int tm, tn;
         tile_of(t, ntiles, ntm, ntn, xcd_remap, tm, tn);
@@ -343,16 +346,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         for (int i = 0; i < 4; ++i) {
             const int r = (wave * 4 + i) * 8 + (lane >> 3);
             const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-            ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
-            gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
+            va[i] = (unsigned)(((long)min(r, M - 1 - m0) * lda + c) * 2);
+            vb[i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + c) * 2);
         }
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, 0x7FFFFFFF, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W + (long)n0 * ldw), 0, 0x7FFFFFFF, 0x00020000);
     };
     tile_setup(blockIdx.x);
-    auto issue2 = [&](const bf16_t* const (&g)[4], int i0, int st, int pos) {
+    auto issue2a = [&](int i0, int st, int pos) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i0 + i] + (long)st * 64), (lds_ptr_t*)(d + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t*)(d + i * 1024), 16, va[i0 + i], st * 128, 0, 0);
+    };
+    auto issue2b = [&](int i0, int st, int pos) {
+        unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t*)(d + i * 1024), 16, vb[i0 + i], st * 128, 0, 0);
     };
 
     f32x16 acc[4][2];
@@ -392,11 +403,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     // (12 in all at K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue
     {
         const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
-        issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
-        issue2(gb, 0, 0, 1); issue2(gb, 2, 0, 1);
-        issue2(ga, 0, s1, 2); issue2(ga, 2, s1, 2);
-        issue2(gb, 0, s1, 3); issue2(gb, 2, s1, 3);
-        issue2(ga, 0, s2, 4); issue2(ga, 2, s2, 4);
+        issue2a(0, 0, 0); issue2a(2, 0, 0);
+        issue2b(0, 0, 1); issue2b(2, 0, 1);
+        issue2a(0, s1, 2); issue2a(2, s1, 2);
+        issue2b(0, s1, 3); issue2b(2, s1, 3);
+        issue2a(0, s2, 4); issue2a(2, s2, 4);
     }
     GTRACE();                                               // 1: prologue pieces issued
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (A_1, W_1, A_2 may fly)
@@ -411,19 +422,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         pan = pan >= 5 ? pan - 5 : pan;
         const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
         load_frags(0, pa, pw, 0);
-        if constexpr (ISSUE) issue2(gb, 0, sw, pwn);
+        if constexpr (ISSUE) issue2b(0, sw, pwn);
         mma8(1);                                            // (s-1, k-step 3); zeros in the first iteration
         sched_kstep();
         load_frags(1, pa, pw, 1);
-        if constexpr (ISSUE) issue2(gb, 2, sw, pwn);
+        if constexpr (ISSUE) issue2b(2, sw, pwn);
         mma8(0);
         sched_kstep();
         load_frags(0, pa, pw, 2);
-        if constexpr (ISSUE) issue2(ga, 0, sa, pan);
+        if constexpr (ISSUE) issue2a(0, sa, pan);
         mma8(1);
         sched_kstep();
         load_frags(1, pa, pw, 3);
-        if constexpr (ISSUE) issue2(ga, 2, sa, pan);
+        if constexpr (ISSUE) issue2a(2, sa, pan);
         mma8(0);
         sched_kstep();
         GTRACE();                                           // 4 + 3 s: the stage's 32 MFMAs issued
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         } else {
             // later tiles: A_0, W_0 arrived under the previous epilogue; A_1 goes out first, W_1 and A_2 with the stage
             const int s1 = NS > 1 ? 1 : 0;
-            issue2(ga, 0, s1, 2); issue2(ga, 2, s1, 2);
+            issue2a(0, s1, 2); issue2a(2, s1, 2);
             stage(0, std::true_type{});
         }
         for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
@@ -467,8 +478,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         GTRACE();                                           // 4 + 3 NS: last k-step issued, ring drained, barrier passed
         if (more) {                                         // the next tile's first chunks land under this tile's epilogue
             tile_setup(t + gridDim.x);
-            issue2(ga, 0, 0, 0); issue2(ga, 2, 0, 0);
-            issue2(gb, 0, 0, 1); issue2(gb, 2, 0, 1);
+            issue2a(0, 0, 0); issue2a(2, 0, 0);
+            issue2b(0, 0, 1); issue2b(2, 0, 1);
         }
         store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem + 2 * CHUNK10) + wave * ep_wave_floats(ACT), C, ldc, M, N,
                                           mt + wm * 128, nt + wn * 64, lane, ep, &ln_pre);

@@ -129,6 +129,71 @@ static void run_mix(float* d, long long* st) {
     }
 }
 
+// What does issuing an LDS-DMA piece (1 KiB: 64 lanes x 16 B, global memory -> LDS) cost a SIMD whose waves are streaming MFMAs?
+// Per loop iteration a wave issues 8 MFMAs and NP pieces, addressed in one of three ways: MODE 0 per-lane 64-bit addresses
+// (global_load_lds), MODE 1 wave-uniform base + 32-bit per-lane offset (the same instruction in its saddr form, if the compiler
+// picks it), MODE 2 a buffer resource + 32-bit offset (buffer_load ... lds).  Sources: a 2 MiB window (L2 resident).
+typedef __attribute__((address_space(3))) void lds_v;
+typedef __attribute__((address_space(1))) const void glb_v;
+template <int NP, int MODE>
+__global__ __launch_bounds__(512) void kdma(float seed, const unsigned char* __restrict__ src, float* out, long long* stamp, int nwaves) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[64 * 1024];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= nwaves) return;
+    f32x16 c0, c1;
+    for (int i = 0; i < 16; ++i) c0[i] = seed, c1[i] = seed * 2;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) a[i] = (__bf16)(seed + i), b[i] = (__bf16)(seed - i);
+    const unsigned voff = (unsigned)((lane >> 3) * 4096 + (lane & 7) * 16 + wave * 32768 + (blockIdx.x & 7) * 262144);
+    const unsigned char* lanep = src + voff;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, 1 << 30, 0x00020000);
+    unsigned char* dst = smem + wave * 8192;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+            else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+            if (u < NP) {
+                const unsigned step = (unsigned)((it & 31) * 128 + u * 1024 * 1024 / 8);
+                if (MODE == 0) __builtin_amdgcn_global_load_lds((glb_v*)(lanep + step), (lds_v*)(dst + u * 1024), 16, 0, 0);
+                if (MODE == 1) __builtin_amdgcn_global_load_lds((glb_v*)(src + step + voff), (lds_v*)(dst + u * 1024), 16, 0, 0);
+                if (MODE == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_v*)(dst + u * 1024), 16, voff, step, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n s_nop 0" ::"v"(c0), "v"(c1));
+    const long long t1 = __builtin_readcyclecounter();
+    float acc = 0.f;
+    for (int i = 0; i < 16; ++i) acc += c0[i] + c1[i];
+    out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc + smem[threadIdx.x];
+    if (lane == 0 && blockIdx.x == 17) stamp[wave] = t1 - t0;
+}
+
+template <int NP, int MODE>
+static void run_dma(const char* what, const unsigned char* src, float* d, long long* st) {
+    HIP_OK(hipMemset(st, 0, 64 * 8));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((kdma<NP, MODE>), dim3(256), dim3(512), 0, 0, 1.0f, src, d, st, 8);
+    HIP_OK(hipEventRecord(e0));
+    hipLaunchKernelGGL((kdma<NP, MODE>), dim3(256), dim3(512), 0, 0, 1.0f, src, d, st, 8);
+    HIP_OK(hipEventRecord(e1));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    long long h[8];
+    HIP_OK(hipMemcpy(h, st, 64, hipMemcpyDeviceToHost));
+    // two waves per SIMD: SIMD cycles per 8-MFMA iteration of BOTH waves = the younger wave's total / ITER (it finishes last)
+    const double older = (double)h[0] / ITER, younger = (double)h[4] / ITER;
+    printf("  8 MFMAs + %d pieces, %-34s | cycles per iteration: older wave %6.1f, younger %6.1f  (%.0f us; 2 x 8 bare MFMAs = 512)\n", NP, what,
+           older, younger, ms * 1e3);
+}
+
 __global__ __launch_bounds__(512) void k(int ra, int rb, float seed, float* out, long long* stamp) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = wave < 4 ? ra : rb;
@@ -176,5 +241,16 @@ int main() {
     run_mix<6, 2>(d, st);
     run_mix<8, 2>(d, st);
     run_mix<10, 2>(d, st);
+    printf("LDS-DMA pieces beside MFMAs (8 waves = 2 per SIMD, one workgroup per CU):\n");
+    unsigned char* src;
+    HIP_OK(hipMalloc(&src, 8 << 20));
+    HIP_OK(hipMemset(src, 1, 8 << 20));
+    run_dma<0, 0>("(none)", src, d, st);
+    run_dma<2, 0>("per-lane 64-bit addresses", src, d, st);
+    run_dma<2, 1>("uniform base + 32-bit lane offset", src, d, st);
+    run_dma<2, 2>("buffer resource + 32-bit offset", src, d, st);
+    run_dma<4, 0>("per-lane 64-bit addresses", src, d, st);
+    run_dma<4, 1>("uniform base + 32-bit lane offset", src, d, st);
+    run_dma<4, 2>("buffer resource + 32-bit offset", src, d, st);
     return 0;
 }
