@@ -38,6 +38,17 @@ typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef __attribute__((address_space(1))) const void glb_ptr_t;
 constexpr int ASTAGE = 16384;   // K tile (8 KiB) + Vt tile (8 KiB)
 
+// LDS-DMA pieces are BUFFER loads: resource = the (batch, head)'s operand, per-lane 32-bit byte offset, the tile as the scalar offset.
+// tools/coissue_lab: beside a wave's MFMA stream a global_load_lds piece (per-lane 64-bit addresses) costs its SIMD ~65 cycles, a
+// buffer_load ... lds piece ~5.  num_records = the operand's valid bytes: rows past the end read as zeros (the kernels mask them
+// anyway), so no per-lane row clamp is needed.
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* base, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7FFFFFFFl ? 0x7FFFFFFFl : bytes), 0x00020000);
+}
+
 // Lab builds only (tools/build_attn_lab.sh trace -DM324_ATTN_TRACE, tools/attn_trace.py): the first wave of each half of one
 // workgroup in the middle of the grid stamps the shader clock at its phase boundaries of key tiles 60-75 into the LSE buffer.
 #ifdef M324_ATTN_TRACE
@@ -143,32 +154,30 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
 
     // LDS-DMA staging.  A wave-instruction fills 8 tile rows (1 KiB); the 8 row groups of the K tile and of the Vt
     // tile are dealt to the waves (NWV = 4: groups 2w, 2w+1; NWV = 8: group w).  Lane l fills row r = 8g + (l >> 3),
-    // slot l & 7, which holds chunk (l & 7) ^ ((r >> 1) & 7).  K rows past Lk are clamped (their scores are masked);
+    // slot l & 7, which holds chunk (l & 7) ^ ((r >> 1) & 7).  K rows past Lk read as zeros (their scores are masked);
     // Vt is zero padded.
     constexpr int GPW = 8 / NWV;                 // row groups per wave per operand
     constexpr int PPT = 2 * GPW;                 // LDS-DMA pieces per wave per tile
-    int srow[GPW], scol[GPW];
-    const bf16_t* gv[GPW];
+    unsigned vk[GPW], vv[GPW];                   // the lane's byte offsets inside a K / V tile of the (batch, head)
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
-        srow[i] = (wave * GPW + i) * 8 + (lane >> 3);
-        scol[i] = ((lane & 7) ^ ((srow[i] >> 1) & 7)) * 8;
+        const int srow = (wave * GPW + i) * 8 + (lane >> 3);
+        const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * 8;
+        vk[i] = (unsigned)((srow * 64 + scol) * 2);
         // VROW: V rows are keys; slot swizzle c ^ 4 ((row >> 1) & 1) keeps the 4 rows x 64 B of a transposing read apart
-        gv[i] = VROW ? Vh + ((lane & 7) ^ (4 * ((srow[i] >> 1) & 1))) * 8 : Vh + (long)srow[i] * Lkp + scol[i];
+        vv[i] = VROW ? (unsigned)((srow * 64 + ((lane & 7) ^ (4 * ((srow >> 1) & 1))) * 8) * 2)
+                     : (unsigned)(((long)srow * Lkp + scol) * 2);
     }
+    const __amdgpu_buffer_rsrc_t rk = dma_rsrc(Kh, (long)Lk * 128);
+    const __amdgpu_buffer_rsrc_t rv = dma_rsrc(Vh, VROW ? (long)Lk * 128 : 64l * Lkp * 2);
     auto issue_tile = [&](int t) {
         const int kv0 = t * KV;
         unsigned char* sk = smem + (t % NST) * ASTAGE + wave * (GPW * 1024);
         unsigned char* sv = sk + 8192;
 #pragma unroll
-        for (int i = 0; i < GPW; ++i) {
-            const bf16_t* gk = Kh + (long)min(kv0 + srow[i], Lk - 1) * 64 + scol[i];
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)gk, (lds_ptr_t*)(sk + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < GPW; ++i) dma_piece(rk, sk + i * 1024, vk[i], (unsigned)(kv0 * 128));
 #pragma unroll
-        for (int i = 0; i < GPW; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(VROW ? gv[i] + (long)min(kv0 + srow[i], Lk - 1) * 64 : gv[i] + kv0),
-                                             (lds_ptr_t*)(sv + i * 1024), 16, 0, 0);
+        for (int i = 0; i < GPW; ++i) dma_piece(rv, sv + i * 1024, vv[i], (unsigned)(VROW ? kv0 * 128 : kv0 * 2));
     };
 
     f32x16 o[NQ][2];
@@ -431,15 +440,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
 // Scale conventions as m324_attention_bwd (include/m324.h): dQ = scale * dS K, dK = ln2 * dS^T Qs.
 // one 64-row x 128-byte tile by LDS-DMA: the 8 row groups are dealt to the NWV waves (2 pieces per wave at 4 waves, 1 at 8)
 template <int NWV>
-__device__ __forceinline__ void dma_rows(unsigned char* part, const bf16_t* src, long row_stride, int row0, int max_row, long col0,
-                                         int wave, int lane) {
+__device__ __forceinline__ void dma_rows(unsigned char* part, __amdgpu_buffer_rsrc_t rs, long row_stride, int row0, long col0, int wave,
+                                         int lane) {
     constexpr int G = 8 / NWV;
+    const unsigned soff = (unsigned)(((long)row0 * row_stride + col0) * 2);
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int r = (wave * G + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const bf16_t* g = src + (long)min(row0 + r, max_row) * row_stride + col0 + c * 8;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t*)g, (lds_ptr_t*)(part + (wave * G + i) * 8 * 128), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)(part + (wave * G + i) * 8 * 128), 16,
+                                                 (unsigned)(((long)r * row_stride + c * 8) * 2), soff, 0, 0);
     }
 }
 
@@ -483,11 +493,12 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dq_mfma_kernel(const bf16_t
         dof[ks] = *reinterpret_cast<bf16x8*>(&c);
     }
     const float l2 = qok ? lse[bh * Lq + q] : 0.f, dl = qok ? D[bh * Lq + q] : 0.f;
-    auto issue = [&](int t) {
+    const __amdgpu_buffer_rsrc_t rK = dma_rsrc(Kh, (long)Lk * 128), rV = dma_rsrc(Vh, (long)Lk * 128), rKt = dma_rsrc(Kth, 64l * Lkp * 2);
+    auto issue = [&](int t) {                                   // rows past Lk read as zeros (masked below)
         unsigned char* st = smem + (t & 1) * 24576;
-        dma_rows<NWV>(st, Kh, 64, t * KV, Lk - 1, 0, wave, lane);
-        dma_rows<NWV>(st + 8192, Vh, 64, t * KV, Lk - 1, 0, wave, lane);
-        dma_rows<NWV>(st + 16384, Kth, Lkp, 0, 63, (long)t * KV, wave, lane);
+        dma_rows<NWV>(st, rK, 64, t * KV, 0, wave, lane);
+        dma_rows<NWV>(st + 8192, rV, 64, t * KV, 0, wave, lane);
+        dma_rows<NWV>(st + 16384, rKt, Lkp, 0, (long)t * KV, wave, lane);
     };
     f32x16 acc[2];
 #pragma unroll
@@ -598,18 +609,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
         kf[ks] = *reinterpret_cast<bf16x8*>(&a);
         vf[ks] = *reinterpret_cast<bf16x8*>(&c);
     }
+    const __amdgpu_buffer_rsrc_t rQ = dma_rsrc(Qh, (long)Lq * 128), rdO = dma_rsrc(dOh, (long)Lq * 128), rQt = dma_rsrc(Qth, 64l * Lqp * 2),
+                                 rdOt = dma_rsrc(dOth, 64l * Lqp * 2), rL = dma_rsrc(lseh, (long)Lq * 4), rD = dma_rsrc(Dh, (long)Lq * 4);
     auto issue = [&](int t) {
         unsigned char* st = smem + (t & 1) * 32768;
-        dma_rows<NWV>(st, Qh, 64, t * KV, Lq - 1, 0, wave, lane);
-        dma_rows<NWV>(st + 8192, dOh, 64, t * KV, Lq - 1, 0, wave, lane);
-        dma_rows<NWV>(st + 16384, Qth, Lqp, 0, 63, (long)t * KV, wave, lane);
-        dma_rows<NWV>(st + 24576, dOth, Lqp, 0, 63, (long)t * KV, wave, lane);
-        // lse / D of the tile's queries: one 4-byte-per-lane LDS-DMA each (256 B), by waves 0 and 1; queries past the end are
-        // clamped here and masked where they are used
-        if (wave < 2) {
-            const float* src = (wave == 0 ? lseh : Dh) + min(t * KV + lane, Lq - 1);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)src, (lds_ptr_t*)(smem + 65536 + (t & 1) * 512 + wave * 256), 4, 0, 0);
-        }
+        dma_rows<NWV>(st, rQ, 64, t * KV, 0, wave, lane);
+        dma_rows<NWV>(st + 8192, rdO, 64, t * KV, 0, wave, lane);
+        dma_rows<NWV>(st + 16384, rQt, Lqp, 0, (long)t * KV, wave, lane);
+        dma_rows<NWV>(st + 24576, rdOt, Lqp, 0, (long)t * KV, wave, lane);
+        // lse / D of the tile's queries: one 4-byte-per-lane LDS-DMA each (256 B), by waves 0 and 1; queries past the end read
+        // as zeros here and are masked where they are used
+        if (wave < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? rL : rD, (lds_ptr_t*)(smem + 65536 + (t & 1) * 512 + wave * 256), 4,
+                                                     (unsigned)(lane * 4), (unsigned)(t * KV * 4), 0, 0);
     };
     f32x16 ak[2], av[2];
 #pragma unroll
