@@ -131,22 +131,23 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
     C += (long)blockIdx.y * ep.strideC;
 
     // this wave stages row groups g = wave*4 + i (8 rows each) of both operands
-    const TIN* ga[4];
-    const TIN* gb[4];
+    unsigned va[4], vb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c * EPC;
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c * EPC;
+        va[i] = (unsigned)(((long)min(r, M - 1 - m0) * lda + c * EPC) * sizeof(TIN));
+        vb[i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + c * EPC) * sizeof(TIN));
     }
+    const __amdgpu_buffer_rsrc_t ra = dma_rsrc(A + (long)m0 * lda), rb = dma_rsrc(W + (long)n0 * ldw);
     auto issue_tile = [&](int kt, int buf) {
         unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave * 4096;
         unsigned char* sb = sa + TILE_BYTES;
+        const unsigned so = (unsigned)(kt * BK * sizeof(TIN));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)kt * BK), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)kt * BK), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
+            dma_piece(ra, sa + i * 1024, va[i], so);
+            dma_piece(rb, sb + i * 1024, vb[i], so);
         }
     };
 
@@ -201,22 +202,23 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
     const int m0 = tm * BM5, n0 = tn * BN5;
 
     // staging: 32 row groups of 8 rows per operand; wave w takes groups w*4 .. w*4+3 of A and of W
-    const TIN* ga[4];
-    const TIN* gb[4];
+    unsigned va[4], vb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c * EPC;
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c * EPC;
+        va[i] = (unsigned)(((long)min(r, M - 1 - m0) * lda + c * EPC) * sizeof(TIN));
+        vb[i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + c * EPC) * sizeof(TIN));
     }
+    const __amdgpu_buffer_rsrc_t ra = dma_rsrc(A + (long)m0 * lda), rb = dma_rsrc(W + (long)n0 * ldw);
     auto issue_tile = [&](int kt, int buf) {
         unsigned char* sa = smem + buf * STAGE5 + wave * 4096;
         unsigned char* sb = sa + BM5 * ROWB;
+        const unsigned so = (unsigned)(kt * BK * sizeof(TIN));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ga[i] + (long)kt * BK), (lds_ptr_t*)(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gb[i] + (long)kt * BK), (lds_ptr_t*)(sb + i * 1024), 16, 0, 0);
+            dma_piece(ra, sa + i * 1024, va[i], so);
+            dma_piece(rb, sb + i * 1024, vb[i], so);
         }
     };
 
@@ -349,21 +351,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
             va[i] = (unsigned)(((long)min(r, M - 1 - m0) * lda + c) * 2);
             vb[i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + c) * 2);
         }
-        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A + (long)m0 * lda), 0, 0x7FFFFFFF, 0x00020000);
-        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W + (long)n0 * ldw), 0, 0x7FFFFFFF, 0x00020000);
+        ra = dma_rsrc(A + (long)m0 * lda);
+        rb = dma_rsrc(W + (long)n0 * ldw);
     };
     tile_setup(blockIdx.x);
     auto issue2a = [&](int i0, int st, int pos) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t*)(d + i * 1024), 16, va[i0 + i], st * 128, 0, 0);
+            dma_piece(ra, d + i * 1024, va[i0 + i], (unsigned)(st * 128));
     };
     auto issue2b = [&](int i0, int st, int pos) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t*)(d + i * 1024), 16, vb[i0 + i], st * 128, 0, 0);
+            dma_piece(rb, d + i * 1024, vb[i0 + i], (unsigned)(st * 128));
     };
 
     f32x16 acc[4][2];
@@ -519,20 +521,20 @@ __global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __rest
     const int m0 = tm * BM, n0 = tn * BN;
 
     // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
-    const bf16_t* ga[4];
-    const bf16_t* gb[4];
+    unsigned ga[4], gb[4];                                  // byte offsets inside the tile's row panels
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
         const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-        ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
-        gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
+        ga[i] = (unsigned)(((long)min(r, M - 1 - m0) * lda + c) * 2);
+        gb[i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + c) * 2);
     }
-    auto issue2 = [&](const bf16_t* const (&g)[4], int i0, int st, int pos) {
+    const __amdgpu_buffer_rsrc_t ra = dma_rsrc(A + (long)m0 * lda), rb = dma_rsrc(W + (long)n0 * ldw);
+    auto issue2 = [&](const unsigned (&g)[4], int i0, int st, int pos) {
         unsigned char* d = smem + pos * CHUNK13 + wave * 4096 + i0 * 1024;
+        const bool isa = &g[0] == &ga[0];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i0 + i] + (long)st * 64), (lds_ptr_t*)(d + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) dma_piece(isa ? ra : rb, d + i * 1024, g[i0 + i], (unsigned)(st * 128));
     };
 
     f32x16 acc[2][2];
@@ -755,15 +757,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 
     // staging: piece p = rows 4p .. 4p+3; wave w moves pieces 4w .. 4w+3 of X and of Y
     const int sr = lane >> 4, sc = (lane & 15) ^ (4 * sr);       // row within the piece, source chunk of this lane's slot
-    const bf16_t* gx = X + min(n0 + sc * 8, N - 8);
-    const bf16_t* gy = Y + min(j0 + sc * 8, Kc - 8);
+    const unsigned cx = (unsigned)(min(n0 + sc * 8, N - 8) * 2), cy = (unsigned)(min(j0 + sc * 8, Kc - 8) * 2);
+    const __amdgpu_buffer_rsrc_t rx = dma_rsrc(X + (long)mbeg * ldx), ry = dma_rsrc(Y + (long)mbeg * ldy);
     auto issue = [&](int t, int stage) {
         unsigned char* st = smem + stage * 2 * TOP + wave * 4096;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const long row = min(mbeg + t * 64 + (wave * 4 + p) * 4 + sr, mend - 1);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gx + row * ldx), (lds_ptr_t*)(st + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gy + row * ldy), (lds_ptr_t*)(st + TOP + p * 1024), 16, 0, 0);
+            const long row = min(t * 64 + (wave * 4 + p) * 4 + sr, mend - 1 - mbeg);      // row inside this slice of the tokens
+            dma_piece(rx, st + p * 1024, (unsigned)(row * ldx * 2) + cx, 0);
+            dma_piece(ry, st + TOP + p * 1024, (unsigned)(row * ldy * 2) + cy, 0);
         }
     };
 
@@ -844,26 +846,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __re
 
     // staging: piece p = rows 2p, 2p+1 of the half-tile; wave w moves pieces 2w, 2w+1 (rows 4w .. 4w+3) of X and of Y
     const int sr = lane >> 5;                    // row within the piece
-    const bf16_t* gx[2];
-    const bf16_t* gy[2];
+    unsigned gx[2], gy[2];                         // byte offsets inside this slice of the tokens
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int r = (wave * 2 + p) * 2 + sr;   // row within the half-tile
         const int c = (lane & 31) ^ (4 * (r & 3));
-        gx[p] = X + (long)(mbeg + r) * ldx + min(n0 + c * 8, N - 8);
-        gy[p] = Y + (long)(mbeg + r) * ldy + min(j0 + c * 8, Kc - 8);
+        gx[p] = (unsigned)(((long)r * ldx + min(n0 + c * 8, N - 8)) * 2);
+        gy[p] = (unsigned)(((long)r * ldy + min(j0 + c * 8, Kc - 8)) * 2);
     }
+    const __amdgpu_buffer_rsrc_t rx = dma_rsrc(X + (long)mbeg * ldx), ry = dma_rsrc(Y + (long)mbeg * ldy);
     auto issue_x = [&](int h, int slot) {
         unsigned char* st = smem + slot * 2 * TOP + wave * 2048;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gx[p] + (long)h * 32 * ldx), (lds_ptr_t*)(st + p * 1024), 16, 0, 0);
+        for (int p = 0; p < 2; ++p) dma_piece(rx, st + p * 1024, gx[p], (unsigned)((long)h * 32 * ldx * 2));
     };
     auto issue_y = [&](int h, int slot) {
         unsigned char* st = smem + slot * 2 * TOP + TOP + wave * 2048;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(gy[p] + (long)h * 32 * ldy), (lds_ptr_t*)(st + p * 1024), 16, 0, 0);
+        for (int p = 0; p < 2; ++p) dma_piece(ry, st + p * 1024, gy[p], (unsigned)((long)h * 32 * ldy * 2));
     };
 
     f32x16 acc[4][2];

@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
     const int NS = K / 64;
 
     // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 8w .. 8w+7 of A and of W
-    const bf16_t* ga[8];
-    const bf16_t* gb[8];
+    unsigned ga[8], gb[8];                                  // byte offsets inside the tile's row panels (buffer-form LDS-DMA)
+    __amdgpu_buffer_rsrc_t ra, rb;
     int m0 = 0, n0 = 0;
     auto tile_setup = [&](int t) {
         int tm, tn;
@@ -45,15 +45,17 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
         for (int i = 0; i < 8; ++i) {
             const int r = (wave * 8 + i) * 8 + (lane >> 3);
             const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-            ga[i] = A + (long)min(m0 + r, M - 1) * lda + c;
-            gb[i] = W + (long)min(n0 + r, N - 1) * ldw + c;
+            ga[i] = (unsigned)(((long)min(r, M - 1 - m0) * lda + c) * 2);
+            gb[i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + c) * 2);
         }
+        ra = dma_rsrc(A + (long)m0 * lda);
+        rb = dma_rsrc(W + (long)n0 * ldw);
     };
-    auto issue4 = [&](const bf16_t* const (&g)[8], int i0, int st, int pos) {
+    auto issue4 = [&](const unsigned (&g)[8], int i0, int st, int pos) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 8192 + i0 * 1024;
+        const bool isa = &g[0] == &ga[0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i0 + i] + (long)st * 64), (lds_ptr_t*)(d + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) dma_piece(isa ? ra : rb, d + i * 1024, g[i0 + i], (unsigned)(st * 128));
     };
     auto issue_prologue = [&]() {                           // A_0, W_0, A_1 -> chunks 0, 1, 2
         issue4(ga, 0, 0, 0); issue4(ga, 4, 0, 0);
@@ -197,23 +199,24 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
     const int m0 = tm * 256, n0 = tn * 128;
 
     // LDS-DMA pieces of 8 rows x 128 B: wave w moves row groups 8w .. 8w+7 of A (32 groups) and 4w .. 4w+3 of W (16 groups)
-    const bf16_t* g[12];
+    unsigned g[12];                                         // byte offsets inside the tile's row panels (buffer-form LDS-DMA)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = (wave * 8 + i) * 8 + (lane >> 3);
-        g[i] = A + (long)min(m0 + r, M - 1) * lda + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        g[i] = (unsigned)(((long)min(r, M - 1 - m0) * lda + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
-        g[8 + i] = W + (long)min(n0 + r, N - 1) * ldw + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        g[8 + i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
     }
+    const __amdgpu_buffer_rsrc_t ra = dma_rsrc(A + (long)m0 * lda), rb = dma_rsrc(W + (long)n0 * ldw);
     auto issue3 = [&](int i0, int st, int slot) {           // pieces i0 .. i0+2 of stage st
         unsigned char* base = smem + slot * STAGE12;
 #pragma unroll
         for (int i = i0; i < i0 + 3; ++i) {
             unsigned char* d = i < 8 ? base + wave * 8192 + i * 1024 : base + 32768 + wave * 4096 + (i - 8) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(g[i] + (long)st * 64), (lds_ptr_t*)d, 16, 0, 0);
+            dma_piece(i < 8 ? ra : rb, d, g[i], (unsigned)(st * 128));
         }
     };
 

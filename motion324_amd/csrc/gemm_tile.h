@@ -862,6 +862,16 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef __attribute__((address_space(1))) const void glb_ptr_t;
 
+// LDS-DMA pieces are BUFFER loads (tools/coissue_lab: beside a wave's MFMA stream a buffer_load ... lds piece costs its SIMD ~5
+// cycles, a global_load_lds piece with per-lane 64-bit addresses ~65): the resource starts at the tile's first row, the lane
+// carries a 32-bit byte offset inside the tile's row panel, the K position rides in the scalar offset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)lds, 16, voff, soff, 0, 0);
+}
+
 constexpr int BM5 = 256, BN5 = 256;              // tile of the 256-wide kernels (v5, v7, v10, v11)
 constexpr int CHUNK10 = 256 * ROWB;              // 32 KiB: one operand's 256 rows x 64 k of one K-stage (v10, v11)
 
