@@ -770,7 +770,7 @@ def run_train(args, D: Dist):
                                 if training.TRAIN_STORE != "0" else "checkpoint per block + recompute (M324_TRAIN_STORE=0)"),
                 "roofline": roofline_from(rec, 1, args.precision, "HIP events around every GEMM / attention-forward launch of one extra "
                                           "training step (forward, dgrad, wgrad; the attention backward kernels are "
-                                          f"not in the classes); symbols as in profiles/{PROFILE_ROUND}_p5_train_kernel_stats.md"),
+                                          f"not in the classes); symbols as in profiles/{PROFILE_ROUND}_p7_train_kernel_stats.md"),
                 "cpu_baseline": None}
     return line
 
