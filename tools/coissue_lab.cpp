@@ -149,6 +149,7 @@ __global__ __launch_bounds__(512) void kdma(float seed, const unsigned char* __r
     const unsigned char* lanep = src + voff;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, 1 << 30, 0x00020000);
     unsigned char* dst = smem + wave * 8192;
+    uint4 ld[4] = {make_uint4(1, 2, 3, 4), make_uint4(5, 6, 7, 8), make_uint4(9, 10, 11, 12), make_uint4(13, 14, 15, 16)};
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
@@ -160,6 +161,11 @@ __global__ __launch_bounds__(512) void kdma(float seed, const unsigned char* __r
                 if (MODE == 0) __builtin_amdgcn_global_load_lds((glb_v*)(lanep + step), (lds_v*)(dst + u * 1024), 16, 0, 0);
                 if (MODE == 1) __builtin_amdgcn_global_load_lds((glb_v*)(src + step + voff), (lds_v*)(dst + u * 1024), 16, 0, 0);
                 if (MODE == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_v*)(dst + u * 1024), 16, voff, step, 0, 0);
+                // plain 16-byte loads into registers and 16-byte stores, per-lane 64-bit address vs buffer resource
+                if (MODE == 3) ld[u & 3] = *reinterpret_cast<const uint4*>(lanep + step);
+                if (MODE == 4) ld[u & 3] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, step, 0));
+                if (MODE == 5) *reinterpret_cast<uint4*>(const_cast<unsigned char*>(lanep) + step + (4 << 20)) = ld[u & 3];
+                if (MODE == 6) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, ld[u & 3]), rsrc, voff + (4 << 20), step, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(512) void kdma(float seed, const unsigned char* __r
     const long long t1 = __builtin_readcyclecounter();
     float acc = 0.f;
     for (int i = 0; i < 16; ++i) acc += c0[i] + c1[i];
-    out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc + smem[threadIdx.x];
+    out[(blockIdx.x & 255) * 512 + threadIdx.x] = acc + smem[threadIdx.x] + (float)(ld[0].x + ld[1].y + ld[2].z + ld[3].w);
     if (lane == 0 && blockIdx.x == 17) stamp[wave] = t1 - t0;
 }
 
@@ -243,8 +249,8 @@ int main() {
     run_mix<10, 2>(d, st);
     printf("LDS-DMA pieces beside MFMAs (8 waves = 2 per SIMD, one workgroup per CU):\n");
     unsigned char* src;
-    HIP_OK(hipMalloc(&src, 8 << 20));
-    HIP_OK(hipMemset(src, 1, 8 << 20));
+    HIP_OK(hipMalloc(&src, 16 << 20));
+    HIP_OK(hipMemset(src, 1, 16 << 20));
     run_dma<0, 0>("(none)", src, d, st);
     run_dma<2, 0>("per-lane 64-bit addresses", src, d, st);
     run_dma<2, 1>("uniform base + 32-bit lane offset", src, d, st);
@@ -252,5 +258,12 @@ int main() {
     run_dma<4, 0>("per-lane 64-bit addresses", src, d, st);
     run_dma<4, 1>("uniform base + 32-bit lane offset", src, d, st);
     run_dma<4, 2>("buffer resource + 32-bit offset", src, d, st);
+    printf("16-byte loads into registers / 16-byte stores beside MFMAs (the same harness; 'pieces' = instructions per 8 MFMAs):\n");
+    run_dma<2, 3>("global_load_dwordx4 (64-bit addr)", src, d, st);
+    run_dma<2, 4>("buffer_load_dwordx4", src, d, st);
+    run_dma<2, 5>("global_store_dwordx4 (64-bit addr)", src, d, st);
+    run_dma<2, 6>("buffer_store_dwordx4", src, d, st);
+    run_dma<4, 5>("global_store_dwordx4 (64-bit addr)", src, d, st);
+    run_dma<4, 6>("buffer_store_dwordx4", src, d, st);
     return 0;
 }
