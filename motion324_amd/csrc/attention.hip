@@ -17,7 +17,7 @@
 // 8-key A fragment is ONE contiguous 16-byte chunk.
 // LDS per stage: K tile [64 kv][64 d] and Vt tile [64 d][64 kv], rows of 128 bytes (bf16), 16-byte chunks
 // XOR-swizzled (chunk ^ ((row >> 1) & 7)) so fragment reads are conflict-free ds_read_b128.  Tiles are
-// staged by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the source address) into a 3-stage ring:
+// staged by LDS-DMA (buffer_load_dwordx4 ... lds, swizzle applied to the source offset) into a 3-stage ring:
 // two tiles in flight, counted vmcnt + raw s_barrier, no ds_write pass and no staging registers.
 // The fp32 parity variant uses v_mfma_f32_32x32x2_f32 on padded fp32 tiles (single buffered).
 #include <stdio.h>

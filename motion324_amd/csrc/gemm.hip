@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TIN* __restrict__ A,
 
 // ------------------------------------------------------------------------------------------------
 // v2: same tile / LDS image / MFMA schedule, but the K-tiles are staged by LDS-DMA
-// (global_load_lds_dwordx4: HBM -> LDS without a VGPR round trip and without the ds_write pass that
+// (buffer_load_dwordx4 ... lds: HBM -> LDS without a VGPR round trip and without the ds_write pass that
 // made v1 LDS-bound: 32 KiB of ds_write_b128 per K-tile at ~79 B/clk/CU is ~415 cycles against 512
 // cycles of MFMA).  A wave-instruction writes 1 KiB = 8 tile rows linearly (LDS address = wave-uniform
 // base + lane * 16), so the XOR swizzle is applied to the SOURCE address: lane l fills row
