@@ -1222,6 +1222,10 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
     M324_REQUIRE(slices >= 1 && slices <= 65535 && (slices == 1 || strideC >= (long)N * ldc), "m324_gemm_tn: bad slicing");
     const int ks = ((M + slices - 1) / slices + 63) / 64 * 64;          // tokens per slice, whole 64-row tiles
     M324_REQUIRE((long)ks * (slices - 1) < M, "m324_gemm_tn: %d slices leave an empty slice for M=%d", slices, M);
+    // the LDS-DMA pieces address a slice's rows with 32-bit byte offsets from its first row (buffer loads, 2 GiB window)
+    M324_REQUIRE(((long)ks + 64) * (ldx > ldy ? ldx : ldy) * 2 < 0x7FFFFFFFl,
+                 "m324_gemm_tn: a slice of %d tokens x leading dimension %ld exceeds the 2 GiB the staging offsets cover; use more slices",
+                 ks, ldx > ldy ? ldx : ldy);
     // 256 x 256 tiles on the pipelined kernel when every slice is whole 32-token half-tiles and the output fills the tiles
     // (M324_GEMM_TN=128 forces the small kernel)
     const bool big = m324::tunable(m324::TUN_GEMM_TN) != 128 && M % 32 == 0 && N % 256 == 0 && Kc % 256 == 0 && M / slices >= 256;
@@ -1250,6 +1254,9 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
                      ((uintptr_t)a->W % 16) == 0,
                  "m324_gemm: A/W rows must be 16-byte aligned");
     M324_REQUIRE(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, "m324_gemm: leading dimension too small");
+    // LDS-DMA pieces address a tile's rows with 32-bit byte offsets from the tile's first row (buffer loads, 2 GiB window)
+    M324_REQUIRE(257l * (a->lda > a->ldw ? a->lda : a->ldw) * esz + (long)a->K * esz < 0x7FFFFFFFl,
+                 "m324_gemm: leading dimension %ld too large for the 256-row staging window", a->lda > a->ldw ? a->lda : a->ldw);
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
     M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
                  "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
