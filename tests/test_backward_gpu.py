@@ -343,6 +343,54 @@ def test_attention_backward_mfma_against_autograd(tune, nw, B, H, Lq, Lk, shared
     assert rel_err(dK.float(), kd.grad) < 2e-2 and rel_err(dV.float(), vd.grad) < 2e-2
 
 
+def _poisoned_tail(t):
+    """A copy of t whose storage is followed directly by NaNs (the tensor is a leading view of a larger buffer)."""
+    big = torch.full((t.numel() + 65536,), float("nan"), dtype=t.dtype, device=t.device)
+    big[:t.numel()] = t.reshape(-1)
+    return big[:t.numel()].view(t.shape)
+
+
+@pytest.mark.parametrize("Lq,Lk", [(70, 70), (33, 200), (324, 324), (130, 129)])
+def test_attention_kernels_never_use_what_lies_behind_their_operands(Lq, Lk):
+    """The kernels stage K / V / Q / dO tiles by buffer-form LDS-DMA whose resources end with the operand (`num_records`):
+    rows of a ragged last tile that lie past the end must read as zeros -- they are multiplied by masked (zero) probabilities,
+    and 0 x NaN would poison the result.  Every operand here is followed DIRECTLY by NaNs in memory (one batch, one head, so
+    the tile overhang of the only head lands in the poison); forward with row-major and transposed V, then the backward."""
+    from motion324_amd import ops
+    dtype = torch.bfloat16
+    B, H = 1, 1
+    C = H * 64
+    dev = lambda t: t.to(dtype).to(DEV)
+    q_tok, k_tok, v_tok = (_q(_rand((L_, C), sd_, 1.2), dtype) for L_, sd_ in ((Lq, 41), (Lk, 42), (Lk, 43)))
+    dO_tok = _q(_rand((Lq, C), 44), dtype)
+    spq = ops.qkv_split(dev(q_tok), None, None, None, None, 0.0, B, Lq, H, dtype, q_scale=ops.Q_PRESCALE, train=True)
+    spk = ops.qkv_split(None, dev(k_tok), dev(v_tok), None, None, 0.0, B, Lk, H, dtype, train=True)
+    spdo = None
+    spq = {k: _poisoned_tail(v) for k, v in spq.items() if torch.is_tensor(v)}
+    spk = {k: _poisoned_tail(v) for k, v in spk.items() if torch.is_tensor(v)}
+    out = torch.empty((Lq, C), dtype=dtype, device=DEV)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=DEV)
+    ops.attention(spq["Q"], spk["K"], spk["Vt"], out, prescaled=True, lse=lse)
+    out_r = torch.empty((Lq, C), dtype=dtype, device=DEV)
+    ops.attention(spq["Q"], spk["K"], spk["V"], out_r, prescaled=True, v_rowmajor=True)
+    ref = _attn = torch.softmax((q_tok.double() @ k_tok.double().T) * 64 ** -0.5, -1) @ v_tok.double()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(out_r.float()).all()
+    assert rel_err(out.float(), ref) < 8e-3 and rel_err(out_r.float(), ref) < 8e-3
+    D = ops.attention_delta(out, dev(dO_tok), B, H, Lq)
+    spdo = {k: _poisoned_tail(v) for k, v in ops.qkv_split(dev(dO_tok), None, None, None, None, 0.0, B, Lq, H, dtype, train=True).items()
+            if torch.is_tensor(v)}
+    dQ, dK, dV = ops.attention_bwd_mfma(spq, spk, spdo, _poisoned_tail(lse), _poisoned_tail(D))
+    for t in (dQ, dK, dV):
+        assert torch.isfinite(t.float()).all()
+    qh = (spq["Q"].float().cpu().double() / ops.Q_PRESCALE).requires_grad_(True)
+    kd = spk["K"].float().cpu().double().requires_grad_(True)
+    vd = spk["V"].float().cpu().double().requires_grad_(True)
+    sc = torch.einsum("bhqd,bhkd->bhqk", qh, kd) * (64 ** -0.5)
+    o = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc, -1), vd).reshape(Lq, C)
+    o.backward(dO_tok.double())
+    assert rel_err(dQ.float(), qh.grad) < 2e-2 and rel_err(dK.float(), kd.grad) < 2e-2 and rel_err(dV.float(), vd.grad) < 2e-2
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K,slices", [(192, 768, 4096, 8), (768, 64, 1000 // 64 * 64 + 64, 3), (100, 52, 640, 4)])
 def test_gemm_splitk_matches_plain(dtype, M, N, K, slices):
