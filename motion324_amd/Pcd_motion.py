@@ -334,8 +334,13 @@ class Motion_Latent_Model(nn.Module):
         self.__dict__["_ag_busy"] = True                    # the capture's own warm-up / capture forwards stay eager
         try:
             res = ag(sample)
-        except Exception:                                   # capture invalidated, out of memory in the private pool, ...:
-            self.auto_graph = False                         # the eager path still serves the call
+        except Exception as exc:                            # capture invalidated, out of memory in the private pool, ...:
+            # the eager path still serves the call -- but say so once: a kernel fault during capture must not turn into a
+            # silent 20 % slowdown (eager passes leave the GPU idle between launches)
+            import warnings
+            warnings.warn(f"motion324_amd: hipGraph capture of the inference forward failed ({type(exc).__name__}: {exc}); "
+                          "this model continues with eager launches (model.auto_graph is now False)", RuntimeWarning, stacklevel=3)
+            self.auto_graph = False
             self._drop_auto_graph()
             try:
                 torch.cuda.synchronize()

@@ -869,6 +869,13 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
 }  // namespace
 
+// attention_pwg.hip: one wave per SIMD, hand-placed instruction stream (long sequences, pre-scaled Q, transposed Vt, Lk % 64 == 0)
+void m324_attn_pwg_launch(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B, int H, int Lq, int Lk,
+                          float* lse, hipStream_t s);
+static bool use_pwg(bool prescaled, bool vrow, bool nq2, int fnw, int Lq, int Lk) {
+    return m324::tunable(m324::TUN_ATTN_PWG) != 0 && prescaled && !vrow && !nq2 && fnw == 0 && Lq >= 2048 && Lk >= 512 && Lk % 64 == 0;
+}
+
 extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B,
                               int H, int Lq, int Lk, float scale, int q_prescaled, float* lse, int dtype, void* stream) {
     M324_REQUIRE(Q && K && Vt && O, "m324_attention: null pointer");
@@ -890,6 +897,12 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         // eight waves per workgroup for long query sets (M324_ATTN_NW=4|8 forces: A/B runs, tests)
         const int fnw = m324::tunable(m324::TUN_ATTN_NW);
         const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
+        if (use_pwg(q_prescaled != 0, vrow, nq2, fnw, Lq, Lk)) {        // M324_ATTN_PWG=0: the eight-wave kernel below (A/B runs, tests)
+            M324_REQUIRE((long)ceil_div(Lq, 256) * H * B < (1l << 31), "m324_attention: grid too large");
+            m324_attn_pwg_launch(Q, q_bstride, K, Vt, O, ldo, B, H, Lq, Lk, lse, s);
+            M324_CHECK_LAUNCH("m324_attention");
+            return M324_OK;
+        }
         dim3 g2(ceil_div(Lq, nq2 ? 2 * QB : (w8 ? 2 * QB : QB)), H, B);
         // XCD-aware flat grid for the 8-wave kernel (M324_ATTN_FLAT=0 keeps the 3-D grid: A/B runs)
         // The same flat order for the short sequences with several query tiles per (batch, head) -- the per-frame blocks:
@@ -948,6 +961,10 @@ extern "C" int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int 
     const bool nq2 = m324::tunable(m324::TUN_ATTN_NQ2) != 0 && Lq >= 1024 && !vrow;
     const int fnw = m324::tunable(m324::TUN_ATTN_NW);
     const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
+    if (use_pwg(ps, vrow, nq2, fnw, Lq, Lk)) {
+        snprintf(buf, (size_t)n, "attn_pwg_kernel grid=%ldx1x1", (long)ceil_div(Lq, 256) * H * B * 256);
+        return 4;
+    }
     const long gx = ceil_div(Lq, (nq2 || w8) ? 2 * QB : QB);
     const int nwv = w8 ? 8 : 4;
     const int flat = m324::tunable(m324::TUN_ATTN_FLAT);

@@ -1,0 +1,494 @@
+#!/usr/bin/env python3
+"""Writes motion324_amd/csrc/attn_pwg_asm.inc: the hand-placed instruction stream of the one-wave-per-SIMD attention forward
+(attention_pwg.hip).  Run it after editing; the .inc is committed, the build does not need this script.
+
+Why a generator: on gfx950 a wave's plain VALU instructions DO issue in the shadow of its own MFMAs (tools/issue_lab, round 4:
+MFMA + 4 v_fma_f32 = 33.5 cycles, + 4 plain + 2 v_exp_f32 = 38-41), but only when they sit between the MFMAs in program order --
+and hipcc does not place them there (round 3's compiler-scheduled lab paid 32 + 2.3 N).  So the tile loop is written out
+instruction by instruction: 32 MFMAs per 64-key tile and wave, ~10 issue slots of softmax / LDS reads / LDS-DMA between
+consecutive MFMAs.  The script keeps the register map symbolic, spreads the filler streams over the MFMA gaps by target
+position, and checks the hazards the assembler does not (MFMA result -> VALU read, VALU -> MFMA operand, transcendental ->
+dependent VALU, the ds_read -> MFMA waits by construction).
+
+Structure of a workgroup (4 waves = 256 queries, wave = 64 queries = two 32-row blocks n = 0, 1):
+  software pipeline over the key tiles t:  S(t+1) = K(t+1) Q^T - m_ref  ||  P(t) = exp2(S(t)), row sums, bf16  ||  O += Vt(t) P(t)
+  S lives in two VGPR sets A / B that swap roles every tile (the loop body is emitted twice).
+Register map (explicit; the asm statement clobbers them):
+  v32-35 kbase[ks]   v36-39 aK[ks]   v40-43 aV[j]   v44-47 l[n][2]   v48-49 mx[n]   v50-51 m_ref[n]   v52-59 T0-T7   v60 floor
+  v64-127 SA[n][kb]  v128-191 SB[n][kb]  v192-223 PF[n][j] (bf16 P^T fragments)  v224-255 MR[n] (= -m_ref, the C operand)
+  a0-63 O[n][db]     a64-95 QF[n][ks]    a96-127 KF[kb][ks]   a128-159 VF[db][j]
+  s50 t  s51 nt-1  s52 K soff of the tile being issued  s53 V soff  s54 tile index being issued  s55-63 scratch
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# ------------------------------------------------------------------------------------------------ registers
+def v(i, n=1):
+    return f"v{i}" if n == 1 else f"v[{i}:{i + n - 1}]"
+
+
+def a(i, n=1):
+    return f"a{i}" if n == 1 else f"a[{i}:{i + n - 1}]"
+
+
+KBASE, AK, AV, LSUM, MX, MREF, T, FLOOR = 32, 36, 40, 44, 48, 50, 52, 60
+S_SET = {"A": 64, "B": 128}
+PF0, MR0 = 192, 224
+O0, QF0, KF0, VF0 = 0, 64, 96, 128
+THR = "8.0"
+
+
+def S(x, n, kb, r=None):
+    b = S_SET[x] + n * 32 + kb * 16
+    return b if r is None else b + r
+
+
+def PF(n, j, i=None):
+    b = PF0 + n * 16 + j * 4
+    return b if i is None else b + i
+
+
+def MR(n):
+    return MR0 + n * 16
+
+
+def O(n, db, r=None):
+    b = O0 + n * 32 + db * 16
+    return b if r is None else b + r
+
+
+def QF(n, ks):
+    return QF0 + n * 16 + ks * 4
+
+
+def KF(kb, ks):
+    return KF0 + kb * 16 + ks * 4
+
+
+def VF(db, j):
+    return VF0 + db * 16 + j * 4
+
+
+# ------------------------------------------------------------------------------------------------ instruction records
+class I:
+    """One emitted line.  kind: mfma | valu | trans | ds | vmem | salu | wait | nop | label | branch | barrier.
+    rd / wr: sets of register names (strings like 'v64', 'a3') for the hazard checker; states: wait states it provides."""
+
+    def __init__(self, text, kind, rd=(), wr=(), states=1, note=""):
+        self.text, self.kind, self.rd, self.wr, self.states, self.note = text, kind, set(rd), set(wr), states, note
+
+
+def regs(prefix, base, n):
+    return [f"{prefix}{base + i}" for i in range(n)]
+
+
+def mfma_s(x, n, kb, ks):
+    d = S(x, n, kb)
+    c = MR(n) if ks == 0 else d
+    return I(f"v_mfma_f32_32x32x16_bf16 {v(d, 16)}, {a(KF(kb, ks), 4)}, {a(QF(n, ks), 4)}, {v(c, 16)}", "mfma",
+             rd=regs("a", KF(kb, ks), 4) + regs("a", QF(n, ks), 4) + regs("v", c, 16), wr=regs("v", d, 16))
+
+
+def mfma_pv(n, db, j):
+    d = O(n, db)
+    return I(f"v_mfma_f32_32x32x16_bf16 {a(d, 16)}, {a(VF(db, j), 4)}, {v(PF(n, j), 4)}, {a(d, 16)}", "mfma",
+             rd=regs("a", VF(db, j), 4) + regs("v", PF(n, j), 4) + regs("a", d, 16), wr=regs("a", d, 16))
+
+
+def valu(text, rd=(), wr=()):
+    return I(text, "valu", rd, wr)
+
+
+def trans(text, rd=(), wr=()):
+    return I(text, "trans", rd, wr)
+
+
+def salu(text):
+    return I(text, "salu")
+
+
+def nop(n):
+    return I(f"s_nop {n - 1}", "nop", states=n)
+
+
+def ds_read(dst_a, addr_v, off):
+    return I(f"ds_read_b128 {a(dst_a, 4)}, {v(addr_v)} offset:{off}", "ds", rd=[f"v{addr_v}"], wr=regs("a", dst_a, 4))
+
+
+# ------------------------------------------------------------------------------------------------ filler streams
+def stream_exp(x):
+    """exp2 / row sums / bf16 pack of S set x, in the order the P.V MFMAs consume the fragments: j = kb * 2 + (r >> 3)."""
+    out = []
+    for j in range(4):
+        kb, half = j >> 1, j & 1
+        for n in range(2):
+            for p in range(4):
+                r = half * 8 + 2 * p
+                s0, s1 = S(x, n, kb, r), S(x, n, kb, r + 1)
+                l0, l1 = LSUM + n * 2, LSUM + n * 2 + 1
+                grp = [
+                    trans(f"v_exp_f32_e32 {v(s0)}, {v(s0)}", [f"v{s0}"], [f"v{s0}"]),
+                    trans(f"v_exp_f32_e32 {v(s1)}, {v(s1)}", [f"v{s1}"], [f"v{s1}"]),
+                    valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(s0)}", [f"v{l0}", f"v{s0}"], [f"v{l0}"]),
+                    valu(f"v_add_f32_e32 {v(l1)}, {v(l1)}, {v(s1)}", [f"v{l1}", f"v{s1}"], [f"v{l1}"]),
+                    valu(f"v_cvt_pk_bf16_f32 {v(PF(n, j, p))}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{PF(n, j, p)}"]),
+                ]
+                for g in grp:
+                    g.note = f"j{j}"
+                out += grp
+    return out
+
+
+def stream_max(y):
+    """per-lane maximum of the lane's 32 scores of each query block of S set y: two interleaved v_max3 chains."""
+    out = []
+    for i in range(16):
+        for n in range(2):
+            kb, r = i >> 3, (i & 7) * 2
+            s0, s1 = S(y, n, kb, r), S(y, n, kb, r + 1)
+            m = MX + n
+            if i == 0:
+                out.append(valu(f"v_max_f32_e32 {v(m)}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{m}"]))
+            else:
+                out.append(valu(f"v_max3_f32 {v(m)}, {v(m)}, {v(s0)}, {v(s1)}", [f"v{m}", f"v{s0}", f"v{s1}"], [f"v{m}"]))
+    return out
+
+
+def stream_vreads():
+    return [ds_read(VF(db, j), AV + j, 8192 + db * 4096) for j in range(4) for db in range(2)]
+
+
+def stream_kreads():
+    return [ds_read(KF(kb, ks), AK + ks, kb * 4096) for ks in range(4) for kb in range(2)]
+
+
+def stream_dma():
+    """LDS-DMA of tile s54 (= t + 3) into ring stage s54 & 3: two K pieces, two Vt pieces per wave.  Unconditional: tiles past
+    the end read out of range (zeros, no memory traffic) into a stage nobody reads."""
+    out = [
+        salu("s_and_b32 s55, s54, 3"),
+        salu("s_lshl_b32 s55, s55, 14"),
+        salu("s_add_u32 s55, s55, %[wlds]"),          # LDS byte address of this wave's K pieces in that stage
+    ]
+    pieces = [("%[vk0]", "%[rk]", "s52", 0), ("%[vk1]", "%[rk]", "s52", 1024), ("%[vv0]", "%[rv]", "s53", 8192), ("%[vv1]", "%[rv]", "s53", 9216)]
+    for voff, rs, soff, lo in pieces:
+        out.append(salu(f"s_add_u32 m0, s55, {lo}"))
+        out.append(nop(1))
+        out.append(I(f"buffer_load_dwordx4 {voff}, {rs}, {soff} offen lds", "vmem"))
+    out += [salu("s_add_u32 s52, s52, 0x2000"), salu("s_add_u32 s53, s53, 0x80"), salu("s_add_u32 s54, s54, 1")]
+    return out
+
+
+def stream_addr():
+    """fragment read addresses of the next iteration: aV -> stage of tile t + 1, aK -> stage of tile t + 3 (s50 = t here)."""
+    out = [salu("s_add_u32 s56, s50, 1"), salu("s_and_b32 s56, s56, 3"), salu("s_lshl_b32 s56, s56, 14"),
+           salu("s_add_u32 s57, s50, 3"), salu("s_and_b32 s57, s57, 3"), salu("s_lshl_b32 s57, s57, 14")]
+    for j in range(4):
+        out.append(valu(f"v_add_u32_e32 {v(AV + j)}, s56, {v(KBASE + j)}", [f"v{KBASE + j}"], [f"v{AV + j}"]))
+    return out
+
+
+def stream_addr_k():
+    # must follow the K reads of this iteration (they use aK of tile t + 2)
+    return [valu(f"v_add_u32_e32 {v(AK + ks)}, s57, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]) for ks in range(4)]
+
+
+COST = {"valu": 1.0, "trans": 2.0, "ds": 1.0, "vmem": 1.0, "salu": 0.7, "nop": 0.3, "wait": 0.3}
+
+
+def spread(items, lo, hi):
+    """target gap positions for a stream: cumulative issue cost mapped linearly onto [lo, hi)."""
+    tot = sum(COST[i.kind] for i in items) or 1.0
+    acc, out = 0.0, []
+    for it in items:
+        out.append((lo + (hi - lo) * acc / tot, it))
+        acc += COST[it.kind]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ hazard checks
+def check(seq, what):
+    """seq: straight-line list of I.  Distances in wait states (every instruction 1, s_nop N = N + 1)."""
+    last_mfma_wr, last_valu_wr, last_trans_wr = {}, {}, {}
+    pos = 0
+    for ins in seq:
+        if ins.kind in ("valu", "trans"):
+            for r in ins.rd | ins.wr:
+                if r in last_mfma_wr and pos - last_mfma_wr[r] < 13:
+                    raise SystemExit(f"{what}: MFMA result {r} touched by VALU after {pos - last_mfma_wr[r]} states: {ins.text}")
+            for r in ins.rd:
+                if r in last_trans_wr and pos - last_trans_wr[r] < 2:
+                    raise SystemExit(f"{what}: transcendental result {r} consumed after {pos - last_trans_wr[r]} state: {ins.text}")
+        if ins.kind == "mfma":
+            for r in ins.rd:
+                if r in last_valu_wr and pos - last_valu_wr[r] < 3:
+                    raise SystemExit(f"{what}: VALU result {r} read by MFMA after {pos - last_valu_wr[r]} states: {ins.text}")
+        if ins.kind == "mfma":
+            for r in ins.wr:
+                last_mfma_wr[r] = pos
+        if ins.kind in ("valu", "trans"):
+            for r in ins.wr:
+                last_valu_wr[r] = pos
+                last_mfma_wr.pop(r, None)
+            if ins.kind == "trans":
+                for r in ins.wr:
+                    last_trans_wr[r] = pos
+            else:
+                for r in ins.wr:
+                    last_trans_wr.pop(r, None)
+        pos += ins.states
+    return True
+
+
+def check_order(seq, what):
+    """every P^T fragment register is written (this iteration) before the P.V MFMA that reads it."""
+    written = set()
+    for ins in seq:
+        if ins.kind == "mfma":
+            for r in ins.rd:
+                if r.startswith("v") and PF0 <= int(r[1:]) < PF0 + 32 and r not in written:
+                    raise SystemExit(f"{what}: {ins.text} reads {r} before this tile's pack wrote it")
+        for r in ins.wr:
+            written.add(r)
+
+
+# ------------------------------------------------------------------------------------------------ body
+def interleave(mfmas, timed):
+    """mfmas: list of I; timed: list of (target gap, I).  A filler with target g is emitted after MFMA floor(g); the streams keep
+    their internal order (stable sort)."""
+    timed = sorted(enumerate(timed), key=lambda e: (e[1][0], e[0]))
+    out, k = [], 0
+    for g, m in enumerate(mfmas):
+        out.append(m)
+        while k < len(timed) and timed[k][1][0] < g + 1:
+            out.append(timed[k][1][1])
+            k += 1
+    out += [e[1][1] for e in timed[k:]]
+    return out
+
+
+def slow_path(y, first, tag):
+    """the reference maximum moves (some score of S set y exceeded m_ref by more than THR) -- or is set for the first time."""
+    L = []
+    L.append(nop(16))
+    L.append(nop(16))                 # P.V MFMAs of this tile have written O; S(y) complete
+    for n in range(2):
+        m, t0, t1, sh, al = MX + n, T + 0, T + 1, T + 2, T + 3
+        L += [valu(f"v_mov_b32_e32 {v(t0)}, {v(m)}", [f"v{m}"], [f"v{t0}"]), valu(f"v_mov_b32_e32 {v(t1)}, {v(m)}", [f"v{m}"], [f"v{t1}"]),
+              nop(2), valu(f"v_permlane32_swap_b32_e32 {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{t0}", f"v{t1}"]), nop(2),
+              valu(f"v_max_f32_e32 {v(m)}, {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{m}"])]     # the row's maximum in both lanes
+        if first:
+            L.append(valu(f"v_mov_b32_e32 {v(sh)}, {v(m)}", [f"v{m}"], [f"v{sh}"]))
+        else:
+            L.append(valu(f"v_max_f32_e32 {v(sh)}, 0, {v(m)}", [f"v{m}"], [f"v{sh}"]))              # m_ref never decreases
+            L.append(trans(f"v_exp_f32_e64 {v(al)}, -{v(sh)}", [f"v{sh}"], [f"v{al}"]))
+            L.append(nop(2))
+            for i in range(2):
+                l = LSUM + n * 2 + i
+                L.append(valu(f"v_mul_f32_e32 {v(l)}, {v(al)}, {v(l)}", [f"v{l}", f"v{al}"], [f"v{l}"]))
+            for db in range(2):
+                for r in range(0, 16, 4):
+                    for i in range(4):
+                        L.append(I(f"v_accvgpr_read_b32 {v(T + 4 + i)}, {a(O(n, db, r + i))}", "valu", [], [f"v{T + 4 + i}"]))
+                    for i in range(4):
+                        L.append(valu(f"v_mul_f32_e32 {v(T + 4 + i)}, {v(al)}, {v(T + 4 + i)}", [f"v{T + 4 + i}", f"v{al}"], [f"v{T + 4 + i}"]))
+                    for i in range(4):
+                        L.append(I(f"v_accvgpr_write_b32 {a(O(n, db, r + i))}, {v(T + 4 + i)}", "valu", [f"v{T + 4 + i}"], []))
+        L.append(valu(f"v_add_f32_e32 {v(MREF + n)}, {v(MREF + n)}, {v(sh)}", [f"v{MREF + n}", f"v{sh}"], [f"v{MREF + n}"]))
+        for kb in range(2):
+            for r in range(16):
+                s = S(y, n, kb, r)
+                L.append(valu(f"v_sub_f32_e32 {v(s)}, {v(s)}, {v(sh)}", [f"v{s}", f"v{sh}"], [f"v{s}"]))
+        for r in range(16):
+            L.append(valu(f"v_sub_f32_e32 {v(MR(n) + r)}, {v(MR(n) + r)}, {v(sh)}", [f"v{MR(n) + r}", f"v{sh}"], [f"v{MR(n) + r}"]))
+    L.append(nop(4))
+    return L
+
+
+def vote(tag):
+    return [valu(f"v_max_f32_e32 {v(T)}, {v(MX)}, {v(MX + 1)}", [f"v{MX}", f"v{MX + 1}"], [f"v{T}"]),
+            I(f"v_cmp_nge_f32_e32 vcc, {THR}, {v(T)}", "valu", [f"v{T}"], []),        # !(8 >= max): above the threshold, or NaN
+            nop(2),
+            salu("s_and_b64 vcc, exec, vcc"),
+            I(f"s_cbranch_vccz L_calm_{tag}%=", "branch")]
+
+
+def body(x, y, tag):
+    """one tile: S(t+1) -> set y, softmax of set x (tile t), O += Vt(t) P(t), fragment reads for the next tile, LDS-DMA of t + 3."""
+    top = [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait"), I("s_barrier", "barrier")]
+    m_s = [mfma_s(y, n, kb, ks) for ks in range(4) for kb in range(2) for n in range(2)]
+    m_pv = [mfma_pv(n, db, j) for j in range(4) for db in range(2) for n in range(2)]
+    ex = stream_exp(x)
+    # deadlines: fragment j of both query blocks before MFMA 16 + 4 j; the pack's last result 3 states earlier
+    tim = []
+    per_j = len(ex) // 4
+    bounds = [(0.0, 13.5), (13.5, 19.3), (19.3, 23.3), (23.3, 27.3)]
+    for j in range(4):
+        tim += spread(ex[j * per_j:(j + 1) * per_j], *bounds[j])
+    tim += spread(stream_vreads(), 0.0, 8.0)
+    tim += spread(stream_dma(), 8.0, 13.0)
+    tim += spread(stream_addr(), 13.0, 15.9)
+    tim += spread(stream_kreads(), 16.0, 24.0)
+    tim += spread(stream_addr_k(), 24.5, 27.0)
+    tim += spread(stream_max(y), 17.6, 31.95)
+    seq = interleave(m_s + m_pv, tim)
+    # the first P.V MFMA needs the Vt fragments: they were requested in gaps 0-7
+    idx = next(i for i, ins in enumerate(seq) if ins is m_pv[0])
+    seq.insert(idx, I("s_waitcnt lgkmcnt(0)", "wait"))
+    return top + seq
+
+
+def tail(x, tag):
+    """last tile: no S(t+1); the softmax of set x has no MFMAs to hide under until the P.V phase."""
+    top = [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait")]
+    ex = stream_exp(x)
+    per_j = len(ex) // 4
+    m_pv = [mfma_pv(n, db, j) for j in range(4) for db in range(2) for n in range(2)]
+    pre = stream_vreads() + ex[:per_j] + [nop(3), I("s_waitcnt lgkmcnt(0)", "wait")]
+    tim = []
+    bounds = [(0.0, 2.9), (3.0, 6.9), (7.0, 10.9)]
+    for j in range(1, 4):
+        tim += spread(ex[j * per_j:(j + 1) * per_j], *bounds[j - 1])
+    return top + pre + interleave(m_pv, tim)
+
+
+def prologue():
+    L = [nop(5)]          # the descriptor words may come straight from v_readfirstlane
+    for ks in range(4):
+        L.append(valu(f"v_xor_b32_e32 {v(KBASE + ks)}, {ks << 5}, %[ko0]", [], [f"v{KBASE + ks}"]))
+    # Q fragments (rows past Lq read as zeros through the buffer resource)
+    for n in range(2):
+        for ks in range(4):
+            L.append(I(f"buffer_load_dwordx4 {a(QF(n, ks), 4)}, %[qoff{n}], %[rq], 0 offen offset:{ks * 32}", "vmem"))
+    # ring: tiles 0, 1, 2 (s54 counts the tile being issued)
+    L += [salu("s_mov_b32 s52, 0"), salu("s_mov_b32 s53, 0"), salu("s_mov_b32 s54, 0"), salu("s_mov_b32 s50, 0"),
+          salu("s_sub_u32 s51, %[nt], 1")]
+    for _ in range(3):
+        L += stream_dma()
+    for i in range(64):
+        L.append(I(f"v_accvgpr_write_b32 {a(O0 + i)}, 0", "valu"))
+    for i in range(32):
+        L.append(valu(f"v_mov_b32_e32 {v(MR0 + i)}, 0", [], [f"v{MR0 + i}"]))
+    for i in range(4):
+        L.append(valu(f"v_mov_b32_e32 {v(LSUM + i)}, 0", [], [f"v{LSUM + i}"]))
+    for n in range(2):
+        L.append(valu(f"v_mov_b32_e32 {v(MREF + n)}, 0", [], [f"v{MREF + n}"]))
+    # tile 0: K fragments straight after it has landed (Q: 8 loads, tile 0: 4 pieces; tiles 1, 2 may still fly)
+    for ks in range(4):
+        L.append(valu(f"v_mov_b32_e32 {v(AK + ks)}, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]))
+        L.append(valu(f"v_mov_b32_e32 {v(AV + ks)}, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AV + ks}"]))
+    L += [I("s_waitcnt vmcnt(8)", "wait"), I("s_barrier", "barrier")]
+    L += stream_kreads()
+    L += [I("s_waitcnt lgkmcnt(0)", "wait")]
+    L += [mfma_s("A", n, kb, ks) for ks in range(4) for kb in range(2) for n in range(2)]
+    # K fragments of tile 1 (stage 1)
+    for ks in range(4):
+        L.append(valu(f"v_add_u32_e32 {v(AK + ks)}, 0x4000, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]))
+    L += [I("s_waitcnt vmcnt(4)", "wait"), I("s_barrier", "barrier")]
+    L += stream_kreads()
+    for ks in range(4):
+        L.append(valu(f"v_add_u32_e32 {v(AK + ks)}, 0x8000, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]))
+    L += [nop(16)]
+    L += stream_max("A")
+    L += slow_path("A", True, "p")
+    return L
+
+
+def epilogue():
+    """O / l -> bf16 rows in the wave's LDS block (the C++ side stores them as whole 128-byte rows), log2-domain LSE."""
+    L = [nop(16), nop(16)]
+    for n in range(2):
+        l0, l1, t0, t1 = LSUM + n * 2, LSUM + n * 2 + 1, T + 0, T + 1
+        L += [valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(l1)}", [f"v{l0}", f"v{l1}"], [f"v{l0}"]),
+              valu(f"v_mov_b32_e32 {v(t0)}, {v(l0)}", [f"v{l0}"], [f"v{t0}"]), valu(f"v_mov_b32_e32 {v(t1)}, {v(l0)}", [f"v{l0}"], [f"v{t1}"]),
+              nop(2), valu(f"v_permlane32_swap_b32_e32 {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{t0}", f"v{t1}"]), nop(2),
+              valu(f"v_add_f32_e32 {v(l0)}, {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{l0}"]),
+              trans(f"v_rcp_f32_e32 {v(l1)}, {v(l0)}", [f"v{l0}"], [f"v{l1}"]),           # l1 = 1 / l_tot
+              trans(f"v_log_f32_e32 {v(l0)}, {v(l0)}", [f"v{l0}"], [f"v{l0}"]),
+              nop(2),
+              valu(f"v_add_f32_e32 {v(MREF + n)}, {v(MREF + n)}, {v(l0)}", [f"v{MREF + n}", f"v{l0}"], [f"v{MREF + n}"])]   # lse
+    # every wave's LDS-DMA has landed and every wave is done with the ring before the blocks are overwritten
+    L += [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait"), I("s_barrier", "barrier")]
+    for c in range(4):
+        L.append(valu(f"v_xor_b32_e32 {v(AK + c)}, {(2 * c) << 4}, %[escr]", [], [f"v{AK + c}"]))
+    flip = 0
+    for n in range(2):
+        inv = LSUM + n * 2 + 1
+        for db in range(2):
+            for gp in range(2):
+                tb = T + 4 * flip            # A0 A1 C0 C1
+                flip ^= 1
+                x = [AV + 0, AV + 1, AV + 2, AV + 3]     # scratch floats (aV is dead)
+                for k in range(2):
+                    for half, dst in ((0, tb + k), (1, tb + 2 + k)):
+                        r0 = (2 * gp + half) * 4 + 2 * k
+                        L.append(I(f"v_accvgpr_read_b32 {v(x[0])}, {a(O(n, db, r0))}", "valu", [], [f"v{x[0]}"]))
+                        L.append(I(f"v_accvgpr_read_b32 {v(x[1])}, {a(O(n, db, r0 + 1))}", "valu", [], [f"v{x[1]}"]))
+                        L.append(valu(f"v_mul_f32_e32 {v(x[0])}, {v(inv)}, {v(x[0])}", [f"v{x[0]}", f"v{inv}"], [f"v{x[0]}"]))
+                        L.append(valu(f"v_mul_f32_e32 {v(x[1])}, {v(inv)}, {v(x[1])}", [f"v{x[1]}", f"v{inv}"], [f"v{x[1]}"]))
+                        L.append(valu(f"v_cvt_pk_bf16_f32 {v(dst)}, {v(x[0])}, {v(x[1])}", [f"v{x[0]}", f"v{x[1]}"], [f"v{dst}"]))
+                L.append(nop(2))
+                for k in range(2):
+                    L.append(valu(f"v_permlane32_swap_b32_e32 {v(tb + k)}, {v(tb + 2 + k)}", [f"v{tb + k}", f"v{tb + 2 + k}"], [f"v{tb + k}", f"v{tb + 2 + k}"]))
+                L.append(nop(2))
+                c = db * 2 + gp
+                L.append(I(f"ds_write_b128 {v(AK + c)}, {v(tb, 4)} offset:{n * 4096}", "ds", regs("v", tb, 4) + [f"v{AK + c}"], []))
+    L += [I("s_waitcnt lgkmcnt(0)", "wait")]
+    L += [valu(f"v_mov_b32_e32 %[lse0], {v(MREF)}", [f"v{MREF}"], []), valu(f"v_mov_b32_e32 %[lse1], {v(MREF + 1)}", [f"v{MREF + 1}"], [])]
+    return L
+
+
+def program():
+    P = []
+    P += prologue()
+    P += [salu("s_cmp_eq_u32 s51, 0"), I("s_cbranch_scc1 L_tail_A%=", "branch")]
+    for x, y in (("A", "B"), ("B", "A")):
+        P.append(I(f"L_body_{x}%=:", "label"))
+        b = body(x, y, x)
+        other = body(y, x, y)
+        check(b + other + b, f"body {x}")      # wrap-around distances through the partner body
+        check_order(b, f"body {x}")
+        P += b
+        P += vote(x)
+        P += slow_path(y, False, x)
+        P.append(I(f"L_calm_{x}%=:", "label"))
+        P += [salu("s_add_u32 s50, s50, 1"), salu("s_cmp_eq_u32 s50, s51"), I(f"s_cbranch_scc1 L_tail_{y}%=", "branch")]
+        if x == "B":
+            P.append(I("s_branch L_body_A%=", "branch"))
+    for x in ("A", "B"):
+        P.append(I(f"L_tail_{x}%=:", "label"))
+        t = tail(x, x)
+        check(t, f"tail {x}")
+        check_order(t, f"tail {x}")
+        P += t
+        if x == "A":
+            P.append(I("s_branch L_epilogue%=", "branch"))
+    P.append(I("L_epilogue%=:", "label"))
+    P += epilogue()
+    return P
+
+
+def main():
+    P = program()
+    out = os.path.join(HERE, "attn_pwg_asm.inc")
+    n_ins = sum(1 for i in P if i.kind != "label")
+    with open(out, "w") as f:
+        f.write("// GENERATED by gen_attn_pwg.py -- do not edit; the instruction stream of attn_pwg_kernel's asm statement.\n")
+        f.write(f"// {n_ins} instructions.  Register map and schedule: see the generator's docstring.\n")
+        for ins in P:
+            f.write('"' + ins.text + '\\n"\n')
+    # clobber list
+    with open(os.path.join(HERE, "attn_pwg_clobbers.inc"), "w") as f:
+        f.write("// GENERATED by gen_attn_pwg.py: registers the asm statement of attn_pwg_kernel owns.\n")
+        names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 160)] + [f"s{i}" for i in range(50, 64)]
+        f.write(", ".join(f'"{n}"' for n in names) + "\n")
+    mf = sum(1 for i in P if i.kind == "mfma")
+    print(f"{out}: {n_ins} instructions, {mf} MFMAs")
+
+
+if __name__ == "__main__":
+    main()

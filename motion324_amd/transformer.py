@@ -133,7 +133,7 @@ class LNFold:
     def usable(P: Prepared, rows: int, C: int, bf16_stream: bool = False) -> bool:
         """bf16_stream: the stream itself is bf16 (level 1 of M324_FOLD_LN folds only those; level 2 every stream)."""
         return (FOLD_LN >= (1 if bf16_stream else 2) and not _FUSE_OFF and P.dtype == torch.bfloat16 and rows > 64
-                and C % 64 == 0 and not torch.is_grad_enabled())
+                and C % 64 == 0 and C >= 128 and not torch.is_grad_enabled())       # m324_gemm's fold paths need K >= 128 (two K-stages)
 
     def from_stream(self, x: torch.Tensor, eps: float) -> "LNFold":
         """Head of a chain: statistics (and the bf16 twin) straight from the fp32 stream."""

@@ -15,9 +15,9 @@ from conftest import CASES, GOLDEN, load_golden, rel_err, synth_sd
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-3
-# bf16 speed mode vs the fp32 reference goldens.  Measured on MI355X (round 1): pcd_moved 4.3-4.6e-3, every captured
-# stage <= 5.2e-3; a regression to 1 % must fail.
-BF16_TOL = 8e-3            # pcd_moved and the non-trunk stages
+# bf16 speed mode vs the fp32 reference goldens.  Measured on MI355X: pcd_moved 3.8e-3 (c2) - 4.8e-3 (tiny), every captured
+# non-trunk stage <= 5.2e-3; the gate sits 25 % above the measured band (round 3's 8e-3 would have let a 2x regression pass).
+BF16_TOL = 6e-3            # pcd_moved and the non-trunk stages
 BF16_STAGE_TOL = {"trunk_block0": 1e-2, "trunk_out": 1e-2}
 
 

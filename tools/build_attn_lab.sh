@@ -8,6 +8,6 @@ mkdir -p tools/lablibs
     -c ${ATTN_SRC:-motion324_amd/csrc/attention.hip} -o tools/lablibs/attn_$name.o
 b=motion324_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lablibs/libm324_$name.so tools/lablibs/attn_$name.o \
-    $b/runtime.o $b/gemm.o $b/gemm_ring4.o $b/elementwise.o $b/backward.o $b/comm.o -ldl
+    $b/runtime.o $b/gemm.o $b/gemm_ring4.o $b/attention_pwg.o $b/elementwise.o $b/backward.o $b/comm.o -ldl
 rm -f tools/lablibs/attn_$name.o
 echo tools/lablibs/libm324_$name.so

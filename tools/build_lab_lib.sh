@@ -11,6 +11,6 @@ mkdir -p tools/lablibs
     -c motion324_amd/csrc/gemm_ring4.hip -o tools/lablibs/gemm_ring4_$name.o
 b=motion324_amd/csrc/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/lablibs/libm324_$name.so tools/lablibs/gemm_$name.o \
-    $b/runtime.o tools/lablibs/gemm_ring4_$name.o $b/attention.o $b/elementwise.o $b/backward.o $b/comm.o -ldl
+    $b/runtime.o tools/lablibs/gemm_ring4_$name.o $b/attention.o $b/attention_pwg.o $b/elementwise.o $b/backward.o $b/comm.o -ldl
 rm -f tools/lablibs/gemm_$name.o tools/lablibs/gemm_ring4_$name.o
 echo tools/lablibs/libm324_$name.so

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Lab: the one-wave-per-SIMD attention forward (attention_pwg.hip, M324_ATTN_PWG=1) against the eight-wave kernel and against
+fp64 softmax attention: values, LSE, forced reference moves, ragged Lq, odd / even / tiny tile counts; then interleaved timing
+at the clip's global-attention shape.   usage: tools/pwg_check.py [--time] [--shapes small|all]"""
+import argparse, math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from motion324_amd import lib, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--time", action="store_true")
+ap.add_argument("--shapes", default="all")
+args = ap.parse_args()
+dev, dt = "cuda", torch.bfloat16
+
+
+def vt_layout(v):
+    B, H, Lk, D = v.shape
+    Lp = (Lk + 63) // 64 * 64
+    vt = torch.zeros((B, H, D, Lp), dtype=v.dtype, device=v.device)
+    vt[..., :Lk] = v.transpose(2, 3)
+    vt = vt.reshape(B, H, D, Lp // 16, 4, 4)[..., [0, 2, 1, 3], :]
+    return vt.reshape(B, H, D, Lp).contiguous()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def run(B, H, Lq, Lk, spike=True, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    q = torch.randn(B, H, Lq, 64, generator=g) * 1.5
+    k = torch.randn(B, H, Lk, 64, generator=g) * 1.5
+    v = torch.randn(B, H, Lk, 64, generator=g)
+    if spike:
+        k[0, 0, Lk - 70] = q[0, 0, 9] * 3.0                      # late dominant key: the reference moves near the end
+        k[0, H - 1, 130] = q[0, H - 1, min(300, Lq - 1)] * 3.0    # early one
+    qs = (q * ops.Q_PRESCALE).to(dt)
+    k, v = k.to(dt), v.to(dt)
+    dq, dk, dvt = qs.to(dev), k.to(dev), vt_layout(v.to(dev))
+    res = {}
+    for pwg in (1, 0):
+        lib.set_tunable("M324_ATTN_PWG", pwg)
+        out = torch.full((B * Lq, H * 64), float("nan"), dtype=dt, device=dev)
+        lse = torch.full((B, H, Lq), float("nan"), dtype=torch.float32, device=dev)
+        ops.attention(dq, dk, dvt, out, prescaled=True, lse=lse)
+        torch.cuda.synchronize()
+        res[pwg] = (out.float().cpu(), lse.cpu())
+    lib.set_tunable("M324_ATTN_PWG")
+    sc = torch.einsum("bhqd,bhkd->bhqk", qs.double(), k.double())
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc * math.log(2.0), dim=-1), v.double()).reshape(B * Lq, H * 64)
+    lse_ref = torch.logsumexp(sc * math.log(2.0), dim=-1) / math.log(2.0)
+    e1, e0 = rel(res[1][0], ref), rel(res[0][0], ref)
+    l1, l0 = float((res[1][1].double() - lse_ref).abs().max()), float((res[0][1].double() - lse_ref).abs().max())
+    fin = bool(torch.isfinite(res[1][0]).all())
+    row9 = rel(res[1][0][9], ref[9])
+    ok = fin and e1 < 8e-3 and l1 < 2e-2 and row9 < 1e-2
+    print(f"B={B} H={H} Lq={Lq} Lk={Lk} spike={spike}: pwg err {e1:.2e} (8-wave {e0:.2e})  lse {l1:.2e} ({l0:.2e})  row9 {row9:.2e}  finite {fin}  "
+          f"{'OK' if ok else 'FAIL'}", flush=True)
+    return ok
+
+
+shapes = [(1, 2, 2048, 512), (1, 2, 2100, 2048), (1, 2, 2304, 1088), (2, 3, 2049, 576), (1, 1, 4096, 4096)]
+if args.shapes == "all":
+    shapes += [(1, 12, 10368, 10368)]
+allok = True
+for s in shapes:
+    allok &= run(*s)
+    allok &= run(*s, spike=False, seed=1)
+print("ALL OK" if allok else "SOME FAILED", flush=True)
+
+if args.time:
+    B, H, L = 1, 12, 10368
+    q = (torch.randn(B, H, L, 64, device=dev) * 1.5 * ops.Q_PRESCALE).to(dt)
+    k = (torch.randn(B, H, L, 64, device=dev) * 1.5).to(dt)
+    vt = vt_layout(torch.randn(B, H, L, 64, device=dev).to(dt))
+    out = torch.empty((B * L, H * 64), dtype=dt, device=dev)
+
+    def t(pwg, iters=20):
+        lib.set_tunable("M324_ATTN_PWG", pwg)
+        for _ in range(3):
+            ops.attention(q, k, vt, out, prescaled=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.attention(q, k, vt, out, prescaled=True)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+
+    for rnd in range(4):
+        a, b = t(1), t(0)
+        fl = 4.0 * B * H * L * L * 64
+        print(f"round {rnd}: pwg {a:.1f} us = {fl / a / 1e6:.0f} TF/s   8-wave {b:.1f} us = {fl / b / 1e6:.0f} TF/s", flush=True)
+    lib.set_tunable("M324_ATTN_PWG")
