@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -175,6 +176,16 @@ class Dist:
         self.dev = torch.device("cuda", self.local)
         torch.cuda.set_device(self.dev)
         self.comm_ranks = 1
+        # M324_BENCH_COLLECT=1 on ONE rank: a 1-rank RCCL communicator with every collective forced (identities there): the
+        # N > 1 code path -- segmented graph chain, sharded video, side-stream exchanges -- rehearsed on a single-GPU box
+        self.force_collect = self.world == 1 and os.environ.get("M324_BENCH_COLLECT") == "1"
+        if self.force_collect:
+            import torch.distributed as dist
+            from motion324_amd import parallel
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            dist.init_process_group(self.backend, rank=0, world_size=1, **({"device_id": self.dev} if self.backend == "nccl" else {}))
+            parallel.ALWAYS_COLLECT = True
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -203,7 +214,7 @@ class Dist:
         return float(t.item())
 
     def close(self):
-        if self.world > 1:
+        if self.world > 1 or self.force_collect:
             torch.distributed.destroy_process_group()
 
 
@@ -374,8 +385,11 @@ def decoder_block_replay(model, sample, steps: int):
         ms = rounds[2]                                       # median of five rounds of >= 20 replays
     del keep
     flops = model.decoder_block_flops(1, T, N)
+    fexe = model.decoder_block_flops_executed(1, T, N)
     return {"ms_per_step": round(ms, 4), "algorithmic_gflop": round(flops / 1e9, 1), "tflops": round(flops / ms / 1e9, 1),
-            "frac_of_bf16_peak": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "rounds_ms": [round(r, 4) for r in rounds],
+            "frac_of_bf16_peak": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+            "executed_gflop": round(fexe / 1e9, 1), "frac_executed_flops": round(fexe / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+            "rounds_ms": [round(r, 4) for r in rounds],
             "timing": "hipGraph of the block alone (k|v projection with the q projection on a second branch as in the product's "
                       "graph, attention, out-projection, MLP), replayed back to back between two HIP events (median of five rounds); input = this "
                       "clip's trunk output"}
@@ -448,11 +462,12 @@ def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
         return {"h2d_ms": round(ms, 3), "mbytes": round(host.numel() * 4 / 1e6, 1), "gbytes_per_s": round(host.numel() * 4 / ms / 1e6, 1),
                 "note": "pinned host -> HBM copy of the clip's fp32 frames; never part of `value`"}
 
-    def train_c3():
-        """BASELINE configs[2]: dyscene.yaml shapes, batch_size_per_gpu = 8, forward + backward + fused AdamW"""
+    def train_c3(Bt=8, timed_steps=5):
+        """BASELINE configs[2]: dyscene.yaml shapes, batch_size_per_gpu = 8, forward + backward + fused AdamW
+        (Bt = 32: configs[3]'s per-GPU workload on this one GPU -- no gradient exchange, that is the 8-GPU run's part)"""
         from motion324_amd import training
         from motion324_amd.optim import FusedAdamW, backward_completion_order, cosine_with_warmup
-        T, N, HW, Bt = 12, 4096, 224, 8
+        T, N, HW = 12, 4096, 224
         tm, _ = build_model(dev, T, train=True)
         sn = synth.synth_inputs(Bt, T, N, N, HW, seed=1, with_target=True)
         smp = {k: torch.from_numpy(v).to(dev) for k, v in sn.items()}
@@ -471,10 +486,10 @@ def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(timed_steps):
             step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 5 * 1e3
+        ms = (time.perf_counter() - t0) / timed_steps * 1e3
         fwd = algorithmic_flops(Bt, T, N, N)
         # executed FLOPs of a step = forward + 2 x backward of the trainable part (its internals are kept, not recomputed:
         # motion324_amd/training.py, M324_TRAIN_STORE; with =0 a fourth, recompute pass runs) + the frozen DINO forward
@@ -487,9 +502,20 @@ def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
                "flop_model": ("DINO forward + 3 x trainable forward (forward with kept internals, 2 x backward)" if kept else
                               "DINO forward + 4 x trainable forward (forward, recompute, 2 x backward)"),
                "activations": "kept in HBM while they fit half of the free memory" if kept else "checkpoint per block + recompute",
-               "loss": round(float(losses[-1]), 6), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+               "loss": round(float(losses[-1]), 6), "finite": bool(all(math.isfinite(float(l)) for l in losses)),
+               "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+        kb = getattr(training, "LAST_STEP_BLOCKS", None)
+        if kb:
+            res["blocks_kept_vs_recomputed"] = kb
         del tm, opt, smp
         return res
+
+    def train_c4():
+        """BASELINE configs[3]'s per-GPU workload (dyscene.yaml, batch_size_per_gpu = 32) on ONE GPU, three timed steps"""
+        torch.cuda.reset_peak_memory_stats()
+        r = train_c3(32, 3)
+        r["note"] = "one GPU, no gradient exchange: the 8-GPU all-reduce of configs[3] is bench.py --mode train --gpus 8"
+        return r
 
     def clip256():
         """BASELINE configs[4] on ONE GPU: the 256-frame clip (82 944 trunk tokens) through the same forward"""
@@ -529,6 +555,7 @@ def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
     guarded("fp32_parity_mode_c2", fp32)
     guarded("h2d", h2d)
     guarded("train_c3", train_c3)
+    guarded("train_c4_per_gpu", train_c4)
     guarded("clip_256_frames_one_gpu", clip256)
     return out
 
@@ -635,6 +662,15 @@ def run_infer(args, D: Dist):
     if world == 1 and fast is not None:
         try:
             blk_replay = decoder_block_replay(model, sample, args.steps)
+            # the same block with the decoder's residual stream in fp32 (M324_BF16_DECODER=0): what the precision shortcut buys
+            import motion324_amd.Pcd_motion as pm_
+            if pm_.BF16_DECODER_STREAM:
+                pm_.BF16_DECODER_STREAM = False
+                try:
+                    r32 = decoder_block_replay(model, sample, args.steps)
+                    blk_replay["fp32_decoder_stream"] = {k: r32[k] for k in ("ms_per_step", "frac_of_bf16_peak", "frac_executed_flops")}
+                finally:
+                    pm_.BF16_DECODER_STREAM = True
         except Exception as e:                          # noqa: BLE001
             blk_replay = {"error": f"{type(e).__name__}: {e}"[:300]}
     # per-kernel HIP-event timing (roofline object): the same K steps again, launched eagerly on the same
@@ -782,18 +818,35 @@ def run_frame_parallel(args, D: Dist):
     world, rank, dev = D.world, D.rank, D.dev
     T = args.frames
     model, _ = build_model(dev, T)
-    s = synth.synth_inputs(1, T, 2048, args.surface, 512, seed=1)             # the SAME clip on every rank
+    from motion324_amd import parallel
+    import functools
+    collect = parallel.collectives_on(world)                                   # N > 1 (or M324_BENCH_COLLECT=1 on one rank: rehearsal)
+    if collect:
+        # every rank generates / uploads ONLY its frames of the same clip (805 MB of fp32 frames at T = 256: 7/8 of a full
+        # upload would be frames the rank never reads)
+        mine = parallel.partition(T, world, rank)
+        s = synth.synth_inputs(1, T, 2048, args.surface, 512, seed=1, frames=mine)
+        fp = functools.partial(model.forward_frame_parallel, local_frames=True, total_frames=T)
+    else:
+        s = synth.synth_inputs(1, T, 2048, args.surface, 512, seed=1)
+        fp = None
     sample = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
     m.set_precision(args.precision)
-    fast = m.GraphedForward(model) if (world == 1 and not args.eager) else None
+    if args.eager:
+        fast = None
+    elif collect:
+        # a chain of hipGraphs cut at the RCCL exchanges (graph.py _Segmenter): collectives cannot be captured on this stack
+        fast = m.GraphedForward(model, forward=fp, segmented=True)
+    else:
+        fast = m.GraphedForward(model)
     last = [None]
 
     def step():
         with torch.no_grad():
-            if world > 1:
-                last[0] = model.forward_frame_parallel(sample).pcd_moved
-            elif fast is not None:
+            if fast is not None:
                 last[0] = fast(sample).pcd_moved
+            elif collect:
+                last[0] = fp(sample).pcd_moved
             else:
                 last[0] = model(sample).pcd_moved
 
@@ -803,8 +856,8 @@ def run_frame_parallel(args, D: Dist):
     from motion324_amd.timing import Recorder
     rec = Recorder()
     with rec, torch.no_grad():                    # one eager forward with an event pair around every GEMM / attention launch
-        if world > 1:
-            model.forward_frame_parallel(sample)
+        if collect:
+            fp(sample)
         else:
             model(sample)
     D.fence()
@@ -818,7 +871,10 @@ def run_frame_parallel(args, D: Dist):
                 "config": {"workload": f"one {T}-frame clip x 2048 points x 512x512, {args.surface} surface samples, training.frames={T} "
                                        "(BASELINE configs[4]); frames sharded over the ranks, K/V all-gather per global block",
                            "parallelism": f"frame-parallel x{world}"},
-                "comm_ranks": D.comm_ranks, "launch": "hipGraph replay" if fast is not None else "eager",
+                "comm_ranks": D.comm_ranks,
+                "launch": ("eager" if fast is None else "hipGraph chain cut at the K/V exchanges (collectives eager between the graphs)" if collect
+                           else "hipGraph replay"),
+                "video": "each rank holds only its frames" if collect else "whole clip",
                 "end_to_end_tflops": round(flops * args.steps / dt / 1e12, 1),
                 "end_to_end_frac_of_bf16_peak": round(flops * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS / world, 4),
                 "finite": bool(torch.isfinite(last[0]).all()), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

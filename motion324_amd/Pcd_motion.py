@@ -17,7 +17,7 @@ from __future__ import annotations
 import contextlib
 import os
 
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
@@ -108,11 +108,20 @@ class _KVGather:
         self.even = B == 1 and all(f == self.frames[0] for f in self.frames)
         self.comm = torch.cuda.Stream(device=dev)
         self.buf = None
+        self.full = None                         # uneven shards under segmented capture: the compacted rows at a fixed address
         self._pending = None
+        self._deferred = None
         self.launch_log = []                     # ids of the streams the collectives were enqueued on (tests)
 
     def start(self, kv_local: torch.Tensor) -> None:
         """kv_local: contiguous [B * T_local * Lt, 2C]."""
+        from . import graph
+        if graph.active_segmenter() is not None:       # segmented hipGraph capture: the exchange runs BETWEEN two graphs, in finish()
+            self._deferred = kv_local
+            return
+        self._start(kv_local)
+
+    def _start(self, kv_local: torch.Tensor) -> None:
         rows, width = kv_local.shape
         main = torch.cuda.current_stream(self.dev)
         self.comm.wait_stream(main)              # the projection has been enqueued; earlier readers of `buf` too
@@ -133,6 +142,33 @@ class _KVGather:
 
     def finish(self):
         """-> ([B * T_full * Lt, 2C] in clip order, T_full * Lt)."""
+        from . import graph
+        seg = graph.active_segmenter()
+        if seg is not None:
+            # The captured graph that follows reads the gathered rows at a FIXED address: the even path's reused buffer, or
+            # (uneven shards) a buffer this object keeps.  The exchange itself is replayed eagerly between the two graphs.
+            kv_local = self._deferred
+            self._deferred = None
+            rows, width = kv_local.shape
+            if self.even:
+                if self.buf is None or self.buf.dtype != kv_local.dtype or self.buf.shape[1] != width:
+                    self.buf = torch.empty((self.world * rows, width), dtype=kv_local.dtype, device=self.dev)
+                full = self.buf
+            else:
+                if self.full is None or self.full.dtype != kv_local.dtype or self.full.shape[1] != width:
+                    self.full = torch.empty((self.B * self.T_full * self.Lt, width), dtype=kv_local.dtype, device=self.dev)
+                full = self.full
+
+            def exchange():
+                self._start(kv_local)
+                got, _ = self._finish()
+                if got.data_ptr() != full.data_ptr():
+                    full.copy_(got)
+            seg.cut(exchange)
+            return full, self.T_full * self.Lt
+        return self._finish()
+
+    def _finish(self):
         work, parts, kv_local = self._pending
         self._pending = None
         with torch.cuda.stream(self.comm):
@@ -277,6 +313,13 @@ class Motion_Latent_Model(nn.Module):
         lin = lambda mm, i, o: 2.0 * mm * i * o
         return B * T * (2 * lin(N, C, C) + 2 * lin(K, C, C) + 2 * lin(N, C, 4 * C) + 4.0 * (C // 64) * N * K * 64)
 
+    def decoder_block_flops_executed(self, B: int, T: int, N: int) -> float:
+        """FLOPs the block actually issues: the q projection of the mesh points runs once per sample, not once per frame
+        (Pcd_motion.py:550-553 recomputes it inside the frame loop; same values).  SURVEY 8(d): hoisting is a speed-up, not
+        utilisation -- bench.py reports the matrix-pipe rate on THIS count next to the north-star figure on the reference count."""
+        C = self.embed_dim
+        return self.decoder_block_flops(B, T, N) - B * (T - 1) * 2.0 * N * C * C
+
     def _video_pos(self, P: Prepared, T: int) -> torch.Tensor:
         g = self.latent_size
         if T == self.latent_length:
@@ -383,16 +426,23 @@ class Motion_Latent_Model(nn.Module):
         lm.xyz_loss = loss.detach() / max(float(self.loss_computer._weight), 1e-30)
         return edict(input_data=sample, pcd_moved=out, loss_metrics=lm)
 
-    def forward_frame_parallel(self, sample: Dict[str, torch.Tensor], group=None):
+    def forward_frame_parallel(self, sample: Dict[str, torch.Tensor], group=None, *, local_frames: bool = False,
+                               total_frames: Optional[int] = None):
         """One long clip, frames sharded over the ranks of `group` with EXACT single-GPU semantics
         (BASELINE config 5; SURVEY.md 8(e) third row).  Every rank passes the same sample (full `rgb_video`
         [B,T,H,W,3]); rank r encodes / decodes frames partition(T, world, r) only.  Per-frame stages (DINO, local
         blocks, decoder) need no communication; each GLOBAL block all-gathers its token-major k|v projection
         (RCCL over xGMI; 2 x T*324*768 bf16 = 255 MB assembled per block at T = 256) so local queries attend to the
-        whole clip; `pcd_moved` is all-gathered at the end and returned complete on every rank."""
+        whole clip; `pcd_moved` is all-gathered at the end and returned complete on every rank.
+
+        local_frames=True: `rgb_video` holds ONLY this rank's frames, [B, len(partition(total_frames, world, rank)), H, W, 3]
+        (a loader that decodes its shard: at T = 256 the full fp32 clip is 805 MB of host-to-device traffic per rank, 7/8 of
+        it for frames the rank never touches); total_frames = the clip's length."""
         from . import parallel
         rank, world = parallel.world_info(group)
-        return self._forward(sample, (rank, world, group))
+        if local_frames and (total_frames is None or total_frames < 1):
+            raise M324Error("forward_frame_parallel(local_frames=True) needs total_frames")
+        return self._forward(sample, (rank, world, group, int(total_frames) if local_frames else None))
 
     def _forward(self, sample: Dict[str, torch.Tensor], shard):
         ref_pcd = sample["ref_pcd"]
@@ -441,12 +491,17 @@ class Motion_Latent_Model(nn.Module):
         t0, kv_gather = 0, None
         if shard is not None:
             from . import parallel
-            rank, world, group = shard
+            rank, world, group, t_local_of = shard
+            if t_local_of is not None:
+                T_full = t_local_of
             mine = parallel.partition(T_full, world, rank)
             if len(mine) == 0:
                 raise M324Error(f"frame-parallel forward: {T_full} frames cannot feed {world} ranks")
             t0 = mine.start
-            video = video[:, mine.start:mine.stop]
+            if t_local_of is None:
+                video = video[:, mine.start:mine.stop]
+            elif video.shape[1] != len(mine):
+                raise M324Error(f"frame-parallel forward: rank {rank} of {world} owns {len(mine)} of {T_full} frames, rgb_video has {video.shape[1]}")
         video = self._f32c(video)
         _, T, Hin, Win, _ = video.shape
         dino_x = self.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))
@@ -475,7 +530,7 @@ class Motion_Latent_Model(nn.Module):
 
         # D. alternating global / local trunk (reference :394-409)
         if shard is not None and parallel.collectives_on(shard[1]):
-            rank, world, group = shard
+            rank, world, group = shard[:3]
             kv_gather = _KVGather(B, T, Lt, parallel.counts(T_full, world), group, dev)
 
         # LayerNorm fold (transformer.LNFold): the statistics of the stream travel from GEMM epilogue to GEMM epilogue
@@ -541,12 +596,17 @@ class Motion_Latent_Model(nn.Module):
             cap["decoder_out_t0"] = torch.stack(cap["decoder_out_t0"], dim=0)
 
         if shard is not None and parallel.collectives_on(shard[1]):
-            rank, world, group = shard
+            rank, world, group = shard[:3]
             frames = parallel.counts(T_full, world)
             buf = torch.zeros((max(frames), B, N, 3), dtype=torch.float32, device=dev)
             buf[:T] = out.transpose(0, 1)
             parts = torch.empty((world,) + tuple(buf.shape), dtype=torch.float32, device=dev)
-            parallel.all_gather_into(parts, buf, group=group)
+            from . import graph
+            seg = graph.active_segmenter()
+            if seg is not None:                     # segmented capture: the exchange is replayed between two graphs
+                seg.cut(lambda: parallel.all_gather_into(parts, buf, group=group))
+            else:
+                parallel.all_gather_into(parts, buf, group=group)
             if all(f == frames[0] for f in frames):
                 out = parts.reshape(T_full, B, N, 3).transpose(0, 1).contiguous()
             else:

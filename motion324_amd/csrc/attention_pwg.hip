@@ -29,71 +29,61 @@ __device__ __forceinline__ i32x4 rsrc_words(const void* base, long bytes) {
     return r;
 }
 
-__global__ __launch_bounds__(256, 1) void attn_pwg_kernel(const bf16_t* __restrict__ Q, long q_bstride, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, long ldo, int H, int Lq,
-                                                          int Lk, int Lkp, float* __restrict__ lse, int nqt) {
-    // four ring stages [K tile 8 KiB | Vt tile 8 KiB]; the only LDS object of the kernel (the asm statement addresses it by value)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * 16384];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    // XCD-aware flat grid as in attention.hip: every XCD walks whole heads
-    int qt, h, b;
-    {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7, loc = blockIdx.x >> 3;
-        const int lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-        qt = lid % nqt;
-        h = (lid / nqt) % H;
-        b = lid / (nqt * H);
-    }
-    const int q0 = (qt * 4 + wave) * 64;
-    const bf16_t* Qh = Q + (long)b * q_bstride + (long)h * Lq * 64;
-    const bf16_t* Kh = K + ((long)b * H + h) * (long)Lk * 64;
-    const bf16_t* Vh = Vt + ((long)b * H + h) * 64 * (long)Lkp;
+#define PWG_KERNEL attn_pwg_kernel
+#define PWG_ASM_INC "attn_pwg_asm.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
 
-    const i32x4 rq = rsrc_words(Qh, (long)Lq * 128), rk = rsrc_words(Kh, (long)Lk * 128), rv = rsrc_words(Vh, 64l * Lkp * 2);
-    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem;
-    // fragment address of (row l31 of a 32-row block, 16-byte chunk hi) in a [64][128 B] tile whose chunks are XOR-swizzled by the row
-    const unsigned ko0 = lds0 + (unsigned)(l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4));
-    // LDS-DMA: a wave-instruction fills 8 tile rows; wave w fills row groups 2w, 2w + 1 of the K tile and of the Vt tile
-    unsigned vk[2], vv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int srow = (wave * 2 + i) * 8 + (lane >> 3);
-        const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * 8;
-        vk[i] = (unsigned)((srow * 64 + scol) * 2);
-        vv[i] = (unsigned)(((long)srow * Lkp + scol) * 2);
-    }
-    const unsigned wlds = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 2048u);
-    const unsigned qoff0 = (unsigned)(((q0 + l31) * 64 + hi * 8) * 2), qoff1 = qoff0 + 32 * 128;
-    // output rows bounce through the wave's 8-KiB block of the ring (two 32-row blocks), XOR-swizzled by the row
-    const unsigned escr = lds0 + (unsigned)(wave * 8192 + l31 * 128 + ((hi ^ (l31 & 7)) << 4));
-    const int nt = __builtin_amdgcn_readfirstlane(Lk >> 6);
-    float lse0, lse1;
-    asm volatile(
-#include "attn_pwg_asm.inc"
-        : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)
-        : [rq] "s"(rq), [rk] "s"(rk), [rv] "s"(rv), [nt] "s"(nt), [wlds] "s"(wlds), [ko0] "v"(ko0), [vk0] "v"(vk[0]), [vk1] "v"(vk[1]),
-          [vv0] "v"(vv[0]), [vv1] "v"(vv[1]), [qoff0] "v"(qoff0), [qoff1] "v"(qoff1), [escr] "v"(escr)
-        : "memory", "vcc", "scc",
-#include "attn_pwg_clobbers.inc"
-    );
-    // whole 128-byte rows out of the wave's block: 8 rows per store instruction
-    const int r8 = lane >> 3, c8 = lane & 7;
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const unsigned char* scr = smem + wave * 8192 + n * 4096;
-        bf16_t* obase = O + ((long)b * Lq + q0 + n * 32) * ldo + h * 64 + c8 * 8;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int r = p * 8 + r8;
-            const uint4 v = *reinterpret_cast<const uint4*>(scr + r * 128 + ((c8 ^ (r & 7)) << 4));
-            if (q0 + n * 32 + r < Lq) *reinterpret_cast<uint4*>(obase + (long)r * ldo) = v;
-        }
-        const int q = q0 + n * 32 + l31;
-        if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = n ? lse1 : lse0;     // log2-domain LSE
-    }
-}
+#ifdef M324_PWG_LAB      // tools/build_attn_lab.sh: timing-only ablations of the stream (gen_attn_pwg.py --lab), M324_ATTN_PWG = 11 .. 17
+#define PWG_KERNEL attn_pwg_lab1_kernel
+#define PWG_ASM_INC "attn_pwg_lab1.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#define PWG_KERNEL attn_pwg_lab2_kernel
+#define PWG_ASM_INC "attn_pwg_lab2.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#define PWG_KERNEL attn_pwg_lab3_kernel
+#define PWG_ASM_INC "attn_pwg_lab3.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#define PWG_KERNEL attn_pwg_lab4_kernel
+#define PWG_ASM_INC "attn_pwg_lab4.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#define PWG_KERNEL attn_pwg_lab5_kernel
+#define PWG_ASM_INC "attn_pwg_lab5.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#define PWG_KERNEL attn_pwg_lab6_kernel
+#define PWG_ASM_INC "attn_pwg_lab6.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#define PWG_KERNEL attn_pwg_lab7_kernel
+#define PWG_ASM_INC "attn_pwg_lab7.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#define PWG_TRACE
+#define PWG_KERNEL attn_pwg_lab8_kernel
+#define PWG_ASM_INC "attn_pwg_lab8.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#undef PWG_TRACE
+#define PWG_KERNEL attn_pwg_lab9_kernel
+#define PWG_ASM_INC "attn_pwg_lab9.inc"
+#include "attn_pwg_kernel.inl"
+#undef PWG_KERNEL
+#undef PWG_ASM_INC
+#endif
 
 }  // namespace
 
@@ -102,6 +92,23 @@ void m324_attn_pwg_launch(const void* Q, long q_bstride, const void* K, const vo
                           float* lse, hipStream_t s) {
     const int Lkp = (Lk + 63) / 64 * 64;
     const int nqt = ceil_div(Lq, 256);
-    hipLaunchKernelGGL(attn_pwg_kernel, dim3((unsigned)((long)nqt * H * B)), dim3(256), 0, s, (const bf16_t*)Q, q_bstride,
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, lse, nqt);
+#define PWG_LAUNCH(KERNEL)                                                                                                  \
+    hipLaunchKernelGGL(KERNEL, dim3((unsigned)((long)nqt * H * B)), dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K, \
+                       (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, lse, nqt)
+#ifdef M324_PWG_LAB
+    switch (m324::tunable(m324::TUN_ATTN_PWG)) {
+        case 11: PWG_LAUNCH(attn_pwg_lab1_kernel); return;
+        case 12: PWG_LAUNCH(attn_pwg_lab2_kernel); return;
+        case 13: PWG_LAUNCH(attn_pwg_lab3_kernel); return;
+        case 14: PWG_LAUNCH(attn_pwg_lab4_kernel); return;
+        case 15: PWG_LAUNCH(attn_pwg_lab5_kernel); return;
+        case 16: PWG_LAUNCH(attn_pwg_lab6_kernel); return;
+        case 17: PWG_LAUNCH(attn_pwg_lab7_kernel); return;
+        case 18: PWG_LAUNCH(attn_pwg_lab8_kernel); return;
+        case 19: PWG_LAUNCH(attn_pwg_lab9_kernel); return;
+        default: break;
+    }
+#endif
+    PWG_LAUNCH(attn_pwg_kernel);
+#undef PWG_LAUNCH
 }

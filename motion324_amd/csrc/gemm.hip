@@ -1023,11 +1023,9 @@ static int pick_variant(const m324_gemm_args* a) {
     // tile's 12 K-stages are pure latency -- the ring's 2.5 stages of look-ahead: 11.4 -> 9.2 us, 10.5 -> 8.3 us)
     const bool heads = a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT;   // cross-attention q / k|v
     if (ring_ok && (!a->aux_mode || heads) && (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) <= 512) return 13;
-#ifdef M324_HEADS_V13_ALL   // lab builds (tools/build_lab_lib.sh h13 -DM324_HEADS_V13_ALL): re-measured in round 3 -- alone v13 runs the
-    // trunk's fused q|k|v GEMM in 46.3 us against v2's 51.9 (DINO: 39.0 / 42.8), in the clip it is 9.77 ms against 9.63 (three
-    // interleaved rounds): what follows it (the attention reading Q / K / V) pays more than the GEMM saves.  v2 stays.
-    if (ring_ok && heads) return 13;
-#endif
+    // M324_QKV_RING=1 (A/B): v13 for every fused q|k|v epilogue.  Round 3: alone v13 runs the trunk's fused q|k|v GEMM in 46.3 us
+    // against v2's 51.9 (DINO: 39.0 / 42.8), in the clip it was 9.77 ms against 9.63 (three interleaved rounds).
+    if (ring_ok && heads && m324::tunable(m324::TUN_QKV_RING) != 0) return 13;
     return 2;
 }
 

@@ -38,7 +38,7 @@ def a(i, n=1):
 KBASE, AK, AV, LSUM, MX, MREF, T, FLOOR = 32, 36, 40, 44, 48, 50, 52, 60
 S_SET = {"A": 64, "B": 128}
 PF0, MR0 = 192, 224
-O0, QF0, KF0, VF0 = 0, 64, 96, 128
+O0, QF0, KF0, VF0, L0, ONES = 0, 64, 96, 128, 160, 192
 THR = "8.0"
 
 
@@ -73,6 +73,11 @@ def VF(db, j):
     return VF0 + db * 16 + j * 4
 
 
+def LS(n, r=None):
+    b = L0 + n * 16
+    return b if r is None else b + r
+
+
 # ------------------------------------------------------------------------------------------------ instruction records
 class I:
     """One emitted line.  kind: mfma | valu | trans | ds | vmem | salu | wait | nop | label | branch | barrier.
@@ -99,6 +104,25 @@ def mfma_pv(n, db, j):
              rd=regs("a", VF(db, j), 4) + regs("v", PF(n, j), 4) + regs("a", d, 16), wr=regs("a", d, 16))
 
 
+def mfma_l(n, j):
+    """OPT lsum_mfma (measured, not used): row sums on the matrix pipe: L[n] += ones . P^T fragment j -- every row of the 32 x 32
+    result is the sum over the k-step's 16 keys of the bf16 P the P.V MFMAs consume.  The stream is VALU-issue-bound (stamps:
+    ~4.2 cycles per issued instruction, the matrix pipe 55 % busy), and 8 MFMAs per tile in place of 64 v_add_f32 do shorten the
+    tile from 1848 to 1738 cycles -- but the chip is power-limited: the clock fell from 1.89 to 1.71 GHz and the kernel got
+    slower against the eight-wave kernel of the same run (-1.6 % instead of -5 %).  Wasted MFMAs cost what useful ones cost."""
+    d = LS(n)
+    return I(f"v_mfma_f32_32x32x16_bf16 {a(d, 16)}, {a(ONES, 4)}, {v(PF(n, j), 4)}, {a(d, 16)}", "mfma",
+             rd=regs("a", ONES, 4) + regs("v", PF(n, j), 4) + regs("a", d, 16), wr=regs("a", d, 16))
+
+
+def pv_block():
+    """the P.V phase's MFMAs: per k-step j the four O updates and the two row-sum updates"""
+    out = []
+    for j in range(4):
+        out += [mfma_pv(n, db, j) for db in range(2) for n in range(2)] + ([mfma_l(n, j) for n in range(2)] if OPT["lsum_mfma"] else [])
+    return out
+
+
 def valu(text, rd=(), wr=()):
     return I(text, "valu", rd, wr)
 
@@ -120,41 +144,56 @@ def ds_read(dst_a, addr_v, off):
 
 
 # ------------------------------------------------------------------------------------------------ filler streams
+OPT = {"lsum_mfma": False, "trace": False, "noexp": False, "nomax": False, "nobarrier": False, "nodma": False, "nofill": False, "lookahead": 1}
+
+
 def stream_exp(x):
-    """exp2 / row sums / bf16 pack of S set x, in the order the P.V MFMAs consume the fragments: j = kb * 2 + (r >> 3)."""
-    out = []
+    """exp2 / row sums / bf16 pack of S set x, in the order the P.V MFMAs consume the fragments: j = kb * 2 + (r >> 3).
+    The two v_exp_f32 of pair p + LOOKAHEAD are issued before the adds / pack of pair p: a transcendental's result is not
+    available to the next instructions (in-order issue would wait on it every pair)."""
+    pairs = []
     for j in range(4):
         kb, half = j >> 1, j & 1
         for n in range(2):
             for p in range(4):
                 r = half * 8 + 2 * p
                 s0, s1 = S(x, n, kb, r), S(x, n, kb, r + 1)
+                op = "v_mov_b32_e32" if OPT["noexp"] else "v_exp_f32_e32"
+                kind = valu if OPT["noexp"] else trans
+                head = [kind(f"{op} {v(s0)}, {v(s0)}", [f"v{s0}"], [f"v{s0}"]), kind(f"{op} {v(s1)}, {v(s1)}", [f"v{s1}"], [f"v{s1}"])]
                 l0, l1 = LSUM + n * 2, LSUM + n * 2 + 1
-                grp = [
-                    trans(f"v_exp_f32_e32 {v(s0)}, {v(s0)}", [f"v{s0}"], [f"v{s0}"]),
-                    trans(f"v_exp_f32_e32 {v(s1)}, {v(s1)}", [f"v{s1}"], [f"v{s1}"]),
+                tail_ = [] if OPT["lsum_mfma"] else [
                     valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(s0)}", [f"v{l0}", f"v{s0}"], [f"v{l0}"]),
-                    valu(f"v_add_f32_e32 {v(l1)}, {v(l1)}, {v(s1)}", [f"v{l1}", f"v{s1}"], [f"v{l1}"]),
-                    valu(f"v_cvt_pk_bf16_f32 {v(PF(n, j, p))}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{PF(n, j, p)}"]),
-                ]
-                for g in grp:
-                    g.note = f"j{j}"
-                out += grp
+                    valu(f"v_add_f32_e32 {v(l1)}, {v(l1)}, {v(s1)}", [f"v{l1}", f"v{s1}"], [f"v{l1}"])]
+                tail_.append(valu(f"v_cvt_pk_bf16_f32 {v(PF(n, j, p))}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{PF(n, j, p)}"]))
+                pairs.append((head, tail_))
+    la = OPT["lookahead"]
+    out = []
+    for i in range(len(pairs) + la):
+        if i < len(pairs):
+            out += pairs[i][0]
+        if i - la >= 0:
+            out += pairs[i - la][1]
     return out
 
 
 def stream_max(y):
-    """per-lane maximum of the lane's 32 scores of each query block of S set y: two interleaved v_max3 chains."""
+    """per-lane maximum of the lane's 32 scores of each query block of S set y: four interleaved v_max3 chains (two per
+    block, one per key half), joined at the end -- a chain's next link is four instructions away."""
+    if OPT["nomax"]:
+        return [valu(f"v_mov_b32_e32 {v(MX + n)}, 0", [], [f"v{MX + n}"]) for n in range(2)]
     out = []
-    for i in range(16):
+    for i in range(8):
         for n in range(2):
-            kb, r = i >> 3, (i & 7) * 2
-            s0, s1 = S(y, n, kb, r), S(y, n, kb, r + 1)
-            m = MX + n
-            if i == 0:
-                out.append(valu(f"v_max_f32_e32 {v(m)}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{m}"]))
-            else:
-                out.append(valu(f"v_max3_f32 {v(m)}, {v(m)}, {v(s0)}, {v(s1)}", [f"v{m}", f"v{s0}", f"v{s1}"], [f"v{m}"]))
+            for kb in range(2):
+                s0, s1 = S(y, n, kb, 2 * i), S(y, n, kb, 2 * i + 1)
+                m = (MX + n) if kb == 0 else (T + 6 + n)
+                if i == 0:
+                    out.append(valu(f"v_max_f32_e32 {v(m)}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{m}"]))
+                else:
+                    out.append(valu(f"v_max3_f32 {v(m)}, {v(m)}, {v(s0)}, {v(s1)}", [f"v{m}", f"v{s0}", f"v{s1}"], [f"v{m}"]))
+    for n in range(2):
+        out.append(valu(f"v_max_f32_e32 {v(MX + n)}, {v(MX + n)}, {v(T + 6 + n)}", [f"v{MX + n}", f"v{T + 6 + n}"], [f"v{MX + n}"]))
     return out
 
 
@@ -166,9 +205,11 @@ def stream_kreads():
     return [ds_read(KF(kb, ks), AK + ks, kb * 4096) for ks in range(4) for kb in range(2)]
 
 
-def stream_dma():
+def stream_dma(force=False):
     """LDS-DMA of tile s54 (= t + 3) into ring stage s54 & 3: two K pieces, two Vt pieces per wave.  Unconditional: tiles past
     the end read out of range (zeros, no memory traffic) into a stage nobody reads."""
+    if OPT["nodma"] and not force:
+        return []
     out = [
         salu("s_and_b32 s55, s54, 3"),
         salu("s_lshl_b32 s55, s55, 14"),
@@ -177,7 +218,7 @@ def stream_dma():
     pieces = [("%[vk0]", "%[rk]", "s52", 0), ("%[vk1]", "%[rk]", "s52", 1024), ("%[vv0]", "%[rv]", "s53", 8192), ("%[vv1]", "%[rv]", "s53", 9216)]
     for voff, rs, soff, lo in pieces:
         out.append(salu(f"s_add_u32 m0, s55, {lo}"))
-        out.append(nop(1))
+        out.append(nop(1))                    # M0 write -> LDS-DMA: one wait state
         out.append(I(f"buffer_load_dwordx4 {voff}, {rs}, {soff} offen lds", "vmem"))
     out += [salu("s_add_u32 s52, s52, 0x2000"), salu("s_add_u32 s53, s53, 0x80"), salu("s_add_u32 s54, s54, 1")]
     return out
@@ -287,17 +328,18 @@ def slow_path(y, first, tag):
             L.append(valu(f"v_max_f32_e32 {v(sh)}, 0, {v(m)}", [f"v{m}"], [f"v{sh}"]))              # m_ref never decreases
             L.append(trans(f"v_exp_f32_e64 {v(al)}, -{v(sh)}", [f"v{sh}"], [f"v{al}"]))
             L.append(nop(2))
-            for i in range(2):
-                l = LSUM + n * 2 + i
-                L.append(valu(f"v_mul_f32_e32 {v(l)}, {v(al)}, {v(l)}", [f"v{l}", f"v{al}"], [f"v{l}"]))
-            for db in range(2):
+            if not OPT["lsum_mfma"]:
+                for i in range(2):
+                    l = LSUM + n * 2 + i
+                    L.append(valu(f"v_mul_f32_e32 {v(l)}, {v(al)}, {v(l)}", [f"v{l}", f"v{al}"], [f"v{l}"]))
+            for base in (O(n, 0), O(n, 1)) + ((LS(n),) if OPT["lsum_mfma"] else ()):          # O (and the MFMA row sums) of this query block
                 for r in range(0, 16, 4):
                     for i in range(4):
-                        L.append(I(f"v_accvgpr_read_b32 {v(T + 4 + i)}, {a(O(n, db, r + i))}", "valu", [], [f"v{T + 4 + i}"]))
+                        L.append(I(f"v_accvgpr_read_b32 {v(T + 4 + i)}, {a(base + r + i)}", "valu", [], [f"v{T + 4 + i}"]))
                     for i in range(4):
                         L.append(valu(f"v_mul_f32_e32 {v(T + 4 + i)}, {v(al)}, {v(T + 4 + i)}", [f"v{T + 4 + i}", f"v{al}"], [f"v{T + 4 + i}"]))
                     for i in range(4):
-                        L.append(I(f"v_accvgpr_write_b32 {a(O(n, db, r + i))}, {v(T + 4 + i)}", "valu", [f"v{T + 4 + i}"], []))
+                        L.append(I(f"v_accvgpr_write_b32 {a(base + r + i)}, {v(T + 4 + i)}", "valu", [f"v{T + 4 + i}"], []))
         L.append(valu(f"v_add_f32_e32 {v(MREF + n)}, {v(MREF + n)}, {v(sh)}", [f"v{MREF + n}", f"v{sh}"], [f"v{MREF + n}"]))
         for kb in range(2):
             for r in range(16):
@@ -314,45 +356,74 @@ def vote(tag):
             I(f"v_cmp_nge_f32_e32 vcc, {THR}, {v(T)}", "valu", [f"v{T}"], []),        # !(8 >= max): above the threshold, or NaN
             nop(2),
             salu("s_and_b64 vcc, exec, vcc"),
-            I(f"s_cbranch_vccz L_calm_{tag}%=", "branch")]
+            I(f"s_cbranch_vccnz L_move_{tag}%=", "branch")]
+
+
+def stamp(k):
+    """lab builds (--lab, variant 8): s_memtime into s[64 + 2k : 65 + 2k]; the waits that follow in the stream retire it"""
+    return [I(f"s_memtime s[{64 + 2 * k}:{65 + 2 * k}]", "salu")] if OPT["trace"] else []
+
+
+def stamp_sums():
+    """after the top wait of the next tile: add the phase lengths of the tile just finished to s80-84 (low words)"""
+    if not OPT["trace"]:
+        return []
+    out = []
+    for k in range(4):       # phases k -> k + 1 of the previous tile: stamps 1..4 live in s66..s73, its stamp 0 was saved in s74
+        prev = "s74" if k == 0 else f"s{64 + 2 * k}"
+        out += [salu(f"s_sub_u32 s59, s{66 + 2 * k}, {prev}"), salu(f"s_add_u32 s{80 + k}, s{80 + k}, s59")]
+    return out
+
+
+def split_after_fragment(ex, j):
+    """index just behind the instruction that completes P^T fragment j of both query blocks"""
+    last = max(i for i, ins in enumerate(ex) if any(f"v{PF(n, j, p)}" in ins.wr for n in range(2) for p in range(4)))
+    return last + 1
 
 
 def body(x, y, tag):
     """one tile: S(t+1) -> set y, softmax of set x (tile t), O += Vt(t) P(t), fragment reads for the next tile, LDS-DMA of t + 3."""
-    top = [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait"), I("s_barrier", "barrier")]
+    # lab stamps: 0 top, 1 LDS-DMA / fragment reads retired, 2 barrier passed, 3 first P.V MFMA, 4 end of the stream; s74:75 =
+    # the previous tile's stamp 0, so that s84 accumulates whole tile periods
+    top = stamp(0) + [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait")]
+    if OPT["trace"]:
+        top += stamp_sums() + [salu("s_sub_u32 s59, s64, s74"), salu("s_add_u32 s84, s84, s59"), salu("s_mov_b32 s74, s64")]
+    top += stamp(1)
+    if not OPT["nobarrier"]:
+        top.append(I("s_barrier", "barrier"))
+    top += stamp(2)
     m_s = [mfma_s(y, n, kb, ks) for ks in range(4) for kb in range(2) for n in range(2)]
-    m_pv = [mfma_pv(n, db, j) for j in range(4) for db in range(2) for n in range(2)]
-    ex = stream_exp(x)
-    # deadlines: fragment j of both query blocks before MFMA 16 + 4 j; the pack's last result 3 states earlier
-    tim = []
-    per_j = len(ex) // 4
-    bounds = [(0.0, 13.5), (13.5, 19.3), (19.3, 23.3), (23.3, 27.3)]
-    for j in range(4):
-        tim += spread(ex[j * per_j:(j + 1) * per_j], *bounds[j])
+    m_pv = pv_block()
+    if OPT["nofill"]:
+        return top + stream_vreads() + m_s + [I("s_waitcnt lgkmcnt(0)", "wait")] + m_pv + stream_kreads() + stream_addr() + stream_addr_k() + stream_dma()
+    # 32 MFMA gaps: 16 (S) + 16 (P.V).  The exponentials run evenly through gaps 0 .. 27.3: fragment j of both query blocks is
+    # then complete before MFMA 16 + 4 j (checked below); the maxima of S(t+1) fill the last gaps.  (lsum_mfma: 40 gaps.)
+    e_end, g_end = (33.3, 39.95) if OPT["lsum_mfma"] else (27.3, 31.95)
+    tim = spread(stream_exp(x), 0.0, e_end)
     tim += spread(stream_vreads(), 0.0, 8.0)
-    tim += spread(stream_dma(), 8.0, 13.0)
+    tim += spread(stream_dma(), 4.0, 9.0)
     tim += spread(stream_addr(), 13.0, 15.9)
     tim += spread(stream_kreads(), 16.0, 24.0)
     tim += spread(stream_addr_k(), 24.5, 27.0)
-    tim += spread(stream_max(y), 17.6, 31.95)
+    tim += spread(stream_max(y), e_end + 0.1, g_end)
     seq = interleave(m_s + m_pv, tim)
     # the first P.V MFMA needs the Vt fragments: they were requested in gaps 0-7
     idx = next(i for i, ins in enumerate(seq) if ins is m_pv[0])
     seq.insert(idx, I("s_waitcnt lgkmcnt(0)", "wait"))
-    return top + seq
+    if OPT["trace"]:
+        seq[idx + 1:idx + 1] = stamp(3)
+    return top + seq + stamp(4)
 
 
 def tail(x, tag):
     """last tile: no S(t+1); the softmax of set x has no MFMAs to hide under until the P.V phase."""
     top = [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait")]
     ex = stream_exp(x)
-    per_j = len(ex) // 4
-    m_pv = [mfma_pv(n, db, j) for j in range(4) for db in range(2) for n in range(2)]
-    pre = stream_vreads() + ex[:per_j] + [nop(3), I("s_waitcnt lgkmcnt(0)", "wait")]
-    tim = []
-    bounds = [(0.0, 2.9), (3.0, 6.9), (7.0, 10.9)]
-    for j in range(1, 4):
-        tim += spread(ex[j * per_j:(j + 1) * per_j], *bounds[j - 1])
+    m_pv = pv_block()
+    c0, c1, c2 = (split_after_fragment(ex, j) for j in range(3))
+    pre = stream_vreads() + ex[:c0] + [nop(3), I("s_waitcnt lgkmcnt(0)", "wait")]
+    st = 6 if OPT["lsum_mfma"] else 4
+    tim = spread(ex[c0:c1], 0.0, st - 1.1) + spread(ex[c1:c2], st - 1.0, 2 * st - 1.1) + spread(ex[c2:], 2 * st - 1.0, 3 * st - 1.1)
     return top + pre + interleave(m_pv, tim)
 
 
@@ -365,12 +436,20 @@ def prologue():
         for ks in range(4):
             L.append(I(f"buffer_load_dwordx4 {a(QF(n, ks), 4)}, %[qoff{n}], %[rq], 0 offen offset:{ks * 32}", "vmem"))
     # ring: tiles 0, 1, 2 (s54 counts the tile being issued)
+    if OPT["trace"]:
+        L += [salu(f"s_mov_b32 s{i}, 0") for i in range(64, 86)]
     L += [salu("s_mov_b32 s52, 0"), salu("s_mov_b32 s53, 0"), salu("s_mov_b32 s54, 0"), salu("s_mov_b32 s50, 0"),
           salu("s_sub_u32 s51, %[nt], 1")]
     for _ in range(3):
-        L += stream_dma()
+        L += stream_dma(force=True)
     for i in range(64):
         L.append(I(f"v_accvgpr_write_b32 {a(O0 + i)}, 0", "valu"))
+    for i in range(32):
+        L.append(I(f"v_accvgpr_write_b32 {a(L0 + i)}, 0", "valu"))
+    L.append(valu(f"v_mov_b32_e32 {v(T)}, 0x3f803f80", [], [f"v{T}"]))          # bf16 (1.0, 1.0)
+    L.append(nop(2))
+    for i in range(4):
+        L.append(I(f"v_accvgpr_write_b32 {a(ONES + i)}, {v(T)}", "valu", [f"v{T}"], []))
     for i in range(32):
         L.append(valu(f"v_mov_b32_e32 {v(MR0 + i)}, 0", [], [f"v{MR0 + i}"]))
     for i in range(4):
@@ -395,6 +474,8 @@ def prologue():
     L += [nop(16)]
     L += stream_max("A")
     L += slow_path("A", True, "p")
+    if OPT["trace"]:
+        L += [I("s_memtime s[64:65]", "salu"), I("s_waitcnt lgkmcnt(0)", "wait")] + [salu(f"s_mov_b32 s{i}, s64") for i in (66, 68, 70, 72, 74)]
     return L
 
 
@@ -402,11 +483,16 @@ def epilogue():
     """O / l -> bf16 rows in the wave's LDS block (the C++ side stores them as whole 128-byte rows), log2-domain LSE."""
     L = [nop(16), nop(16)]
     for n in range(2):
-        l0, l1, t0, t1 = LSUM + n * 2, LSUM + n * 2 + 1, T + 0, T + 1
-        L += [valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(l1)}", [f"v{l0}", f"v{l1}"], [f"v{l0}"]),
-              valu(f"v_mov_b32_e32 {v(t0)}, {v(l0)}", [f"v{l0}"], [f"v{t0}"]), valu(f"v_mov_b32_e32 {v(t1)}, {v(l0)}", [f"v{l0}"], [f"v{t1}"]),
-              nop(2), valu(f"v_permlane32_swap_b32_e32 {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{t0}", f"v{t1}"]), nop(2),
-              valu(f"v_add_f32_e32 {v(l0)}, {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{l0}"]),
+        l0, l1 = LSUM + n * 2, LSUM + n * 2 + 1
+        if OPT["lsum_mfma"]:
+            L += [I(f"v_accvgpr_read_b32 {v(l0)}, {a(LS(n))}", "valu", [], [f"v{l0}"]), nop(2)]   # every row of L[n] is the whole row sum
+        else:
+            t0, t1 = T + 0, T + 1
+            L += [valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(l1)}", [f"v{l0}", f"v{l1}"], [f"v{l0}"]),
+                  valu(f"v_mov_b32_e32 {v(t0)}, {v(l0)}", [f"v{l0}"], [f"v{t0}"]), valu(f"v_mov_b32_e32 {v(t1)}, {v(l0)}", [f"v{l0}"], [f"v{t1}"]),
+                  nop(2), valu(f"v_permlane32_swap_b32_e32 {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{t0}", f"v{t1}"]), nop(2),
+                  valu(f"v_add_f32_e32 {v(l0)}, {v(t0)}, {v(t1)}", [f"v{t0}", f"v{t1}"], [f"v{l0}"]), nop(2)]
+        L += [
               trans(f"v_rcp_f32_e32 {v(l1)}, {v(l0)}", [f"v{l0}"], [f"v{l1}"]),           # l1 = 1 / l_tot
               trans(f"v_log_f32_e32 {v(l0)}, {v(l0)}", [f"v{l0}"], [f"v{l0}"]),
               nop(2),
@@ -439,6 +525,8 @@ def epilogue():
                 L.append(I(f"ds_write_b128 {v(AK + c)}, {v(tb, 4)} offset:{n * 4096}", "ds", regs("v", tb, 4) + [f"v{AK + c}"], []))
     L += [I("s_waitcnt lgkmcnt(0)", "wait")]
     L += [valu(f"v_mov_b32_e32 %[lse0], {v(MREF)}", [f"v{MREF}"], []), valu(f"v_mov_b32_e32 %[lse1], {v(MREF + 1)}", [f"v{MREF + 1}"], [])]
+    if OPT["trace"]:
+        L += [valu(f"v_mov_b32_e32 %[dbg{k}], s{80 + k}", [], []) for k in range(5)]
     return L
 
 
@@ -446,15 +534,16 @@ def program():
     P = []
     P += prologue()
     P += [salu("s_cmp_eq_u32 s51, 0"), I("s_cbranch_scc1 L_tail_A%=", "branch")]
+    bodies = {x: body(x, y, x) for x, y in (("A", "B"), ("B", "A"))}
     for x, y in (("A", "B"), ("B", "A")):
         P.append(I(f"L_body_{x}%=:", "label"))
-        b = body(x, y, x)
-        other = body(y, x, y)
-        check(b + other + b, f"body {x}")      # wrap-around distances through the partner body
-        check_order(b, f"body {x}")
+        b = bodies[x]
+        if not OPT["nofill"]:
+            check(b + bodies[y] + b, f"body {x}")      # wrap-around distances through the partner body
+            check_order(b, f"body {x}")
         P += b
-        P += vote(x)
-        P += slow_path(y, False, x)
+        if not OPT["nomax"]:
+            P += vote(x)                                # rare: L_move_x (behind the loop) moves the reference, returns to L_calm_x
         P.append(I(f"L_calm_{x}%=:", "label"))
         P += [salu("s_add_u32 s50, s50, 1"), salu("s_cmp_eq_u32 s50, s51"), I(f"s_cbranch_scc1 L_tail_{y}%=", "branch")]
         if x == "B":
@@ -465,29 +554,54 @@ def program():
         check(t, f"tail {x}")
         check_order(t, f"tail {x}")
         P += t
-        if x == "A":
-            P.append(I("s_branch L_epilogue%=", "branch"))
+        P.append(I("s_branch L_epilogue%=", "branch"))
+    for x, y in (("A", "B"), ("B", "A")):
+        P.append(I(f"L_move_{x}%=:", "label"))
+        P += slow_path(y, False, x)
+        P.append(I(f"s_branch L_calm_{x}%=", "branch"))
     P.append(I("L_epilogue%=:", "label"))
     P += epilogue()
     return P
 
 
-def main():
-    P = program()
-    out = os.path.join(HERE, "attn_pwg_asm.inc")
+def write(name, P):
+    out = os.path.join(HERE, name)
     n_ins = sum(1 for i in P if i.kind != "label")
     with open(out, "w") as f:
         f.write("// GENERATED by gen_attn_pwg.py -- do not edit; the instruction stream of attn_pwg_kernel's asm statement.\n")
         f.write(f"// {n_ins} instructions.  Register map and schedule: see the generator's docstring.\n")
         for ins in P:
             f.write('"' + ins.text + '\\n"\n')
-    # clobber list
-    with open(os.path.join(HERE, "attn_pwg_clobbers.inc"), "w") as f:
-        f.write("// GENERATED by gen_attn_pwg.py: registers the asm statement of attn_pwg_kernel owns.\n")
-        names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 160)] + [f"s{i}" for i in range(50, 64)]
-        f.write(", ".join(f'"{n}"' for n in names) + "\n")
     mf = sum(1 for i in P if i.kind == "mfma")
     print(f"{out}: {n_ins} instructions, {mf} MFMAs")
+
+
+def main():
+    write("attn_pwg_asm.inc", program())
+    with open(os.path.join(HERE, "attn_pwg_clobbers.inc"), "w") as f:
+        f.write("// GENERATED by gen_attn_pwg.py: registers the asm statement of attn_pwg_kernel owns.\n")
+        names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 196)] + [f"s{i}" for i in range(50, 64)]
+        f.write(", ".join(f'"{n}"' for n in names) + "\n")
+    with open(os.path.join(HERE, "attn_pwg_clobbers_lab.inc"), "w") as f:
+        names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 196)] + [f"s{i}" for i in range(50, 86)]
+        f.write(", ".join(f'"{n}"' for n in names) + "\n")
+    if "--lab" in sys.argv:
+        # timing-only ablations (wrong results) for tools/pwg_check.py --ablate: which stream costs what
+        for i, key in enumerate(("noexp", "nomax", "nobarrier", "nodma", "nofill")):
+            OPT[key] = True
+            write(f"attn_pwg_lab{i + 1}.inc", program())
+            OPT[key] = False
+        OPT["lookahead"] = 2
+        write("attn_pwg_lab6.inc", program())
+        OPT["lookahead"] = 3
+        write("attn_pwg_lab7.inc", program())
+        OPT["lookahead"] = 1
+        OPT["trace"] = True
+        write("attn_pwg_lab8.inc", program())
+        OPT["trace"] = False
+        OPT["lsum_mfma"] = True
+        write("attn_pwg_lab9.inc", program())
+        OPT["lsum_mfma"] = False
 
 
 if __name__ == "__main__":

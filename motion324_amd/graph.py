@@ -31,11 +31,57 @@ _KEYS = ("ref_shape_pcd", "ref_shape_normals", "ref_shape_rgbs", "ref_pcd", "ref
          "point_clouds")
 
 
+class _Segmenter:
+    """A forward captured as a CHAIN of hipGraphs that share one memory pool, cut wherever the forward asks for an eager action
+    between two of them (``cut(fn)``): the frame-parallel forward's RCCL exchanges.  Capturing a collective into a hipGraph
+    segfaults on this stack (ROCm 7.0.2 / RCCL 2.26.6, tools/fp_graph_lab.py); an eager N > 1 forward leaves
+    the GPU idle between its ~350 launches.  The chain replays graph, exchange, graph, ...: nine host calls plus eight
+    collectives per clip instead of ~430 launches."""
+
+    def __init__(self, capture_error_mode: str):
+        self.pool = torch.cuda.graph_pool_handle()
+        self.mode = capture_error_mode
+        self.graphs, self.between, self.cur = [], [], None
+
+    def begin(self) -> None:
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool, capture_error_mode=self.mode)
+
+    def cut(self, eager_fn) -> None:
+        """Ends the open graph, runs eager_fn once (buffers only: nothing has executed yet), opens the next graph."""
+        self.cur.capture_end()
+        self.graphs.append(self.cur)
+        self.cur = None
+        eager_fn()
+        self.between.append(eager_fn)
+        self.begin()
+
+    def end(self) -> None:
+        if self.cur is not None:
+            self.cur.capture_end()
+            self.graphs.append(self.cur)
+            self.cur = None
+
+    def replay(self) -> None:
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.between):
+                self.between[i]()
+
+
+_SEGMENTER = None
+
+
+def active_segmenter():
+    """The segmenter of the capture in progress on this process, if any (Pcd_motion asks before every collective)."""
+    return _SEGMENTER
+
+
 class GraphedForward:
     def __init__(self, model: torch.nn.Module, warmup: int = 2, weak: bool = False, max_graphs: int = 0,
-                 capture_error_mode: str = "global", forward=None):
-        # forward: the callable captured instead of model(sample) -- e.g. model.forward_frame_parallel (its RCCL collectives
-        # are captured with it: torch's NCCL process group is capture-aware)
+                 capture_error_mode: str = "global", forward=None, segmented: bool = False):
+        # forward: the callable captured instead of model(sample) -- e.g. model.forward_frame_parallel
+        # segmented: capture a chain of graphs cut at the forward's collectives (_Segmenter) instead of one graph
         # max_graphs > 0: keep at most that many captured shape sets, dropping the least recently used (each graph owns a
         # private memory pool with a clip's activations and its static inputs).  capture_error_mode: torch.cuda.graph's
         # -- "thread_local" lets other threads (a DataLoader's pin-memory thread, another stream's allocation) keep
@@ -47,6 +93,7 @@ class GraphedForward:
         self.warmup = warmup
         self.max_graphs = max_graphs
         self._forward = forward
+        self.segmented = segmented
         self.capture_error_mode = capture_error_mode
         self._graphs: Dict[Tuple, tuple] = {}               # insertion order = recency (re-inserted on every use)
 
@@ -91,13 +138,28 @@ class GraphedForward:
                         run(static_in)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
                 gc_was_on = gc.isenabled()
                 gc.collect()
                 gc.disable()                  # no collector run may free a stream / event / graph while the capture is open
                 try:
-                    with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
-                        static_out = run(static_in)
+                    if self.segmented:
+                        global _SEGMENTER
+                        g = _Segmenter(self.capture_error_mode)
+                        cap_stream = torch.cuda.Stream()
+                        cap_stream.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(cap_stream):
+                            _SEGMENTER = g
+                            g.begin()
+                            try:
+                                static_out = run(static_in)
+                            finally:
+                                _SEGMENTER = None
+                                g.end()
+                        torch.cuda.current_stream().wait_stream(cap_stream)
+                    else:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
+                            static_out = run(static_in)
                 finally:
                     if gc_was_on:
                         gc.enable()

@@ -45,14 +45,15 @@ def _stream_seed(seed: int, key: str) -> np.uint64:
     return mixed[0]
 
 
-def uniform(seed: int, key: str, shape, lo: float = 0.0, hi: float = 1.0) -> np.ndarray:
-    """U[lo, hi) float32 tensor, element i = f(seed, key, i)."""
+def uniform(seed: int, key: str, shape, lo: float = 0.0, hi: float = 1.0, offset: int = 0) -> np.ndarray:
+    """U[lo, hi) float32 tensor, element i = f(seed, key, offset + i): `offset` cuts a window out of a longer stream (a rank's
+    frames of a clip) without generating the rest."""
     n = int(np.prod(shape))
     out = np.empty(n, dtype=np.float32)
     s = _stream_seed(seed, key)
     step = 1 << 22
     for a in range(0, n, step):
-        idx = np.arange(a, min(n, a + step), dtype=np.uint64)
+        idx = np.arange(offset + a, offset + min(n, a + step), dtype=np.uint64)
         with np.errstate(over="ignore"):
             bits = _splitmix64(idx * np.uint64(0xD1342543DE82EF95) + s)
         u = (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
@@ -220,12 +221,13 @@ def synth_state_dict(dm: Dims, seed: int = 0, perturb: bool = True) -> Dict[str,
     return {k: synth_tensor(seed, k, shape, kind, perturb) for k, (shape, kind) in state_dict_spec(dm).items()}
 
 
-def synth_inputs(B: int, T: int, N: int, S: int, HW: int, seed: int = 1, with_target: bool = False
-                 ) -> Dict[str, np.ndarray]:
+def synth_inputs(B: int, T: int, N: int, S: int, HW: int, seed: int = 1, with_target: bool = False,
+                 frames: range = None) -> Dict[str, np.ndarray]:
     """Random sample dict with the keys Motion_Latent_Model.forward reads (Pcd_motion.py:450-582).
 
     rgb_video ~ U[0,1) [B,T,HW,HW,3]; point sets ~ U[-0.5,0.5)^3 (the callers normalise meshes to a
     unit cube, scripts/inference_with_video_mesh.py:94-97); normals unit-length; colours U[0,1).
+    frames: only that window of the clip's frames is generated (values identical to the full clip's).
     """
     def unit(key, shape):
         v = normal(seed, key, shape).astype(np.float64)
@@ -239,8 +241,14 @@ def synth_inputs(B: int, T: int, N: int, S: int, HW: int, seed: int = 1, with_ta
         "ref_pcd": uniform(seed, "ref_pcd", (B, N, 3), -0.5, 0.5),
         "ref_normal": unit("ref_normal", (B, N, 3)),
         "ref_rgb": uniform(seed, "ref_rgb", (B, N, 3)),
-        "rgb_video": uniform(seed, "rgb_video", (B, T, HW, HW, 3)),
     }
+    if frames is None:
+        s["rgb_video"] = uniform(seed, "rgb_video", (B, T, HW, HW, 3))
+    else:
+        # only frames [start, stop) of the same T-frame clip (a frame-parallel rank's shard; B = 1: the frames are contiguous)
+        if B != 1:
+            raise ValueError("synth_inputs(frames=...) cuts a contiguous window: B must be 1")
+        s["rgb_video"] = uniform(seed, "rgb_video", (B, len(frames), HW, HW, 3), offset=frames.start * HW * HW * 3)
     if with_target:
         s["point_clouds"] = (s["ref_pcd"][:, None] + 0.05 * normal(seed, "point_clouds", (B, T, N, 3))).astype(np.float32)
     return s

@@ -94,6 +94,54 @@ def test_c3_training_step_batch8_gradients_and_three_optimizer_steps():
     assert all(torch.isfinite(p).all() for p in model.parameters())
 
 
+# ------------------------------------------------------------------------------------------------------ c4 (per-GPU workload)
+def test_c4_per_gpu_training_step_batch32():
+    """configs[3]'s per-GPU workload: dyscene.yaml shapes at batch_size_per_gpu = 32 (reference configs/dyscene.yaml:21-56,
+    README.md:115,124-125), bf16, ONE GPU (the 8-GPU gradient all-reduce is the driver's multi-GPU run; its bucketed launch is
+    covered by the 1-rank RCCL and the 2-rank tests).  ~110 GB of kept block internals at this batch: the kept-vs-recompute
+    budget of training.forward_backward is exercised at full scale.  Size-independent property: the loss is a batch mean, so
+    grad(B = 32) equals the mean of the four B = 8 gradients; everything finite; one real optimizer step."""
+    import motion324_amd as m
+    from motion324_amd import synth, training
+    from motion324_amd.optim import FusedAdamW, backward_completion_order
+    model = _full_model(12, train=True)
+    s_np = synth.synth_inputs(32, 12, 4096, 4096, 224, seed=5, with_target=True)
+    full = {k: torch.from_numpy(v).cuda() for k, v in s_np.items()}
+    del s_np
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    m.set_precision("bf16")
+    try:
+        loss32, out32, G32 = training.forward_backward(model, full)
+        g32 = {n: G32.get(p).float().clone() for n, p in model.named_parameters() if p.requires_grad}
+        assert out32.shape == (32, 12, 4096, 3) and torch.isfinite(out32).all() and math.isfinite(float(loss32))
+        acc = {n: torch.zeros_like(g) for n, g in g32.items()}
+        losses8 = []
+        for i in range(4):
+            part = {k: v[8 * i:8 * i + 8].contiguous() for k, v in full.items()}
+            l8, o8, G8 = training.forward_backward(model, part)
+            losses8.append(float(l8))
+            assert rel_err(o8, out32[8 * i:8 * i + 8]) < 2e-3
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    acc[n] += G8.get(p).float() / 4
+        torch.cuda.synchronize()
+        assert float(loss32) == pytest.approx(sum(losses8) / 4, rel=1e-4)
+        assert all(torch.isfinite(g).all() for g in g32.values())
+        num = math.sqrt(sum(float((g32[n] - acc[n]).double().pow(2).sum()) for n in names))
+        den = math.sqrt(sum(float(acc[n].double().pow(2).sum()) for n in names))
+        assert num / den < 1e-2, num / den
+        opt = FusedAdamW(model.named_parameters(), lr=4e-6, betas=(0.9, 0.95), weight_decay=0.05, grad_clip_norm=1.0,
+                         allowed_gradnorm_factor=1e9, order=backward_completion_order(model))
+        loss, _, _ = training.forward_backward(model, full, sink=opt)
+        opt.finish_reduce()
+        info = opt.step()
+        assert not info["skipped"] and math.isfinite(info["grad_norm"]) and float(loss) == pytest.approx(float(loss32), rel=1e-3)
+        torch.cuda.synchronize()
+    finally:
+        m.set_precision(None)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
 # ------------------------------------------------------------------------------------------------------ c5
 def _c5_available():
     return os.path.exists(os.path.join(GOLDEN, "c5.npz"))
@@ -277,6 +325,32 @@ def _rccl_worker(rank, port, ret):
             torch.cuda.synchronize()
             # the collective path splits q and k|v (m324_qkv_split instead of the fused epilogue): bf16 rounding apart
             res[f"fp_{prec}"] = (rel_err(got.pcd_moved, ref.pcd_moved), abs(float(got.loss_metrics.loss) - float(ref.loss_metrics.loss)))
+        # (1b) the same forward as a CHAIN of hipGraphs cut at the exchanges (graph.py _Segmenter; collectives cannot be captured
+        # on this stack), with the rank holding only its own frames (local_frames): replays equal the eager collective run
+        import functools
+        from motion324_amd.graph import GraphedForward
+        m.set_precision("bf16")
+        parallel.ALWAYS_COLLECT = True
+        with torch.no_grad():
+            eager = model.forward_frame_parallel(sample).pcd_moved.clone()
+            T_all = sample["rgb_video"].shape[1]
+            fp = functools.partial(model.forward_frame_parallel, local_frames=True, total_frames=T_all)
+            chain = GraphedForward(model, forward=fp, segmented=True)
+            r1 = chain(sample).pcd_moved.clone()
+            r2 = chain(sample).pcd_moved.clone()
+            seg = chain._graphs[chain._key(sample)][0]
+            # B = 1: the even-shard path (one all_gather_into_tensor straight into the reused buffer)
+            one_b = {k: v[:1].contiguous() for k, v in sample.items()}
+            eager1 = model.forward_frame_parallel(one_b).pcd_moved.clone()
+            c1 = chain(one_b).pcd_moved.clone()
+        torch.cuda.synchronize()
+        res["chain"] = (len(seg.graphs), len(seg.between), bool(torch.equal(r1, eager)), bool(torch.equal(r2, eager)))
+        res["chain_b1"] = bool(torch.equal(c1, eager1))
+        try:
+            model.forward_frame_parallel(sample, local_frames=True)
+            res["local_needs_total"] = False
+        except Exception:
+            res["local_needs_total"] = True
         m.set_precision(None)
         # (2) the sliding-window driver: windows gathered with all_gather over RCCL
         cfg = dict(training=dict(frames=dm.frames, use_amp=True))
@@ -335,6 +409,9 @@ def test_multi_gpu_paths_over_rccl_with_one_rank():
     assert r["backend"] == "nccl" and r["allreduce_ok"]
     assert r["fp_fp32"][0] < 5e-6 and r["fp_fp32"][1] < 1e-6
     assert r["fp_bf16"][0] < BF16_TOL
+    n_graphs, n_cuts, eq1, eq2 = r["chain"]
+    assert n_cuts == 2 // 2 + 1 and n_graphs == n_cuts + 1, r["chain"]      # tiny: one global block (n_layer 2) + the output gather
+    assert eq1 and eq2 and r["chain_b1"] and r["local_needs_total"]
     assert r["windows_equal"]
     assert r["train_equal"]
     early, nbuckets, side = r["buckets"]

@@ -626,6 +626,55 @@ def test_attention_long_sequence_schedules(tune, sched, Lq, Lk, odd):
     assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 2048, 512), (1, 2, 2100, 2048), (1, 2, 2304, 1088), (2, 3, 2049, 576), (1, 1, 4096, 64 * 37)])
+@pytest.mark.parametrize("spike", [True, False])
+def test_attention_one_wave_per_simd_stream(tune, B, H, Lq, Lk, spike):
+    """attention_pwg.hip (the chooser's pick for long sequences with Lk % 64 == 0): hand-placed software pipeline over the key
+    tiles.  Even / odd / prime tile counts (8, 32, 17, 9, 37: both loop bodies and both tails), ragged query counts, batches,
+    dominant keys late and early (the lazy reference moves inside the pipeline, with P.V of the previous tile in flight), the
+    LSE -- against fp64 softmax attention, and against the eight-wave kernel (M324_ATTN_PWG=0) on the same operands."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    assert "attn_pwg_kernel" in ops._attn_plan(B, H, Lq, Lk, 1, ops.code_of(dtype))
+    q, k, v = (_rand((B, H, L, 64), s_, 1.5) for L, s_ in ((Lq, 161), (Lk, 162), (Lk, 163)))
+    if spike:
+        k[0, 0, Lk - 70] = q[0, 0, 9] * 3.0                       # q9 . k >> everything, second-to-last tile
+        k[0, H - 1, 130] = q[0, H - 1, 300] * 3.0                 # an early one
+        k[B - 1, 0, 64 * 3 + 5] = q[B - 1, 0, Lq - 1] * 2.5       # the last (possibly ragged) query row
+    k, v = _q(k, dtype), _q(v, dtype)
+    qs = _q(q * ops.Q_PRESCALE, dtype)
+    dq, dk, dvt = qs.to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV)
+    res = {}
+    for pwg in ("1", "0"):
+        tune("M324_ATTN_PWG", pwg)
+        out = torch.full((B * Lq + 3, H * 64), float("nan"), dtype=dtype, device=DEV)     # three guard rows behind the output
+        lse = torch.full((B, H, Lq), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(dq, dk, dvt, out, prescaled=True, lse=lse)
+        assert torch.isnan(out[B * Lq:].float()).all()                                     # rows past Lq are never stored
+        res[pwg] = (out[:B * Lq].float().cpu(), lse.cpu())
+    sc = torch.einsum("bhqd,bhkd->bhqk", qs.double(), k.double())                          # log2-domain scores
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc * math.log(2.0), dim=-1), v.double()).reshape(B * Lq, H * 64)
+    out, lse = res["1"]
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 8e-3
+    assert rel_err(out[9], ref[9]) < 1e-2 and rel_err(out[B * Lq - 1], ref[B * Lq - 1]) < 1e-2
+    lse_ref = torch.logsumexp(sc * math.log(2.0), dim=-1) / math.log(2.0)
+    assert float((lse.double() - lse_ref).abs().max()) < 2e-2
+    assert rel_err(out, res["0"][0]) < 6e-3                       # same mathematics, different summation order
+
+
+def test_attention_one_wave_per_simd_nan_propagates():
+    """a NaN key poisons every row of its (batch, head) in the long-sequence kernel too, and only those"""
+    ops = _ops()
+    dtype = torch.bfloat16
+    B, H, L = 1, 2, 2048
+    q, k, v = (_q(_rand((B, H, L, 64), s_), dtype) for s_ in (171, 172, 173))
+    k[0, 1, 777, 5] = float("nan")
+    out = torch.empty((B * L, H * 64), dtype=dtype, device=DEV)
+    ops.attention((q * ops.Q_PRESCALE).to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV), out, prescaled=True)
+    assert torch.isnan(out[:, 64:].float()).all() and torch.isfinite(out[:, :64].float()).all()
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 64, 64), (2, 3, 100, 100), (1, 12, 324, 324), (2, 12, 257, 257), (1, 2, 2100, 2100),
                                        (3, 2, 200, 64), (1, 1, 70, 1000)])
 def test_attention_row_major_v(B, H, Lq, Lk):

@@ -10,6 +10,8 @@ from motion324_amd import lib, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--time", action="store_true")
 ap.add_argument("--shapes", default="all")
+ap.add_argument("--trace", action="store_true", help="lab library: in-kernel phase sums of one workgroup (variant 18)")
+ap.add_argument("--ablate", action="store_true", help="lab library (tools/build_pwg_lab.sh, M324_LIB=...): time the stream ablations")
 args = ap.parse_args()
 dev, dt = "cuda", torch.bfloat16
 
@@ -60,9 +62,11 @@ def run(B, H, Lq, Lk, spike=True, seed=0):
     return ok
 
 
-shapes = [(1, 2, 2048, 512), (1, 2, 2100, 2048), (1, 2, 2304, 1088), (2, 3, 2049, 576), (1, 1, 4096, 4096)]
+shapes = [] if args.shapes == "none" else [(1, 2, 2048, 512), (1, 2, 2100, 2048), (1, 2, 2304, 1088), (2, 3, 2049, 576), (1, 1, 4096, 4096)]
 if args.shapes == "all":
     shapes += [(1, 12, 10368, 10368)]
+if args.shapes == "small":
+    shapes = shapes[:3]
 allok = True
 for s in shapes:
     allok &= run(*s)
@@ -89,8 +93,24 @@ if args.time:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e3
 
+    fl = 4.0 * B * H * L * L * 64
     for rnd in range(4):
         a, b = t(1), t(0)
-        fl = 4.0 * B * H * L * L * 64
         print(f"round {rnd}: pwg {a:.1f} us = {fl / a / 1e6:.0f} TF/s   8-wave {b:.1f} us = {fl / b / 1e6:.0f} TF/s", flush=True)
+    if args.ablate:
+        names = {1: "product", 11: "no exp (v_mov)", 12: "no max / vote", 13: "no barrier", 14: "no LDS-DMA in the loop", 15: "MFMAs + reads only",
+                 16: "exp lookahead 2", 17: "exp lookahead 3", 19: "row sums by MFMA", 0: "8-wave kernel"}
+        for rnd in range(3):
+            print("  ".join(f"[{names[k]}] {t(k, 10):.1f}" for k in names), flush=True)
+    if args.trace:
+        buf = torch.zeros(B * H * L + 64, dtype=torch.float32, device=dev)
+        lib.set_tunable("M324_ATTN_PWG", 18)
+        for _ in range(3):
+            ops.attention(q, k, vt, out, prescaled=True, lse=buf[:B * H * L].view(B, H, L))
+        torch.cuda.synchronize()
+        d = buf[B * H * L:].view(torch.int32).cpu().tolist()
+        for w in range(4):
+            r = d[w * 8:w * 8 + 6]
+            n = max(1, r[5] - 2)
+            print(f"wave {w}: per tile (cycles): wait {r[0] / n:.0f}  barrier {r[1] / n:.0f}  S phase {r[2] / n:.0f}  P.V phase {r[3] / n:.0f}  period {r[4] / n:.0f}   (nt {r[5]})", flush=True)
     lib.set_tunable("M324_ATTN_PWG")
