@@ -49,27 +49,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* base, lon
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7FFFFFFFl ? 0x7FFFFFFFl : bytes), 0x00020000);
 }
 
-// Lab builds only (tools/build_attn_lab.sh trace -DM324_ATTN_TRACE, tools/attn_trace.py): the first wave of each half of one
-// workgroup in the middle of the grid stamps the shader clock at its phase boundaries of key tiles 60-75 into the LSE buffer.
-#ifdef M324_ATTN_TRACE
-#define ATRACE_DECL                                                                                                     \
-    const bool tr_on = lse && blockIdx.x == (gridDim.x >> 1) + 3 && (wave & 3) == 0;                                     \
-    long long* tbuf = reinterpret_cast<long long*>(lse) + (wave >> 2) * 1024;
-#define ATRACE(t, slot)                                                                                                 \
-    do {                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        if (tr_on && (t) >= 60 && (t) < 76) {                                                                           \
-            const long long c_ = __builtin_readcyclecounter();                                                          \
-            if (lane == 0) tbuf[((t) - 60) * 8 + (slot)] = c_;                                                          \
-        }                                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-    } while (0)
-#define ATRACE_LSE(x)
-#else
-#define ATRACE_DECL
-#define ATRACE(t, slot)
-#define ATRACE_LSE(x) x
-#endif
 
 // A row of an O^T-style accumulator pair (lanes l and l + 32 hold alternating 4-value groups of row l & 31, 16 values per
 // 32-column block db): v_permlane32_swap trades the odd groups of the lower lanes for the even groups of the upper ones, so
@@ -199,7 +178,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
     bool first = true;
 
     const int nt = (Lk + KV - 1) / KV;
-    ATRACE_DECL
     issue_tile(0);
     if (nt > 1) issue_tile(1);
     // Static priority for the second-dispatched half of an 8-wave workgroup (experiment switch M324_ATTN_EXP bit 0): the
@@ -215,13 +193,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
     for (int t = 0; t < nt; ++t) {
         // tile t landed (this wave's 4 pieces; tile t+1's may still fly), then the barrier publishes every
         // wave's pieces and retires all reads of the stage that tile t+2 is about to overwrite
-        ATRACE(t, 0);
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ATRACE(t, 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        ATRACE(t, 2);
         if (t + 2 < nt) issue_tile(t + 2);
         const unsigned char* sk = smem + (t % NST) * ASTAGE;
         const unsigned char* sv = sk + 8192;
@@ -271,7 +246,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
                     for (int r = 0; r < 16; ++r) s[n][kb][r] *= scale_log2e;
         }
         const int kv0 = t * KV;
-        ATRACE(t, 3);
         if (kv0 + KV > Lk) {   // ragged last tile: mask keys >= Lk (wave-uniform branch)
 #pragma unroll
             for (int n = 0; n < NQ; ++n)
@@ -315,7 +289,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
             }
             first = false;
         }
-        ATRACE(t, 4);
         bf16x8 pf[NQ][4];   // P^T fragments, k-step j = kb*2 + (r>>3)
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
@@ -336,7 +309,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
             l_run[n] += rs2[0] + rs2[1];
         }
 
-        ATRACE(t, 5);
         // ---- O^T += Vt P^T.  k-step j contracts keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}: with the permuted
         //      key order of Vt that is the single 16-byte chunk 2j + hi of row d
 #pragma unroll
@@ -371,7 +343,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
         const float l_tot = l_run[n] + __shfl_xor(l_run[n], 32, 64);
         const float inv = 1.0f / l_tot;
         const int q = q0 + n * QW + l31;
-        ATRACE_LSE(if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_ref[n] + log2f(l_tot);)   // log2-domain LSE
+        if (lse && q < Lq && hi == 0) lse[((long)b * H + h) * Lq + q] = m_ref[n] + log2f(l_tot);   // log2-domain LSE
         // The two lanes of a query (l, l + 32) hold alternating 4-value groups of its row.  v_permlane32_swap trades the
         // odd groups of the lower lanes for the even groups of the upper ones, so every lane has whole 8-value (16-byte)
         // chunks; those bounce through a wave-private, XOR-swizzled 32 x 128-byte LDS block so that a store instruction
@@ -629,33 +601,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
 #pragma unroll
         for (int r = 0; r < 16; ++r) ak[i][r] = 0.f, av[i][r] = 0.f;
     const int nt = (Lq + KV - 1) / KV;
-#ifdef M324_ATTN_TRACE
-    // lab builds: stamps of query tiles 20-35 of one workgroup's first wave go behind the dV tensor (tools/attn_bwd_lab.py)
-    const bool tr_on = blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == (gridDim.z >> 1) && wave == 0;
-    long long* tbuf = reinterpret_cast<long long*>(dV + (long)gridDim.z * H * Lk * 64);
-#define BTRACE(t, slot)                                                                                                 \
-    do {                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-        if (tr_on && (t) >= 20 && (t) < 36) {                                                                           \
-            const long long c_ = __builtin_readcyclecounter();                                                          \
-            if (lane == 0) tbuf[((t) - 20) * 8 + (slot)] = c_;                                                          \
-        }                                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-    } while (0)
-#else
-#define BTRACE(t, slot)
-#endif
     issue(0);
     for (int t = 0; t < nt; ++t) {
         // the LDS-DMA of tile t must have landed: stated explicitly -- __syncthreads() alone is compiled to
         // `s_waitcnt lgkmcnt(0); s_barrier` here (no vmcnt), which let a workgroup read a stage that was still in flight
-        BTRACE(t, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BTRACE(t, 1);
         __syncthreads();
-        BTRACE(t, 2);
         if (t + 1 < nt) issue(t + 1);
-        BTRACE(t, 3);
         const unsigned char* sq = smem + (t & 1) * 32768;
         const unsigned char* sdo = sq + 8192;
         const unsigned char* sqt = sq + 16384;
@@ -702,7 +654,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
                 ft[i] = *reinterpret_cast<const bf16x8*>((i & 1 ? sqt : sdot) + k_off(((i >> 1) & 1) * 32 + l31, 2 * (i >> 2) + hi));
             __builtin_amdgcn_sched_barrier(0);
         }
-        BTRACE(t, 4);
         const float* rowv = reinterpret_cast<const float*>(smem + 65536 + (t & 1) * 512);
         const bool ragged = q0 + KV > Lq;
 #pragma unroll
@@ -724,7 +675,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf
         bf16x8 pf[4], dsf[4];
         pack_frags(s, pf);
         pack_frags(dp, dsf);
-        BTRACE(t, 5);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll

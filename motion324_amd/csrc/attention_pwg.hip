@@ -35,55 +35,6 @@ __device__ __forceinline__ i32x4 rsrc_words(const void* base, long bytes) {
 #undef PWG_KERNEL
 #undef PWG_ASM_INC
 
-#ifdef M324_PWG_LAB      // tools/build_attn_lab.sh: timing-only ablations of the stream (gen_attn_pwg.py --lab), M324_ATTN_PWG = 11 .. 17
-#define PWG_KERNEL attn_pwg_lab1_kernel
-#define PWG_ASM_INC "attn_pwg_lab1.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#define PWG_KERNEL attn_pwg_lab2_kernel
-#define PWG_ASM_INC "attn_pwg_lab2.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#define PWG_KERNEL attn_pwg_lab3_kernel
-#define PWG_ASM_INC "attn_pwg_lab3.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#define PWG_KERNEL attn_pwg_lab4_kernel
-#define PWG_ASM_INC "attn_pwg_lab4.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#define PWG_KERNEL attn_pwg_lab5_kernel
-#define PWG_ASM_INC "attn_pwg_lab5.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#define PWG_KERNEL attn_pwg_lab6_kernel
-#define PWG_ASM_INC "attn_pwg_lab6.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#define PWG_KERNEL attn_pwg_lab7_kernel
-#define PWG_ASM_INC "attn_pwg_lab7.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#define PWG_TRACE
-#define PWG_KERNEL attn_pwg_lab8_kernel
-#define PWG_ASM_INC "attn_pwg_lab8.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#undef PWG_TRACE
-#define PWG_KERNEL attn_pwg_lab9_kernel
-#define PWG_ASM_INC "attn_pwg_lab9.inc"
-#include "attn_pwg_kernel.inl"
-#undef PWG_KERNEL
-#undef PWG_ASM_INC
-#endif
 
 }  // namespace
 
@@ -95,20 +46,6 @@ void m324_attn_pwg_launch(const void* Q, long q_bstride, const void* K, const vo
 #define PWG_LAUNCH(KERNEL)                                                                                                  \
     hipLaunchKernelGGL(KERNEL, dim3((unsigned)((long)nqt * H * B)), dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K, \
                        (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, lse, nqt)
-#ifdef M324_PWG_LAB
-    switch (m324::tunable(m324::TUN_ATTN_PWG)) {
-        case 11: PWG_LAUNCH(attn_pwg_lab1_kernel); return;
-        case 12: PWG_LAUNCH(attn_pwg_lab2_kernel); return;
-        case 13: PWG_LAUNCH(attn_pwg_lab3_kernel); return;
-        case 14: PWG_LAUNCH(attn_pwg_lab4_kernel); return;
-        case 15: PWG_LAUNCH(attn_pwg_lab5_kernel); return;
-        case 16: PWG_LAUNCH(attn_pwg_lab6_kernel); return;
-        case 17: PWG_LAUNCH(attn_pwg_lab7_kernel); return;
-        case 18: PWG_LAUNCH(attn_pwg_lab8_kernel); return;
-        case 19: PWG_LAUNCH(attn_pwg_lab9_kernel); return;
-        default: break;
-    }
-#endif
     PWG_LAUNCH(attn_pwg_kernel);
 #undef PWG_LAUNCH
 }

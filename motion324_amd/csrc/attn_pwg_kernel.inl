@@ -1,5 +1,5 @@
 // The kernel body of attention_pwg.hip; included once per instruction stream (PWG_KERNEL = kernel name, PWG_ASM_INC = the
-// generated stream: attn_pwg_asm.inc for the product, attn_pwg_lab*.inc for the timing-only ablations of lab builds).
+// generated stream: attn_pwg_asm.inc for the product; tools/lab_src/attention_pwg_lab.hip includes it with the timing-only ablation streams).
 __global__ __launch_bounds__(256, 1) void PWG_KERNEL(const bf16_t* __restrict__ Q, long q_bstride, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, long ldo, int H, int Lq,
                                                           int Lk, int Lkp, float* __restrict__ lse, int nqt) {
@@ -41,30 +41,14 @@ __global__ __launch_bounds__(256, 1) void PWG_KERNEL(const bf16_t* __restrict__ 
     const unsigned escr = lds0 + (unsigned)(wave * 8192 + l31 * 128 + ((hi ^ (l31 & 7)) << 4));
     const int nt = __builtin_amdgcn_readfirstlane(Lk >> 6);
     float lse0, lse1;
-#ifdef PWG_TRACE
-    unsigned dbg0, dbg1, dbg2, dbg3, dbg4;
-#endif
     asm volatile(
 #include PWG_ASM_INC
         : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)
-#ifdef PWG_TRACE
-          , [dbg0] "=&v"(dbg0), [dbg1] "=&v"(dbg1), [dbg2] "=&v"(dbg2), [dbg3] "=&v"(dbg3), [dbg4] "=&v"(dbg4)
-#endif
         : [rq] "s"(rq), [rk] "s"(rk), [rv] "s"(rv), [nt] "s"(nt), [wlds] "s"(wlds), [ko0] "v"(ko0), [vk0] "v"(vk[0]), [vk1] "v"(vk[1]),
           [vv0] "v"(vv[0]), [vv1] "v"(vv[1]), [qoff0] "v"(qoff0), [qoff1] "v"(qoff1), [escr] "v"(escr)
         : "memory", "vcc", "scc",
-#ifdef PWG_TRACE
-#include "attn_pwg_clobbers_lab.inc"
-#else
 #include "attn_pwg_clobbers.inc"
-#endif
     );
-#ifdef PWG_TRACE     // phase sums of one workgroup in the middle of the grid, behind the LSE rows (tools/pwg_check.py --trace)
-    if (lse && blockIdx.x == (gridDim.x >> 1) + 3 && lane == 0) {
-        unsigned* d = reinterpret_cast<unsigned*>(lse + (long)gridDim.x / nqt * Lq) + wave * 8;
-        d[0] = dbg0, d[1] = dbg1, d[2] = dbg2, d[3] = dbg3, d[4] = dbg4, d[5] = (unsigned)nt;
-    }
-#endif
     // whole 128-byte rows out of the wave's block: 8 rows per store instruction
     const int r8 = lane >> 3, c8 = lane & 7;
 #pragma unroll

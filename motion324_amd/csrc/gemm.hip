@@ -294,29 +294,6 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
 //   lgkmcnt(0) (stage s is in registers), vmcnt(4) (W_{s+1} landed; the 4 pieces of A_{s+2} may fly), X_s.
 // Past the end of K the last stage is fetched again into free chunks (never read), so the loop is branch-free.
 
-// Lab builds only (tools/build_lab_lib.sh trace -DM324_GEMM_TRACE, tools/gemm_trace.py): waves 0 and 4 of one workgroup in the
-// middle of the grid stamp s_memtime around the prologue, every K-stage (start / MFMAs issued / own LDS-DMA landed) and the
-// epilogue of the 256 x 256 chunk-ring kernel into a buffer handed over by m324_lab_trace_buffer().
-#ifdef M324_GEMM_TRACE
-__device__ long long* g_m324_trace = nullptr;
-#define GTRACE_DECL                                                                                        \
-    long long* tbuf_ = g_m324_trace;                                                                       \
-    const bool tr_on_ = tbuf_ && blockIdx.x == (gridDim.x >> 1) + 5 && (wave & 3) == 0;                    \
-    int tslot_ = 0;
-#define GTRACE()                                                                                           \
-    do {                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if (tr_on_) {                                                                                      \
-            const long long c_ = __builtin_readcyclecounter();                                             \
-            if (lane == 0 && tslot_ < 120) tbuf_[(wave >> 2) * 128 + tslot_] = c_;                         \
-            ++tslot_;                                                                                      \
-        }                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-    } while (0)
-#else
-#define GTRACE_DECL
-#define GTRACE()
-#endif
 
 template <typename TOUT, int ACT, int RES>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
@@ -399,8 +376,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
     };
 
-    GTRACE_DECL
-    GTRACE();                                               // 0: kernel entry (after address set-up)
     // prologue of the FIRST tile: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile
     // (12 in all at K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue
     {
@@ -411,11 +386,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         issue2b(0, s1, 3); issue2b(2, s1, 3);
         issue2a(0, s2, 4); issue2a(2, s2, 4);
     }
-    GTRACE();                                               // 1: prologue pieces issued
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (A_1, W_1, A_2 may fly)
-    GTRACE();                                               // 2: stage 0 landed (own pieces)
     M324_BARRIER();
-    GTRACE();                                               // 3: first barrier passed
     int pa = 0, pw = 1;                                     // ring positions of A_s, W_s
     auto stage = [&](int s, auto issue_tag) {
         constexpr bool ISSUE = decltype(issue_tag)::value;
@@ -439,13 +411,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         if constexpr (ISSUE) issue2a(2, sa, pan);
         mma8(0);
         sched_kstep();
-        GTRACE();                                           // 4 + 3 s: the stage's 32 MFMAs issued
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        GTRACE();                                           // 5 + 3 s: own LDS-DMA pieces of the next stage landed
-#ifndef M324_LAB_NO_STAGE_BARRIER                          // lab only (WRONG results): what do the stage barriers cost?
         M324_BARRIER();
-#endif
-        GTRACE();                                           // 6 + 3 s: barrier passed
         pa = pa + 2 >= 5 ? pa - 3 : pa + 2;
         pw = pw + 2 >= 5 ? pw - 3 : pw + 2;
     };
@@ -477,7 +444,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         mma8(1);                                            // (NS-1, k-step 3)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the main loop: the ring becomes scratch
         M324_BARRIER();
-        GTRACE();                                           // 4 + 3 NS: last k-step issued, ring drained, barrier passed
         if (more) {                                         // the next tile's first chunks land under this tile's epilogue
             tile_setup(t + gridDim.x);
             issue2a(0, 0, 0); issue2a(2, 0, 0);
@@ -485,7 +451,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         }
         store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem + 2 * CHUNK10) + wave * ep_wave_floats(ACT), C, ldc, M, N,
                                           mt + wm * 128, nt + wn * 64, lane, ep, &ln_pre);
-        GTRACE();                                           // 5 + 3 NS: epilogue done
         if (more) {
             // everything this wave has in flight -- the two prefetched chunks and the epilogue's stores (loads and stores share
             // vmcnt and may retire out of order with respect to each other) -- must be done before the next tile starts.  The
@@ -1332,9 +1297,3 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
     M324_FAIL(M324_ERR_UNSUPPORTED, "m324_gemm: unsupported dtype pair in=%d out=%d", a->in_dtype, a->out_dtype);
 }
 
-#ifdef M324_GEMM_TRACE
-extern "C" int m324_lab_trace_buffer(void* buf) {
-    long long* p = static_cast<long long*>(buf);
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_m324_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
-}
-#endif

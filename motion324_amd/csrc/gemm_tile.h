@@ -454,11 +454,6 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                                                int nw, int lane, const Epilogue& ep, const LnPre* pre = nullptr) {
     constexpr int ACT = ACTX & 7;
     constexpr bool fold = (ACTX & 8) != 0, STATS = (ACTX & 16) != 0, COPY = (ACTX & 32) != 0;
-#if defined(M324_LAB_NOSTORE) && defined(__HIP_DEVICE_COMPILE__)          // tools/ lab builds only: main loop without its epilogue (accumulators kept alive)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) { asm volatile("" ::"v"(acc[i][0])); asm volatile("" ::"v"(acc[i][1])); }
-    return;
-#endif
     const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
     const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
     const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """Attention backward (bf16 MFMA kernels) alone, at the training step's shapes: time of the dQ + dK/dV pair per call, A/B of
-M324_ATTN_BWD_NW, and -- with a lab build (tools/build_attn_lab.sh trace -DM324_ATTN_TRACE; M324_LIB=...) -- the dK/dV
-kernel's own timeline (s_memtime stamps of one wave, query tiles 20-35):
-    0 tile body done | 1 LDS-DMA landed | 2 barrier passed | 3 next tile's LDS-DMA issued | 4 S / dP MFMAs issued |
-    5 exp / products / packs done | (next 0) dV / dK MFMAs issued
-usage: tools/attn_bwd_lab.py [--B 8] [--L 3888] [--trace]"""
+M324_ATTN_BWD_NW.  (Round 3's in-kernel s_memtime stamps of the dK/dV kernel -- the measurement behind lse / D riding with the
+tile, profiles/r03_coissue_lab.md and DESIGN 7b -- needed trace macros inside the kernels; round 4 took all lab hooks out of
+the product sources, the stamped build is commit 427cabf.)
+usage: tools/attn_bwd_lab.py [--B 8] [--L 3888]"""
 import argparse, ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +13,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=8)
 ap.add_argument("--L", type=int, default=3888)
 ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--trace", action="store_true")
 a = ap.parse_args()
 dev, dt = "cuda", torch.bfloat16
 B, H, L = a.B, 12, a.L
@@ -61,14 +59,3 @@ for nw in (4, 8):
     ms = sorted(res[nw])[len(res[nw]) // 2]
     print(f"B={B} H={H} L={L} M324_ATTN_BWD_NW={nw}: dQ + dK/dV {ms * 1e3:.1f} us per call = {flops / ms / 1e9:.0f} TF/s (median of 5 interleaved rounds)", flush=True)
 lib.set_tunable("M324_ATTN_BWD_NW", 0)
-if a.trace:
-    call()
-    torch.cuda.synchronize()
-    tb = dV[B * H * L * 64:].view(torch.int64).cpu()[:128].reshape(16, 8).tolist()
-    NS = 6
-    seq = [tb[t][s] for t in range(16) for s in range(NS)]
-    d = {s: [] for s in range(NS)}
-    for i in range(len(seq) - 1):
-        d[i % NS].append(seq[i + 1] - seq[i])
-    med = {s: sorted(v)[len(v) // 2] for s, v in d.items() if v}
-    print("dK/dV kernel, wave 0 of one workgroup: " + "  ".join(f"{s}->{(s + 1) % NS}: {med[s]}" for s in range(NS)) + f"   period {sum(med.values())} cycles")

@@ -11,7 +11,7 @@ from motion324_amd import build as B
 
 bad_total = 0
 n_dma_kernels = 0
-SRCS = ("gemm.hip", "gemm_ring4.hip", "attention.hip")
+SRCS = ("gemm.hip", "gemm_ring4.hip", "attention.hip", "attention_pwg.hip")
 asm = B.assembly(SRCS)
 for src in SRCS:
     if True:

@@ -80,15 +80,33 @@ if args.time:
     vt = vt_layout(torch.randn(B, H, L, 64, device=dev).to(dt))
     out = torch.empty((B * L, H * 64), dtype=dt, device=dev)
 
+    import ctypes as C
+
+    def lab_call(variant, lse_t=None):
+        """tools/lab_src/attention_pwg_lab.hip (lab library only): ablation stream `variant` at the product's launch geometry"""
+        f = lib.load().m324_lab_attn_pwg
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
+        rc = f(variant, q.data_ptr(), H * L * 64, k.data_ptr(), vt.data_ptr(), out.data_ptr(), H * 64, B, H, L, L,
+               lse_t.data_ptr() if lse_t is not None else None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+
     def t(pwg, iters=20):
-        lib.set_tunable("M324_ATTN_PWG", pwg)
+        if pwg >= 10:
+            fn = lambda: lab_call(pwg - 10)
+        else:
+            lib.set_tunable("M324_ATTN_PWG", pwg)
+            fn = lambda: ops.attention(q, k, vt, out, prescaled=True)
+        return _t(fn, iters)
+
+    def _t(fn, iters):
         for _ in range(3):
-            ops.attention(q, k, vt, out, prescaled=True)
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.attention(q, k, vt, out, prescaled=True)
+            fn()
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e3
@@ -104,9 +122,8 @@ if args.time:
             print("  ".join(f"[{names[k]}] {t(k, 10):.1f}" for k in names), flush=True)
     if args.trace:
         buf = torch.zeros(B * H * L + 64, dtype=torch.float32, device=dev)
-        lib.set_tunable("M324_ATTN_PWG", 18)
         for _ in range(3):
-            ops.attention(q, k, vt, out, prescaled=True, lse=buf[:B * H * L].view(B, H, L))
+            lab_call(8, buf)
         torch.cuda.synchronize()
         d = buf[B * H * L:].view(torch.int32).cpu().tolist()
         for w in range(4):
