@@ -115,6 +115,11 @@ def weight_grad(dy: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] =
         else:                                                    # 128 x 128 tiles, two workgroups per CU
             tiles = ((N + 127) // 128) * ((Ka + 127) // 128)
             slices = max(1, min(32, (640 + tiles - 1) // tiles, M // 512))
+        # m324_gemm_tn addresses a slice's rows through 32-bit buffer offsets: (rows per slice + 64) * ld * 2 bytes < 2 GiB.
+        # Very long token counts need more slices than the occupancy rule asks for.
+        ld = max(dy.stride(0), a.stride(0))
+        while slices < 4096 and (M // slices + 64 + 1) * ld * 2 >= (1 << 31):
+            slices *= 2
         return ops.gemm_tn(dy, a, slices, out=out)
     return _wgrad(ops.transpose(dy), ops.transpose(a))
 

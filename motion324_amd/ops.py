@@ -42,6 +42,15 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+def _wrote(*tensors) -> None:
+    """libm324 writes through raw pointers: torch's in-place version counters do not see it.  Every wrapper marks the tensors
+    its kernels write, so that `_version`-keyed caches (backward.Carry's bf16 twin of a gradient, the Prepared weight stamp) are
+    invalidated by library writes exactly as by torch writes."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def _vec(t: Optional[torch.Tensor], n: int, name: str) -> Optional[int]:
     if t is None:
         return None
@@ -207,6 +216,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
             L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
         return part
     args.C, args.ldc = _rows(out, "out")
+    _wrote(out)
     args.in_dtype, args.out_dtype = code_of(a.dtype), code_of(out.dtype)
     args.bias = _vec(bias, N, "bias")
     args.act = act
@@ -553,6 +563,7 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     px, ldx = _rows(x, "x")
     pdy, ldy = _rows(dy, "dy")
     pdx, lddx = _rows(dx, "dx")
+    _wrote(dx)
     n_partial = min(512, (rows + 7) // 8)               # workgroups of 8 waves, one row per wave at a time
     nb = 2 if cast_out is None else 3
     partial = torch.empty((n_partial, nb * Cdim), dtype=torch.float32, device=x.device)
@@ -566,6 +577,7 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     if cast_out.dtype != torch.bfloat16 or cast_out.shape != dx.shape:
         raise L.M324Error("layernorm_bwd: cast_out must be a bf16 tensor shaped like dx")
     pc, ldc = _rows(cast_out, "cast_out")
+    _wrote(cast_out)
     L.check(L.load().m324_layernorm_bwd_cast(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
                                              int(accumulate), _p(partial), n_partial, rows, Cdim, gin, gout, off, pc, ldc,
                                              _stream()), "m324_layernorm_bwd_cast")

@@ -188,6 +188,10 @@ class FusedAdamW:
         """Call before a backward whose GradStore uses this optimizer as its sink."""
         self._reset_reduce_state()
 
+    def step_launches(self) -> int:
+        """Gradient buckets of the current step already handed to the other ranks (a step cannot be redone after that)."""
+        return len(self._works)
+
     def _launch_bucket(self, b: int) -> None:
         world = self._world()
         self._launched[b] = True

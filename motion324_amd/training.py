@@ -49,6 +49,9 @@ def _point_features_bwd(model, P: Prepared, G: bw.GradStore, enc, feat, d_pf: to
 TRAIN_STORE = switches.get("M324_TRAIN_STORE")             # "1": keep block internals while they fit, "0": always recompute
 
 
+LAST_STEP_BLOCKS = None      # {"trunk_blocks_kept": n, ...} of the most recent forward_backward (bench.py reports it)
+
+
 def _store_budget(dev: torch.device) -> int:
     """Bytes the forward may spend on kept block internals: half of what is free now (the backward's own work buffers,
     the decoder and the gradient buckets need the rest); 0 with M324_TRAIN_STORE=0."""
@@ -65,8 +68,29 @@ def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float =
     sink: a motion324_amd.optim.FusedAdamW -- gradients are then written into its flat buffer and each bucket's
     all-reduce leaves on the optimizer's side stream as soon as the backward has finished the bucket's tensors."""
     from .transformer import fusion_disabled
+    global TRAIN_STORE
     with fusion_disabled():
-        return _forward_backward(model, sample, grad_scale, drop_seed, sink)
+        try:
+            return _forward_backward(model, sample, grad_scale, drop_seed, sink)
+        except torch.cuda.OutOfMemoryError:
+            # The keep-internals budget is an estimate taken before the forward (half of the free memory); on a shared or
+            # smaller device the backward's own peak can still exceed what is left.  One retry with the reference's policy
+            # (checkpoint every block, recompute in the backward) -- unless this step already sent gradient buckets to the
+            # other ranks: they would reduce this rank's first attempt.
+            if TRAIN_STORE == "0" or (sink is not None and getattr(sink, "step_launches", lambda: 0)() > 0):
+                raise
+            import warnings
+            warnings.warn("motion324_amd.training: out of memory with kept block internals; this step is redone with "
+                          "checkpoint + recompute (M324_TRAIN_STORE=0 makes that the policy)", RuntimeWarning)
+            if drop_seed is None and model.training and float(model.drop_rate) > 0.0:
+                drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            torch.cuda.empty_cache()
+            keep = TRAIN_STORE
+            TRAIN_STORE = "0"
+            try:
+                return _forward_backward(model, sample, grad_scale, drop_seed, sink)
+            finally:
+                TRAIN_STORE = keep
 
 
 def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None,
@@ -141,7 +165,9 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     out = torch.empty((B, T, N, 3), dtype=torch.float32, device=dev)
     pcd, nrm, rgb = (_f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
     dec_saved = []
-    per_dec = T * N * C * 30                                  # bytes kept per sample: decoder block internals + head
+    # bytes kept per sample: decoder block internals (o 2C, x_mid 4C, h2 2C, z 8C, g 8C, x 4C) + head (h, z2, h2: 6C) per row =
+    # 34 C, plus the q / k|v side tensors; 38 C bounds it
+    per_dec = T * N * C * 38
     for b in range(B):
         pf, enc_p, feat_p = _point_features_train(model, P, pcd[b], nrm[b].contiguous(), rgb[b].contiguous())
         tok_b = tok[b * T * Lt:(b + 1) * T * Lt]
@@ -167,6 +193,10 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
             head = None
         ops.linear_n3(h2, w3, b3, out[b])
         dec_saved.append((pf, enc_p, feat_p, x, sv, head))
+    global LAST_STEP_BLOCKS
+    LAST_STEP_BLOCKS = {"trunk_blocks_kept": sum(1 for t in trunk_saved if t is not None), "trunk_blocks_recomputed":
+                        sum(1 for t in trunk_saved if t is None), "decoder_samples_kept": sum(1 for d in dec_saved if d[4] is not None),
+                        "decoder_samples_recomputed": sum(1 for d in dec_saved if d[4] is None)}
     target = _f32c(sample["point_clouds"])
     mse = ops.mse(out, target, 1.0)
     loss = mse * weight

@@ -492,6 +492,45 @@ def test_layernorm_row_gather():
     assert rel_err(out, ref) < 1e-6
 
 
+@pytest.mark.parametrize("rows_per_wave", [2, 1])
+def test_reductions_give_the_solo_result_beside_a_chunk_ring_gemm(tune, rows_per_wave):
+    """Dynamic guard for the round-3 wrong-result hazard (v_mov_b32_dpp + v_pk_add_f32 returned ulp-shifted row sums whenever a
+    chunk-ring GEMM shared the CU; the build's -fno-slp-vectorize removed the pair, tools/audit_dpp.py scans for it statically):
+    200 LayerNorm launches and 100 row-statistics launches on one stream while a second stream runs chunk-ring GEMMs (v10, then
+    v13) -- every result must equal the solo result bit for bit, whatever the compiler version makes of the DPP reductions."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    tune("M324_LN_ROWS", rows_per_wave)
+    M, C = 1285, 768
+    x = _rand((M, C), 301, 1.3).to(DEV) + 0.2
+    w, b = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1
+    a2 = _rand((1028, 768), 302).to(torch.bfloat16).to(DEV)
+    w2 = _rand((3072, 768), 303, 0.02).to(torch.bfloat16).to(DEV)
+    o2 = torch.empty(1028, 3072, device=DEV, dtype=torch.bfloat16)
+    bias2 = torch.randn(3072, device=DEV)
+    ref = torch.empty(M, C, device=DEV, dtype=torch.bfloat16)
+    ops.layernorm(x, w, b, 1e-6, ref)
+    st_ref = torch.empty((M, 2), dtype=torch.float32, device=DEV)
+    ops.rowstats(x, 1e-6, st_ref, None)
+    torch.cuda.synchronize()
+    for sched in ("v10", "v13"):
+        tune("M324_GEMM", sched)
+        side = torch.cuda.Stream()
+        outs = [torch.empty(M, C, device=DEV, dtype=torch.bfloat16) for _ in range(200)]
+        stats = [torch.empty((M, 2), dtype=torch.float32, device=DEV) for _ in range(100)]
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(400):
+                ops.gemm(a2, w2, o2, bias=bias2, act=ACT_GELU)
+        for i, o in enumerate(outs):
+            ops.layernorm(x, w, b, 1e-6, o)
+            if i < len(stats):
+                ops.rowstats(x, 1e-6, stats[i], None)
+        torch.cuda.synchronize()
+        bad = sum(int(not torch.equal(o, ref)) for o in outs) + sum(int(not torch.equal(t, st_ref)) for t in stats)
+        assert bad == 0, f"{bad} of 300 reduction results beside {sched} differ from the solo result"
+
+
 # ------------------------------------------------------------------------------------------- qkv split
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,L,H,norm", [(2, 100, 3, True), (1, 324, 12, True), (3, 257, 12, False), (2, 64, 2, True)])
