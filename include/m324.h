@@ -184,9 +184,13 @@ int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, con
  *   (Lkp = round_up(Lk,64), zero padded).  O[B, Lq, H*64] token-major (ldo = row stride), same dtype.
  *   q_prescaled is a flag word: M324_ATTN_Q_PRESCALED (1): Q already holds q * scale * log2(e) (see m324_qkv_split) and
  *   `scale` is ignored; M324_ATTN_V_ROWMAJOR (2, bf16 only): the `Vt` argument is row-major V[B,H,Lk,64] (not transposed,
- *   not padded) and the kernel transposes its fragments in the LDS read.
+ *   not padded) and the kernel transposes its fragments in the LDS read; M324_ATTN_SCORES_BOUNDED (4): the caller vouches
+ *   that every log2-domain score |q . k * scale * log2(e)| is <= 64 (per-head RMSNorm bounds it by 64 max|w_q| max|w_k|
+ *   scale log2(e), transformer.py:36-42): kernels that have such a form (the long-sequence kernel attention_pwg.hip) then run
+ *   the softmax without a reference maximum -- exp2, sum and bf16 pack only; the others ignore the flag.  Results are the
+ *   same softmax (2^s / sum 2^s needs no shift inside fp32 / bf16 range); scores beyond the vouched bound overflow.
  * ------------------------------------------------------------------------------------------ */
-enum { M324_ATTN_Q_PRESCALED = 1, M324_ATTN_V_ROWMAJOR = 2 };
+enum { M324_ATTN_Q_PRESCALED = 1, M324_ATTN_V_ROWMAJOR = 2, M324_ATTN_SCORES_BOUNDED = 4 };
 int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo,
                    int B, int H, int Lq, int Lk, float scale, int q_prescaled, float* lse, int dtype, void* stream);
 /* Host-only twin of m324_gemm_plan for m324_attention (flags = the q_prescaled flag word). */

@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libm324.so")
 SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "attention.hip", "attention_pwg.hip", "elementwise.hip", "backward.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(HERE, "..", "include", "m324.h"),
-           os.path.join(CSRC, "attn_pwg_asm.inc"), os.path.join(CSRC, "attn_pwg_clobbers.inc"),
+           os.path.join(CSRC, "attn_pwg_asm.inc"), os.path.join(CSRC, "attn_pwg_bounded_asm.inc"), os.path.join(CSRC, "attn_pwg_clobbers.inc"),
            os.path.join(CSRC, "attn_pwg_kernel.inl")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified 512-entry file), which removes the
 # v_accvgpr_read/write shuffling around every softmax / epilogue access of an accumulator

@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
 // attention_pwg.hip: one wave per SIMD, hand-placed instruction stream (long sequences, pre-scaled Q, transposed Vt, Lk % 64 == 0)
 void m324_attn_pwg_launch(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B, int H, int Lq, int Lk,
-                          float* lse, hipStream_t s);
+                          float* lse, bool bounded, hipStream_t s);
 static bool use_pwg(bool prescaled, bool vrow, bool nq2, int fnw, int Lq, int Lk) {
     return m324::tunable(m324::TUN_ATTN_PWG) != 0 && prescaled && !vrow && !nq2 && fnw == 0 && Lq >= 2048 && Lk >= 512 && Lk % 64 == 0;
 }
@@ -836,6 +836,7 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
     dim3 grid(ceil_div(Lq, QB), H, B);
     hipStream_t s = (hipStream_t)stream;
     const bool vrow = (q_prescaled & M324_ATTN_V_ROWMAJOR) != 0;
+    const bool bounded = (q_prescaled & M324_ATTN_SCORES_BOUNDED) != 0;
     q_prescaled &= M324_ATTN_Q_PRESCALED;
     M324_REQUIRE(!vrow || dtype == M324_BF16, "m324_attention: row-major V needs the bf16 kernel (transposing LDS reads)");
     const float sl = q_prescaled ? 1.0f : scale * LOG2E;
@@ -849,7 +850,7 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
         if (use_pwg(q_prescaled != 0, vrow, nq2, fnw, Lq, Lk)) {        // M324_ATTN_PWG=0: the eight-wave kernel below (A/B runs, tests)
             M324_REQUIRE((long)ceil_div(Lq, 256) * H * B < (1l << 31), "m324_attention: grid too large");
-            m324_attn_pwg_launch(Q, q_bstride, K, Vt, O, ldo, B, H, Lq, Lk, lse, s);
+            m324_attn_pwg_launch(Q, q_bstride, K, Vt, O, ldo, B, H, Lq, Lk, lse, bounded, s);
             M324_CHECK_LAUNCH("m324_attention");
             return M324_OK;
         }
@@ -912,7 +913,8 @@ extern "C" int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int 
     const int fnw = m324::tunable(m324::TUN_ATTN_NW);
     const bool w8 = !nq2 && (fnw ? fnw == 8 : (Lq >= 2048 && Lk >= 512));
     if (use_pwg(ps, vrow, nq2, fnw, Lq, Lk)) {
-        snprintf(buf, (size_t)n, "attn_pwg_kernel grid=%ldx1x1", (long)ceil_div(Lq, 256) * H * B * 256);
+        snprintf(buf, (size_t)n, "%s grid=%ldx1x1", (flags & M324_ATTN_SCORES_BOUNDED) ? "attn_pwg_bounded_kernel" : "attn_pwg_kernel",
+                 (long)ceil_div(Lq, 256) * H * B * 256);
         return 4;
     }
     const long gx = ceil_div(Lq, (nq2 || w8) ? 2 * QB : QB);

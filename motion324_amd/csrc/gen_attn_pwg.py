@@ -93,6 +93,9 @@ def regs(prefix, base, n):
 
 def mfma_s(x, n, kb, ks):
     d = S(x, n, kb)
+    if ks == 0 and OPT["bounded"]:        # no reference maximum: the tile's first MFMA starts from the inline constant 0
+        return I(f"v_mfma_f32_32x32x16_bf16 {v(d, 16)}, {a(KF(kb, ks), 4)}, {a(QF(n, ks), 4)}, 0", "mfma",
+                 rd=regs("a", KF(kb, ks), 4) + regs("a", QF(n, ks), 4), wr=regs("v", d, 16))
     c = MR(n) if ks == 0 else d
     return I(f"v_mfma_f32_32x32x16_bf16 {v(d, 16)}, {a(KF(kb, ks), 4)}, {a(QF(n, ks), 4)}, {v(c, 16)}", "mfma",
              rd=regs("a", KF(kb, ks), 4) + regs("a", QF(n, ks), 4) + regs("v", c, 16), wr=regs("v", d, 16))
@@ -144,7 +147,7 @@ def ds_read(dst_a, addr_v, off):
 
 
 # ------------------------------------------------------------------------------------------------ filler streams
-OPT = {"lsum_mfma": False, "trace": False, "noexp": False, "nomax": False, "nobarrier": False, "nodma": False, "nofill": False, "lookahead": 1}
+OPT = {"bounded": False, "lsum_mfma": False, "trace": False, "noexp": False, "nomax": False, "nobarrier": False, "nodma": False, "nofill": False, "lookahead": 1}
 
 
 def stream_exp(x):
@@ -180,6 +183,8 @@ def stream_exp(x):
 def stream_max(y):
     """per-lane maximum of the lane's 32 scores of each query block of S set y: four interleaved v_max3 chains (two per
     block, one per key half), joined at the end -- a chain's next link is four instructions away."""
+    if OPT["bounded"]:
+        return []
     if OPT["nomax"]:
         return [valu(f"v_mov_b32_e32 {v(MX + n)}, 0", [], [f"v{MX + n}"]) for n in range(2)]
     out = []
@@ -398,7 +403,7 @@ def body(x, y, tag):
         return top + stream_vreads() + m_s + [I("s_waitcnt lgkmcnt(0)", "wait")] + m_pv + stream_kreads() + stream_addr() + stream_addr_k() + stream_dma()
     # 32 MFMA gaps: 16 (S) + 16 (P.V).  The exponentials run evenly through gaps 0 .. 27.3: fragment j of both query blocks is
     # then complete before MFMA 16 + 4 j (checked below); the maxima of S(t+1) fill the last gaps.  (lsum_mfma: 40 gaps.)
-    e_end, g_end = (33.3, 39.95) if OPT["lsum_mfma"] else (27.3, 31.95)
+    e_end, g_end = (33.3, 39.95) if OPT["lsum_mfma"] else ((26.9, 31.95) if OPT["bounded"] else (27.3, 31.95))
     tim = spread(stream_exp(x), 0.0, e_end)
     tim += spread(stream_vreads(), 0.0, 8.0)
     tim += spread(stream_dma(), 4.0, 9.0)
@@ -472,8 +477,9 @@ def prologue():
     for ks in range(4):
         L.append(valu(f"v_add_u32_e32 {v(AK + ks)}, 0x8000, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]))
     L += [nop(16)]
-    L += stream_max("A")
-    L += slow_path("A", True, "p")
+    if not OPT["bounded"]:
+        L += stream_max("A")
+        L += slow_path("A", True, "p")
     if OPT["trace"]:
         L += [I("s_memtime s[64:65]", "salu"), I("s_waitcnt lgkmcnt(0)", "wait")] + [salu(f"s_mov_b32 s{i}, s64") for i in (66, 68, 70, 72, 74)]
     return L
@@ -542,7 +548,7 @@ def program():
             check(b + bodies[y] + b, f"body {x}")      # wrap-around distances through the partner body
             check_order(b, f"body {x}")
         P += b
-        if not OPT["nomax"]:
+        if not (OPT["nomax"] or OPT["bounded"]):
             P += vote(x)                                # rare: L_move_x (behind the loop) moves the reference, returns to L_calm_x
         P.append(I(f"L_calm_{x}%=:", "label"))
         P += [salu("s_add_u32 s50, s50, 1"), salu("s_cmp_eq_u32 s50, s51"), I(f"s_cbranch_scc1 L_tail_{y}%=", "branch")]
@@ -556,6 +562,8 @@ def program():
         P += t
         P.append(I("s_branch L_epilogue%=", "branch"))
     for x, y in (("A", "B"), ("B", "A")):
+        if OPT["bounded"]:
+            break
         P.append(I(f"L_move_{x}%=:", "label"))
         P += slow_path(y, False, x)
         P.append(I(f"s_branch L_calm_{x}%=", "branch"))
@@ -578,6 +586,9 @@ def write(name, P):
 
 def main():
     write("attn_pwg_asm.inc", program())
+    OPT["bounded"] = True          # M324_ATTN_SCORES_BOUNDED: the caller vouches for |score| <= 64 (log2 domain): no maxima, no
+    write("attn_pwg_bounded_asm.inc", program())       # reference, no vote, C = 0 -- the softmax is exp2 + add + pack
+    OPT["bounded"] = False
     with open(os.path.join(HERE, "attn_pwg_clobbers.inc"), "w") as f:
         f.write("// GENERATED by gen_attn_pwg.py: registers the asm statement of attn_pwg_kernel owns.\n")
         names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 196)] + [f"s{i}" for i in range(50, 64)]

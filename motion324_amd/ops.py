@@ -352,9 +352,10 @@ def qkv_split(q_src, k_src, v_src, q_w, k_w, eps: float, B: int, Lq: int, H: int
 
 def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Tensor, *, shared_q: bool = False,
               scale: Optional[float] = None, prescaled: bool = False, lse: Optional[torch.Tensor] = None,
-              v_rowmajor: bool = False) -> torch.Tensor:
+              v_rowmajor: bool = False, bounded: bool = False) -> torch.Tensor:
     """out[B*Lq, H*64] = softmax(Q K^T scale) V.  Q[Bq,H,Lq,64] (Bq == 1 with shared_q), K[B,H,Lk,64],
-    Vt[B,H,64,Lkp] -- or, with v_rowmajor (bf16 only), V[B,H,Lk,64].  prescaled: Q carries Q_PRESCALE."""
+    Vt[B,H,64,Lkp] -- or, with v_rowmajor (bf16 only), V[B,H,Lk,64].  prescaled: Q carries Q_PRESCALE.
+    bounded: the caller vouches for |log2-domain score| <= 64 (M324_ATTN_SCORES_BOUNDED; see qk_score_bound)."""
     B, H, Lk, D = K.shape
     Lq = Q.shape[2]
     vshape = (B, H, Lk, 64) if v_rowmajor else (B, H, 64, (Lk + 63) // 64 * 64)
@@ -374,10 +375,10 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     esz = Q.element_size()
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
               esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq),
-              f"{_attn_plan(B, H, Lq, Lk, int(prescaled) | (2 if v_rowmajor else 0), code_of(Q.dtype))} | B={B} H={H} Lq={Lq} Lk={Lk}"
+              f"{_attn_plan(B, H, Lq, Lk, int(prescaled) | (2 if v_rowmajor else 0) | (4 if bounded else 0), code_of(Q.dtype))} | B={B} H={H} Lq={Lq} Lk={Lk}"
               if _timing() else ""):
         L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale,
-                                        int(prescaled) | (2 if v_rowmajor else 0), _p(lse), code_of(Q.dtype), _stream()),
+                                        int(prescaled) | (2 if v_rowmajor else 0) | (4 if bounded else 0), _p(lse), code_of(Q.dtype), _stream()),
                 "m324_attention")
     return out
 

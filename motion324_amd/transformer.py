@@ -76,6 +76,18 @@ class _AttnBase(nn.Module):
             return None, None
         return P.vec(self.q_norm.weight), P.vec(self.k_norm.weight)
 
+    def scores_bounded(self, P: Prepared) -> bool:
+        """May m324_attention run without a reference maximum (M324_ATTN_SCORES_BOUNDED)?  The per-head RMSNorm of q and k
+        (reference transformer.py:36-42,200-207) bounds every log2-domain score: a normalised 64-vector has norm <= 8, so
+        |q^ . k^| scale log2(e) <= 64 max|w_q| max|w_k| * 0.18 = 11.5 at unit norm weights.  Vouched for only with a margin
+        (<= 48 of the kernel's 64; fp32 sums of 2^48 x 10^5 keys are far inside range), from the CURRENT weights (cached per
+        weight version: one device read at preparation, none per call); ATTN_BOUNDED = False (M324_ATTN_BOUNDED=0) never vouches."""
+        if not (ATTN_BOUNDED and not _FUSE_OFF and self.use_qk_norm and P.dtype == torch.bfloat16):
+            return False
+        t = P.derived("qk_score_bound", (self.q_norm.weight, self.k_norm.weight), lambda: torch.tensor(
+            [64.0 * ops.Q_PRESCALE * float(self.q_norm.weight.detach().abs().max()) * float(self.k_norm.weight.detach().abs().max())]))
+        return float(t[0]) <= 48.0
+
 
 class QK_Norm_SelfAttention(_AttnBase):
     def __init__(self, dim, head_dim, qkv_bias=False, fc_bias=True, attn_dropout=0.0, fc_dropout=0.0, use_qk_norm=True):
@@ -113,6 +125,7 @@ class QK_Norm_CrossAttention(_AttnBase):
 #     boundary: break-even within +-0.5 % of the clip.  OFF by default; M324_FOLD_LN=2 folds them too (tests do).
 # M324_FOLD_LN=0 restores every separate pass.
 FOLD_LN = int(switches.get("M324_FOLD_LN"))
+ATTN_BOUNDED = switches.flag("M324_ATTN_BOUNDED")
 
 
 class LNFold:
@@ -250,7 +263,7 @@ class QK_Norm_TransformerBlock(nn.Module):
             V = torch.empty((B, a.num_heads, 64, L) if long_seq else (B, a.num_heads, L, 64), dtype=P.dtype, device=x.device)
             ops.gemm(src, w, None, bias=bias, qkv_heads=(Q, K, V, qw, kw, RMS_EPS, ops.Q_PRESCALE, L, a.num_heads),
                      **lnk(0, 3 * C))
-            ops.attention(Q, K, V, h, prescaled=True, v_rowmajor=not long_seq)
+            ops.attention(Q, K, V, h, prescaled=True, v_rowmajor=not long_seq, bounded=long_seq and a.scores_bounded(P))
             ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x, **out_kw())
             return _mlp_residual(P, self.norm2, self.mlp, x, fold, feed_next)
         if kv_gather is None:
@@ -269,7 +282,7 @@ class QK_Norm_TransformerBlock(nn.Module):
             kv_full, L_full = kv_gather.finish()
             _, K, Vt = ops.qkv_split(None, kv_full[:, :C], kv_full[:, C:], None, kw, RMS_EPS, B, L_full, a.num_heads,
                                      P.dtype)
-        ops.attention(Q, K, Vt, h, prescaled=True)                                       # h reused as the attention output
+        ops.attention(Q, K, Vt, h, prescaled=True, bounded=a.scores_bounded(P))          # h reused as the attention output
         ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x, **out_kw())
         return _mlp_residual(P, self.norm2, self.mlp, x, fold, feed_next)
 

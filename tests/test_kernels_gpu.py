@@ -702,6 +702,35 @@ def test_attention_one_wave_per_simd_stream(tune, B, H, Lq, Lk, spike):
     assert rel_err(out, res["0"][0]) < 6e-3                       # same mathematics, different summation order
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,amp", [(1, 2, 2048, 512, 1.5), (1, 2, 2100, 2048, 1.5), (2, 3, 2049, 576, 2.2), (1, 1, 4096, 64 * 37, 1.0)])
+def test_attention_bounded_scores_stream(tune, B, H, Lq, Lk, amp):
+    """M324_ATTN_SCORES_BOUNDED: the long-sequence kernel without a reference maximum (exp2, sum, pack only).  Same softmax as the
+    lazy-maximum stream and as fp64 attention for scores inside the vouched range -- here up to |s| ~ 40 in the log2 domain
+    (amp 2.2) -- and the same log2-domain LSE."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    assert "attn_pwg_bounded_kernel" in ops._attn_plan(B, H, Lq, Lk, 1 | 4, ops.code_of(dtype))
+    q, k, v = (_rand((B, H, L, 64), s_, amp) for L, s_ in ((Lq, 181), (Lk, 182), (Lk, 183)))
+    k, v = _q(k, dtype), _q(v, dtype)
+    qs = _q(q * ops.Q_PRESCALE, dtype)
+    sc = torch.einsum("bhqd,bhkd->bhqk", qs.double(), k.double())                          # log2-domain scores
+    assert float(sc.abs().max()) < 60.0
+    dq, dk, dvt = qs.to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV)
+    res = {}
+    for bounded in (True, False):
+        out = torch.full((B * Lq, H * 64), float("nan"), dtype=dtype, device=DEV)
+        lse = torch.full((B, H, Lq), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(dq, dk, dvt, out, prescaled=True, lse=lse, bounded=bounded)
+        res[bounded] = (out.float().cpu(), lse.cpu())
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc * math.log(2.0), dim=-1), v.double()).reshape(B * Lq, H * 64)
+    lse_ref = torch.logsumexp(sc * math.log(2.0), dim=-1) / math.log(2.0)
+    out, lse = res[True]
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 8e-3
+    assert float((lse.double() - lse_ref).abs().max()) < 2e-2
+    assert rel_err(out, res[False][0]) < 6e-3
+
+
 def test_attention_one_wave_per_simd_nan_propagates():
     """a NaN key poisons every row of its (batch, head) in the long-sequence kernel too, and only those"""
     ops = _ops()

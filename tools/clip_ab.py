@@ -26,10 +26,25 @@ model, _ = bench.build_model(dev, args.frames)
 m.set_precision("bf16")
 s = synth.synth_inputs(1, args.frames, 2048, 4096, 512, seed=1)
 sample = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+HOST = {"M324_ATTN_BOUNDED": ("motion324_amd.transformer", "ATTN_BOUNDED"), "M324_FOLD_LN": ("motion324_amd.transformer", "FOLD_LN"),
+        "M324_BF16_DECODER": ("motion324_amd.Pcd_motion", "BF16_DECODER_STREAM"), "M324_FUSE_HEAD": ("motion324_amd.Pcd_motion", "FUSE_HEAD_N3")}
+
+
+def set_switch(k, v):
+    if k in HOST:                      # host switches are module constants read at capture time
+        import importlib
+        mod, attr = HOST[k]
+        setattr(importlib.import_module(mod), attr, v)
+    elif v is None:
+        lib.set_tunable(k)
+    else:
+        lib.set_tunable(k, v)
+
+
 arms = {}
 for combo in itertools.product(*values):
     for k, v in zip(names, combo):
-        lib.set_tunable(k, v)
+        set_switch(k, v)
     fast = m.GraphedForward(model)
     with torch.no_grad():
         clip = fast.static_inputs(sample)
@@ -37,7 +52,8 @@ for combo in itertools.product(*values):
             out = fast(clip).pcd_moved.clone()
     arms[combo] = (fast, clip, out)
 for k in names:
-    lib.set_tunable(k)
+    if k not in HOST:
+        set_switch(k, None)
 base = arms[next(iter(arms))][2]
 res = {c: [] for c in arms}
 for rnd in range(args.rounds):
