@@ -17,7 +17,7 @@ Register map (explicit; the asm statement clobbers them):
   v32-35 kbase[ks]   v36-39 aK[ks]   v40-43 aV[j]   v44-47 l[n][2]   v48-49 mx[n]   v50-51 m_ref[n]   v52-59 T0-T7   v60 floor
   v64-127 SA[n][kb]  v128-191 SB[n][kb]  v192-223 PF[n][j] (bf16 P^T fragments)  v224-255 MR[n] (= -m_ref, the C operand)
   a0-63 O[n][db]     a64-95 QF[n][ks]    a96-127 KF[kb][ks]   a128-159 VF[db][j]
-  s50 t  s51 nt-1  s52 K soff of the tile being issued  s53 V soff  s54 tile index being issued  s55-63 scratch
+  s50 t  s51 nt-1  s52 K soff of the tile being issued  s53 V soff  s56-59 scratch  s58 loop body of a vote
 """
 from __future__ import annotations
 
@@ -202,45 +202,34 @@ def stream_max(y):
     return out
 
 
-def stream_vreads():
-    return [ds_read(VF(db, j), AV + j, 8192 + db * 4096) for j in range(4) for db in range(2)]
+def stream_vreads(stage=None):
+    """Vt fragments of tile t.  stage = t & 3 known at generation time (the loop body is emitted once per ring stage): the
+    stage offset is an immediate on the lane's base address; stage None (the tails): address registers aV."""
+    if stage is None:
+        return [ds_read(VF(db, j), AV + j, 8192 + db * 4096) for j in range(4) for db in range(2)]
+    return [ds_read(VF(db, j), KBASE + j, stage * 16384 + 8192 + db * 4096) for j in range(4) for db in range(2)]
 
 
-def stream_kreads():
-    return [ds_read(KF(kb, ks), AK + ks, kb * 4096) for ks in range(4) for kb in range(2)]
+def stream_kreads(stage):
+    """K fragments of the tile in ring stage `stage`"""
+    return [ds_read(KF(kb, ks), KBASE + ks, stage * 16384 + kb * 4096) for ks in range(4) for kb in range(2)]
 
 
-def stream_dma(force=False):
-    """LDS-DMA of tile s54 (= t + 3) into ring stage s54 & 3: two K pieces, two Vt pieces per wave.  Unconditional: tiles past
-    the end read out of range (zeros, no memory traffic) into a stage nobody reads."""
+def stream_dma(stage, force=False):
+    """LDS-DMA of the next tile to issue into ring stage `stage` (an immediate): two K pieces, two Vt pieces per wave.
+    Unconditional: tiles past the end read out of range (zeros, no memory traffic) into a stage nobody reads."""
     if OPT["nodma"] and not force:
         return []
-    out = [
-        salu("s_and_b32 s55, s54, 3"),
-        salu("s_lshl_b32 s55, s55, 14"),
-        salu("s_add_u32 s55, s55, %[wlds]"),          # LDS byte address of this wave's K pieces in that stage
-    ]
+    out = []
     pieces = [("%[vk0]", "%[rk]", "s52", 0), ("%[vk1]", "%[rk]", "s52", 1024), ("%[vv0]", "%[rv]", "s53", 8192), ("%[vv1]", "%[rv]", "s53", 9216)]
     for voff, rs, soff, lo in pieces:
-        out.append(salu(f"s_add_u32 m0, s55, {lo}"))
-        out.append(nop(1))                    # M0 write -> LDS-DMA: one wait state
+        out.append(salu(f"s_add_u32 m0, %[wlds], {stage * 16384 + lo}"))
+        if force:
+            out.append(nop(1))                # M0 write -> LDS-DMA: one wait state (in the loop another stream's instruction
+                                              # sits between the two; fix_m0() pads where none does)
         out.append(I(f"buffer_load_dwordx4 {voff}, {rs}, {soff} offen lds", "vmem"))
-    out += [salu("s_add_u32 s52, s52, 0x2000"), salu("s_add_u32 s53, s53, 0x80"), salu("s_add_u32 s54, s54, 1")]
+    out += [salu("s_add_u32 s52, s52, 0x2000"), salu("s_add_u32 s53, s53, 0x80")]
     return out
-
-
-def stream_addr():
-    """fragment read addresses of the next iteration: aV -> stage of tile t + 1, aK -> stage of tile t + 3 (s50 = t here)."""
-    out = [salu("s_add_u32 s56, s50, 1"), salu("s_and_b32 s56, s56, 3"), salu("s_lshl_b32 s56, s56, 14"),
-           salu("s_add_u32 s57, s50, 3"), salu("s_and_b32 s57, s57, 3"), salu("s_lshl_b32 s57, s57, 14")]
-    for j in range(4):
-        out.append(valu(f"v_add_u32_e32 {v(AV + j)}, s56, {v(KBASE + j)}", [f"v{KBASE + j}"], [f"v{AV + j}"]))
-    return out
-
-
-def stream_addr_k():
-    # must follow the K reads of this iteration (they use aK of tile t + 2)
-    return [valu(f"v_add_u32_e32 {v(AK + ks)}, s57, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]) for ks in range(4)]
 
 
 COST = {"valu": 1.0, "trans": 2.0, "ds": 1.0, "vmem": 1.0, "salu": 0.7, "nop": 0.3, "wait": 0.3}
@@ -303,6 +292,16 @@ def check_order(seq, what):
 
 
 # ------------------------------------------------------------------------------------------------ body
+def fix_m0(seq):
+    """an LDS-DMA must not directly follow the SALU write of M0 it depends on (one wait state)"""
+    out = []
+    for ins in seq:
+        if ins.kind == "vmem" and " lds" in ins.text and out and out[-1].kind == "salu" and " m0," in out[-1].text:
+            out.append(nop(1))
+        out.append(ins)
+    return out
+
+
 def interleave(mfmas, timed):
     """mfmas: list of I; timed: list of (target gap, I).  A filler with target g is emitted after MFMA floor(g); the streams keep
     their internal order (stable sort)."""
@@ -356,12 +355,13 @@ def slow_path(y, first, tag):
     return L
 
 
-def vote(tag):
+def vote(k, y):
     return [valu(f"v_max_f32_e32 {v(T)}, {v(MX)}, {v(MX + 1)}", [f"v{MX}", f"v{MX + 1}"], [f"v{T}"]),
             I(f"v_cmp_nge_f32_e32 vcc, {THR}, {v(T)}", "valu", [f"v{T}"], []),        # !(8 >= max): above the threshold, or NaN
+            salu(f"s_mov_b32 s58, {k}"),
             nop(2),
             salu("s_and_b64 vcc, exec, vcc"),
-            I(f"s_cbranch_vccnz L_move_{tag}%=", "branch")]
+            I(f"s_cbranch_vccnz L_move_{y}%=", "branch")]
 
 
 def stamp(k):
@@ -386,8 +386,9 @@ def split_after_fragment(ex, j):
     return last + 1
 
 
-def body(x, y, tag):
-    """one tile: S(t+1) -> set y, softmax of set x (tile t), O += Vt(t) P(t), fragment reads for the next tile, LDS-DMA of t + 3."""
+def body(x, y, stage):
+    """one tile t (t & 3 = stage): S(t+1) -> set y, softmax of set x (tile t), O += Vt(t) P(t), K fragments of tile t + 2,
+    LDS-DMA of tile t + 3.  Every ring-stage offset is an immediate: the loop is emitted four times."""
     # lab stamps: 0 top, 1 LDS-DMA / fragment reads retired, 2 barrier passed, 3 first P.V MFMA, 4 end of the stream; s74:75 =
     # the previous tile's stamp 0, so that s84 accumulates whole tile periods
     top = stamp(0) + [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait")]
@@ -399,19 +400,18 @@ def body(x, y, tag):
     top += stamp(2)
     m_s = [mfma_s(y, n, kb, ks) for ks in range(4) for kb in range(2) for n in range(2)]
     m_pv = pv_block()
+    kst, dst = (stage + 2) & 3, (stage + 3) & 3
     if OPT["nofill"]:
-        return top + stream_vreads() + m_s + [I("s_waitcnt lgkmcnt(0)", "wait")] + m_pv + stream_kreads() + stream_addr() + stream_addr_k() + stream_dma()
+        return top + stream_vreads(stage) + m_s + [I("s_waitcnt lgkmcnt(0)", "wait")] + m_pv + stream_kreads(kst) + fix_m0(stream_dma(dst))
     # 32 MFMA gaps: 16 (S) + 16 (P.V).  The exponentials run evenly through gaps 0 .. 27.3: fragment j of both query blocks is
     # then complete before MFMA 16 + 4 j (checked below); the maxima of S(t+1) fill the last gaps.  (lsum_mfma: 40 gaps.)
     e_end, g_end = (33.3, 39.95) if OPT["lsum_mfma"] else ((26.9, 31.95) if OPT["bounded"] else (27.3, 31.95))
     tim = spread(stream_exp(x), 0.0, e_end)
-    tim += spread(stream_vreads(), 0.0, 8.0)
-    tim += spread(stream_dma(), 4.0, 9.0)
-    tim += spread(stream_addr(), 13.0, 15.9)
-    tim += spread(stream_kreads(), 16.0, 24.0)
-    tim += spread(stream_addr_k(), 24.5, 27.0)
+    tim += spread(stream_vreads(stage), 0.0, 8.0)
+    tim += spread(stream_dma(dst), 4.0, 9.0)
+    tim += spread(stream_kreads(kst), 16.0, 24.0)
     tim += spread(stream_max(y), e_end + 0.1, g_end)
-    seq = interleave(m_s + m_pv, tim)
+    seq = fix_m0(interleave(m_s + m_pv, tim))
     # the first P.V MFMA needs the Vt fragments: they were requested in gaps 0-7
     idx = next(i for i, ins in enumerate(seq) if ins is m_pv[0])
     seq.insert(idx, I("s_waitcnt lgkmcnt(0)", "wait"))
@@ -422,7 +422,9 @@ def body(x, y, tag):
 
 def tail(x, tag):
     """last tile: no S(t+1); the softmax of set x has no MFMAs to hide under until the P.V phase."""
-    top = [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait")]
+    top = [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait"), salu("s_and_b32 s56, s50, 3"), salu("s_lshl_b32 s56, s56, 14")]
+    for j in range(4):                     # once per workgroup: the stage of the last tile as an address register
+        top.append(valu(f"v_add_u32_e32 {v(AV + j)}, s56, {v(KBASE + j)}", [f"v{KBASE + j}"], [f"v{AV + j}"]))
     ex = stream_exp(x)
     m_pv = pv_block()
     c0, c1, c2 = (split_after_fragment(ex, j) for j in range(3))
@@ -443,10 +445,9 @@ def prologue():
     # ring: tiles 0, 1, 2 (s54 counts the tile being issued)
     if OPT["trace"]:
         L += [salu(f"s_mov_b32 s{i}, 0") for i in range(64, 86)]
-    L += [salu("s_mov_b32 s52, 0"), salu("s_mov_b32 s53, 0"), salu("s_mov_b32 s54, 0"), salu("s_mov_b32 s50, 0"),
-          salu("s_sub_u32 s51, %[nt], 1")]
-    for _ in range(3):
-        L += stream_dma(force=True)
+    L += [salu("s_mov_b32 s52, 0"), salu("s_mov_b32 s53, 0"), salu("s_mov_b32 s50, 0"), salu("s_sub_u32 s51, %[nt], 1")]
+    for st in range(3):
+        L += stream_dma(st, force=True)
     for i in range(64):
         L.append(I(f"v_accvgpr_write_b32 {a(O0 + i)}, 0", "valu"))
     for i in range(32):
@@ -462,20 +463,13 @@ def prologue():
     for n in range(2):
         L.append(valu(f"v_mov_b32_e32 {v(MREF + n)}, 0", [], [f"v{MREF + n}"]))
     # tile 0: K fragments straight after it has landed (Q: 8 loads, tile 0: 4 pieces; tiles 1, 2 may still fly)
-    for ks in range(4):
-        L.append(valu(f"v_mov_b32_e32 {v(AK + ks)}, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]))
-        L.append(valu(f"v_mov_b32_e32 {v(AV + ks)}, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AV + ks}"]))
     L += [I("s_waitcnt vmcnt(8)", "wait"), I("s_barrier", "barrier")]
-    L += stream_kreads()
+    L += stream_kreads(0)
     L += [I("s_waitcnt lgkmcnt(0)", "wait")]
     L += [mfma_s("A", n, kb, ks) for ks in range(4) for kb in range(2) for n in range(2)]
     # K fragments of tile 1 (stage 1)
-    for ks in range(4):
-        L.append(valu(f"v_add_u32_e32 {v(AK + ks)}, 0x4000, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]))
     L += [I("s_waitcnt vmcnt(4)", "wait"), I("s_barrier", "barrier")]
-    L += stream_kreads()
-    for ks in range(4):
-        L.append(valu(f"v_add_u32_e32 {v(AK + ks)}, 0x8000, {v(KBASE + ks)}", [f"v{KBASE + ks}"], [f"v{AK + ks}"]))
+    L += stream_kreads(1)
     L += [nop(16)]
     if not OPT["bounded"]:
         L += stream_max("A")
@@ -540,20 +534,21 @@ def program():
     P = []
     P += prologue()
     P += [salu("s_cmp_eq_u32 s51, 0"), I("s_cbranch_scc1 L_tail_A%=", "branch")]
-    bodies = {x: body(x, y, x) for x, y in (("A", "B"), ("B", "A"))}
-    for x, y in (("A", "B"), ("B", "A")):
-        P.append(I(f"L_body_{x}%=:", "label"))
-        b = bodies[x]
-        if not OPT["nofill"]:
-            check(b + bodies[y] + b, f"body {x}")      # wrap-around distances through the partner body
-            check_order(b, f"body {x}")
-        P += b
-        if not (OPT["nomax"] or OPT["bounded"]):
-            P += vote(x)                                # rare: L_move_x (behind the loop) moves the reference, returns to L_calm_x
-        P.append(I(f"L_calm_{x}%=:", "label"))
+    lazy = not (OPT["nomax"] or OPT["bounded"])
+    sets = [("A", "B"), ("B", "A"), ("A", "B"), ("B", "A")]          # tile t: stage t & 3, S set of tile t = sets[t & 3][0]
+    bodies = [body(x, y, k) for k, (x, y) in enumerate(sets)]
+    if not OPT["nofill"]:
+        check(bodies[0] + bodies[1] + bodies[2] + bodies[3] + bodies[0], "loop")      # hazard distances across the seams
+        for k in range(4):
+            check_order(bodies[k], f"body {k}")
+    for k, (x, y) in enumerate(sets):
+        P.append(I(f"L_body_{k}%=:", "label"))
+        P += bodies[k]
+        if lazy:        # rare: L_move_y (behind the loop) moves the reference of set y and returns to L_calm_k (s58 = k)
+            P += vote(k, y)
+        P.append(I(f"L_calm_{k}%=:", "label"))
         P += [salu("s_add_u32 s50, s50, 1"), salu("s_cmp_eq_u32 s50, s51"), I(f"s_cbranch_scc1 L_tail_{y}%=", "branch")]
-        if x == "B":
-            P.append(I("s_branch L_body_A%=", "branch"))
+    P.append(I("s_branch L_body_0%=", "branch"))
     for x in ("A", "B"):
         P.append(I(f"L_tail_{x}%=:", "label"))
         t = tail(x, x)
@@ -561,12 +556,11 @@ def program():
         check_order(t, f"tail {x}")
         P += t
         P.append(I("s_branch L_epilogue%=", "branch"))
-    for x, y in (("A", "B"), ("B", "A")):
-        if OPT["bounded"]:
-            break
-        P.append(I(f"L_move_{x}%=:", "label"))
-        P += slow_path(y, False, x)
-        P.append(I(f"s_branch L_calm_{x}%=", "branch"))
+    if lazy:
+        for y, ks in (("B", (0, 2)), ("A", (1, 3))):
+            P.append(I(f"L_move_{y}%=:", "label"))
+            P += slow_path(y, False, y)
+            P += [salu(f"s_cmp_eq_u32 s58, {ks[0]}"), I(f"s_cbranch_scc1 L_calm_{ks[0]}%=", "branch"), I(f"s_branch L_calm_{ks[1]}%=", "branch")]
     P.append(I("L_epilogue%=:", "label"))
     P += epilogue()
     return P

@@ -112,9 +112,14 @@ if args.time:
         return e0.elapsed_time(e1) / iters * 1e3
 
     fl = 4.0 * B * H * L * L * 64
+
+    def tb(iters=20):
+        lib.set_tunable("M324_ATTN_PWG", 1)
+        return _t(lambda: ops.attention(q, k, vt, out, prescaled=True, bounded=True), iters)
+
     for rnd in range(4):
-        a, b = t(1), t(0)
-        print(f"round {rnd}: pwg {a:.1f} us = {fl / a / 1e6:.0f} TF/s   8-wave {b:.1f} us = {fl / b / 1e6:.0f} TF/s", flush=True)
+        a, b, c = t(1), t(0), tb()
+        print(f"round {rnd}: pwg {a:.1f} us = {fl / a / 1e6:.0f} TF/s   bounded {c:.1f} us = {fl / c / 1e6:.0f} TF/s   8-wave {b:.1f} us = {fl / b / 1e6:.0f} TF/s", flush=True)
     if args.ablate:
         names = {1: "product", 11: "no exp (v_mov)", 12: "no max / vote", 13: "no barrier", 14: "no LDS-DMA in the loop", 15: "MFMAs + reads only",
                  16: "exp lookahead 2", 17: "exp lookahead 3", 19: "row sums by MFMA", 0: "8-wave kernel"}
