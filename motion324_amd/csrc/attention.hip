@@ -819,11 +819,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
 }  // namespace
 
-// attention_pwg.hip: one wave per SIMD, hand-placed instruction stream (long sequences, pre-scaled Q, transposed Vt, Lk % 64 == 0)
+// attention_pwg.hip: one wave per SIMD, hand-placed instruction stream (long sequences, pre-scaled Q, transposed zero-padded Vt)
 void m324_attn_pwg_launch(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B, int H, int Lq, int Lk,
                           float* lse, bool bounded, hipStream_t s);
 static bool use_pwg(bool prescaled, bool vrow, bool nq2, int fnw, int Lq, int Lk) {
-    return m324::tunable(m324::TUN_ATTN_PWG) != 0 && prescaled && !vrow && !nq2 && fnw == 0 && Lq >= 2048 && Lk >= 512 && Lk % 64 == 0;
+    return m324::tunable(m324::TUN_ATTN_PWG) != 0 && prescaled && !vrow && !nq2 && fnw == 0 && Lq >= 2048 && Lk >= 512;
 }
 
 extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B,

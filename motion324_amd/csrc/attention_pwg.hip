@@ -1,5 +1,5 @@
 // attn_pwg_kernel: the long-sequence attention forward of m324_attention (bf16, head_dim 64, pre-scaled Q, transposed
-// key-permuted Vt, Lk % 64 == 0) as ONE wave per SIMD with a hand-placed instruction stream.
+// key-permuted Vt) as ONE wave per SIMD with a hand-placed instruction stream.
 //
 // Round 4 measurement behind it (tools/issue_lab.cpp): on gfx950 a wave's plain VALU instructions issue in the shadow of its
 // OWN MFMAs when they sit between them in program order -- MFMA + 4 v_fma_f32 = 33.5 cycles per MFMA, + 4 plain + 2 v_exp_f32

@@ -380,6 +380,25 @@ def stamp_sums():
     return out
 
 
+def mask_tail_keys(x, tag):
+    """Ragged key count: the last tile holds %[rem] valid keys (1..63; 0 = the tile is whole and this block is skipped).  Its
+    surplus keys were staged as zero rows (the K descriptor ends at Lk) and score -m_ref: they become -inf before maxima /
+    exponentials see them.  Key of register r of block kb in lane half hi: kb * 32 + (r & 3) + 8 (r >> 2) + 4 hi (%[hi4] = 4 hi)."""
+    L = [salu("s_cmp_eq_u32 %[rem], 0"), I(f"s_cbranch_scc1 L_whole_{tag}%=", "branch"),
+         valu(f"v_mov_b32_e32 {v(T + 5)}, 0xff800000", [], [f"v{T + 5}"])]
+    for kb in range(2):
+        for r in range(16):
+            c = kb * 32 + (r & 3) + 8 * (r >> 2)
+            L += [salu(f"s_sub_i32 s59, %[rem], {c}"),
+                  I(f"v_cmp_le_i32_e32 vcc, s59, %[hi4]", "valu"),           # rem - c <= 4 hi  <=>  key >= rem
+                  nop(2)]
+            for n in range(2):
+                sreg = S(x, n, kb, r)
+                L.append(valu(f"v_cndmask_b32_e32 {v(sreg)}, {v(sreg)}, {v(T + 5)}, vcc", [f"v{sreg}", f"v{T + 5}"], [f"v{sreg}"]))
+    L.append(I(f"L_whole_{tag}%=:", "label"))
+    return L
+
+
 def split_after_fragment(ex, j):
     """index just behind the instruction that completes P^T fragment j of both query blocks"""
     last = max(i for i, ins in enumerate(ex) if any(f"v{PF(n, j, p)}" in ins.wr for n in range(2) for p in range(4)))
@@ -425,6 +444,8 @@ def tail(x, tag):
     top = [I("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait"), salu("s_and_b32 s56, s50, 3"), salu("s_lshl_b32 s56, s56, 14")]
     for j in range(4):                     # once per workgroup: the stage of the last tile as an address register
         top.append(valu(f"v_add_u32_e32 {v(AV + j)}, s56, {v(KBASE + j)}", [f"v{KBASE + j}"], [f"v{AV + j}"]))
+    if OPT["bounded"]:                     # no vote in front of the tail: mask here (the lazy stream masks before its last vote)
+        top += [nop(16)] + mask_tail_keys(x, f"t{tag}")
     ex = stream_exp(x)
     m_pv = pv_block()
     c0, c1, c2 = (split_after_fragment(ex, j) for j in range(3))
@@ -472,6 +493,9 @@ def prologue():
     L += stream_kreads(1)
     L += [nop(16)]
     if not OPT["bounded"]:
+        L += [salu("s_cmp_lg_u32 s51, 0"), I("s_cbranch_scc1 L_p_many%=", "branch")]     # nt == 1: tile 0 is the (possibly ragged) last one
+        L += mask_tail_keys("A", "p")
+        L.append(I("L_p_many%=:", "label"))
         L += stream_max("A")
         L += slow_path("A", True, "p")
     if OPT["trace"]:
@@ -544,11 +568,21 @@ def program():
     for k, (x, y) in enumerate(sets):
         P.append(I(f"L_body_{k}%=:", "label"))
         P += bodies[k]
+        # set y now holds S(t + 1).  If that is the last tile, its (possibly ragged) keys are masked before anything looks at them
+        P += [salu("s_add_u32 s50, s50, 1"), salu("s_cmp_eq_u32 s50, s51"),
+              I(f"s_cbranch_scc1 L_{'last' if lazy else 'tail'}_{y}%=", "branch")]
         if lazy:        # rare: L_move_y (behind the loop) moves the reference of set y and returns to L_calm_k (s58 = k)
             P += vote(k, y)
         P.append(I(f"L_calm_{k}%=:", "label"))
-        P += [salu("s_add_u32 s50, s50, 1"), salu("s_cmp_eq_u32 s50, s51"), I(f"s_cbranch_scc1 L_tail_{y}%=", "branch")]
     P.append(I("s_branch L_body_0%=", "branch"))
+    if lazy:
+        for y in ("A", "B"):
+            P.append(I(f"L_last_{y}%=:", "label"))
+            P += [salu("s_cmp_eq_u32 %[rem], 0"), I(f"s_cbranch_scc1 L_lastvote_{y}%=", "branch"), nop(16)]
+            P += mask_tail_keys(y, f"l{y}") + stream_max(y)
+            P.append(I(f"L_lastvote_{y}%=:", "label"))
+            P += vote(4, y)                              # s58 = 4: the rescale path returns to the tail
+            P.append(I(f"s_branch L_tail_{y}%=", "branch"))
     for x in ("A", "B"):
         P.append(I(f"L_tail_{x}%=:", "label"))
         t = tail(x, x)
@@ -560,7 +594,8 @@ def program():
         for y, ks in (("B", (0, 2)), ("A", (1, 3))):
             P.append(I(f"L_move_{y}%=:", "label"))
             P += slow_path(y, False, y)
-            P += [salu(f"s_cmp_eq_u32 s58, {ks[0]}"), I(f"s_cbranch_scc1 L_calm_{ks[0]}%=", "branch"), I(f"s_branch L_calm_{ks[1]}%=", "branch")]
+            P += [salu(f"s_cmp_eq_u32 s58, {ks[0]}"), I(f"s_cbranch_scc1 L_calm_{ks[0]}%=", "branch"),
+                  salu(f"s_cmp_eq_u32 s58, {ks[1]}"), I(f"s_cbranch_scc1 L_calm_{ks[1]}%=", "branch"), I(f"s_branch L_tail_{y}%=", "branch")]
     P.append(I("L_epilogue%=:", "label"))
     P += epilogue()
     return P

@@ -665,13 +665,15 @@ def test_attention_long_sequence_schedules(tune, sched, Lq, Lk, odd):
     assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-2
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 2048, 512), (1, 2, 2100, 2048), (1, 2, 2304, 1088), (2, 3, 2049, 576), (1, 1, 4096, 64 * 37)])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 2048, 512), (1, 2, 2100, 2048), (1, 2, 2304, 1088), (2, 3, 2049, 576), (1, 1, 4096, 64 * 37),
+                                       (1, 2, 2100, 2100), (1, 2, 2304, 1025), (2, 3, 2049, 639), (1, 1, 3888, 3888), (1, 2, 2048, 513)])
 @pytest.mark.parametrize("spike", [True, False])
 def test_attention_one_wave_per_simd_stream(tune, B, H, Lq, Lk, spike):
-    """attention_pwg.hip (the chooser's pick for long sequences with Lk % 64 == 0): hand-placed software pipeline over the key
-    tiles.  Even / odd / prime tile counts (8, 32, 17, 9, 37: both loop bodies and both tails), ragged query counts, batches,
-    dominant keys late and early (the lazy reference moves inside the pipeline, with P.V of the previous tile in flight), the
-    LSE -- against fp64 softmax attention, and against the eight-wave kernel (M324_ATTN_PWG=0) on the same operands."""
+    """attention_pwg.hip (the chooser's pick for long sequences): hand-placed software pipeline over the key tiles.  Tile counts
+    8, 32, 17, 9, 37, 33, 10, 61 (every loop body as the last one, both tails), ragged query counts, RAGGED KEY counts (1, 52,
+    63, 48 valid keys in the last tile: masked before the last vote), batches, dominant keys late and early (the lazy reference
+    moves inside the pipeline, with P.V of the previous tile in flight -- also in the masked last tile), the LSE -- against fp64
+    softmax attention, and against the eight-wave kernel (M324_ATTN_PWG=0) on the same operands."""
     ops = _ops()
     dtype = torch.bfloat16
     assert "attn_pwg_kernel" in ops._attn_plan(B, H, Lq, Lk, 1, ops.code_of(dtype))
@@ -702,7 +704,8 @@ def test_attention_one_wave_per_simd_stream(tune, B, H, Lq, Lk, spike):
     assert rel_err(out, res["0"][0]) < 6e-3                       # same mathematics, different summation order
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,amp", [(1, 2, 2048, 512, 1.5), (1, 2, 2100, 2048, 1.5), (2, 3, 2049, 576, 2.2), (1, 1, 4096, 64 * 37, 1.0)])
+@pytest.mark.parametrize("B,H,Lq,Lk,amp", [(1, 2, 2048, 512, 1.5), (1, 2, 2100, 2048, 1.5), (2, 3, 2049, 576, 2.2), (1, 1, 4096, 64 * 37, 1.0),
+                                           (1, 2, 2100, 2100, 1.5), (2, 3, 2049, 513, 1.5), (1, 1, 3888, 3888, 1.0)])
 def test_attention_bounded_scores_stream(tune, B, H, Lq, Lk, amp):
     """M324_ATTN_SCORES_BOUNDED: the long-sequence kernel without a reference maximum (exp2, sum, pack only).  Same softmax as the
     lazy-maximum stream and as fp64 attention for scores inside the vouched range -- here up to |s| ~ 40 in the log2 domain

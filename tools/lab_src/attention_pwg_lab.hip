@@ -99,14 +99,16 @@ __global__ __launch_bounds__(256, 1) void attn_pwg_lab8_kernel(const bf16_t* __r
     const unsigned qoff0 = (unsigned)(((q0 + l31) * 64 + hi * 8) * 2), qoff1 = qoff0 + 32 * 128;
     // output rows bounce through the wave's 8-KiB block of the ring (two 32-row blocks), XOR-swizzled by the row
     const unsigned escr = lds0 + (unsigned)(wave * 8192 + l31 * 128 + ((hi ^ (l31 & 7)) << 4));
-    const int nt = __builtin_amdgcn_readfirstlane(Lk >> 6);
+    const int nt = __builtin_amdgcn_readfirstlane((Lk + 63) >> 6);
+    const int rem = __builtin_amdgcn_readfirstlane(Lk & 63);        // valid keys of a ragged last tile (0: whole)
+    const unsigned hi4 = (unsigned)(hi * 4);
     float lse0, lse1;
     unsigned dbg0, dbg1, dbg2, dbg3, dbg4;
     asm volatile(
 #include "../../motion324_amd/csrc/attn_pwg_lab8.inc"
         : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)
           , [dbg0] "=&v"(dbg0), [dbg1] "=&v"(dbg1), [dbg2] "=&v"(dbg2), [dbg3] "=&v"(dbg3), [dbg4] "=&v"(dbg4)
-        : [rq] "s"(rq), [rk] "s"(rk), [rv] "s"(rv), [nt] "s"(nt), [wlds] "s"(wlds), [ko0] "v"(ko0), [vk0] "v"(vk[0]), [vk1] "v"(vk[1]),
+        : [rq] "s"(rq), [rk] "s"(rk), [rv] "s"(rv), [nt] "s"(nt), [rem] "s"(rem), [hi4] "v"(hi4), [wlds] "s"(wlds), [ko0] "v"(ko0), [vk0] "v"(vk[0]), [vk1] "v"(vk[1]),
           [vv0] "v"(vv[0]), [vv1] "v"(vv[1]), [qoff0] "v"(qoff0), [qoff1] "v"(qoff1), [escr] "v"(escr)
         : "memory", "vcc", "scc",
 #include "../../motion324_amd/csrc/attn_pwg_clobbers_lab.inc"

@@ -62,7 +62,7 @@ def run(B, H, Lq, Lk, spike=True, seed=0):
     return ok
 
 
-shapes = [] if args.shapes == "none" else [(1, 2, 2048, 512), (1, 2, 2100, 2048), (1, 2, 2304, 1088), (2, 3, 2049, 576), (1, 1, 4096, 4096)]
+shapes = [] if args.shapes == "none" else [(1, 2, 2048, 512), (1, 2, 2100, 2100), (1, 2, 2304, 1025), (2, 3, 2049, 639), (1, 1, 4096, 4096), (1, 2, 2100, 2048)]
 if args.shapes == "all":
     shapes += [(1, 12, 10368, 10368)]
 if args.shapes == "small":
