@@ -186,8 +186,23 @@ def _fp_worker(rank, world, port, case, precision, ret):
         m.set_precision(precision)
         with torch.no_grad():
             out = model.forward_frame_parallel(sample)
+            torch.cuda.synchronize()
+            # the same clip with this rank holding ONLY its frames, replayed as a chain of hipGraphs cut at the exchanges
+            # (graph._Segmenter): must reproduce the eager run of the full-sample form bit for bit, twice
+            import functools
+            from motion324_amd import parallel
+            from motion324_amd.graph import GraphedForward
+            T_all = sample["rgb_video"].shape[1]
+            mine = parallel.partition(T_all, world, rank)
+            local = dict(sample)
+            local["rgb_video"] = sample["rgb_video"][:, mine.start:mine.stop].contiguous()
+            fp = functools.partial(model.forward_frame_parallel, local_frames=True, total_frames=T_all)
+            chain = GraphedForward(model, forward=fp, segmented=True)
+            c1 = chain(local).pcd_moved.clone()
+            c2 = chain(local).pcd_moved.clone()
         torch.cuda.synchronize()
         ret[rank] = out.pcd_moved.cpu()
+        ret[f"chain{rank}"] = bool(torch.equal(c1, out.pcd_moved)) and bool(torch.equal(c2, out.pcd_moved))
     finally:
         dist.destroy_process_group()
 
@@ -212,6 +227,7 @@ def test_frame_parallel_at_c2_size(world, precision, tol):
         assert ret[r].shape == ref.shape
         assert rel_err(ret[r], ref) < tol, (r, rel_err(ret[r], ref))
     assert all(torch.equal(ret[0], ret[r]) for r in range(1, world))        # every rank holds the same complete result
+    assert all(ret[f"chain{r}"] for r in range(world))                        # the graph chain with sharded frames == eager
 
 
 # ------------------------------------------------------------------------------------------------------ c4 (2 ranks)
