@@ -990,7 +990,10 @@ static int pick_variant(const m324_gemm_args* a) {
     if (ring_ok && (!a->aux_mode || heads) && (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) <= 512) return 13;
     // M324_QKV_RING=1 (A/B): v13 for every fused q|k|v epilogue.  Round 3: alone v13 runs the trunk's fused q|k|v GEMM in 46.3 us
     // against v2's 51.9 (DINO: 39.0 / 42.8), in the clip it was 9.77 ms against 9.63 (three interleaved rounds).
-    if (ring_ok && heads && m324::tunable(m324::TUN_QKV_RING) != 0) return 13;
+    if (ring_ok && heads && (m324::tunable(m324::TUN_QKV_RING) & 1) != 0) return 13;
+    // bit 1 (A/B): v13 for every plain bf16 output as well (the training step's projections and dgrad GEMMs; microbench round 4:
+    // M = 10368, N = 2304, K = 768 plain 46.9 us against v2's 50.9)
+    if (ring_ok && !a->aux_mode && a->out_dtype == M324_BF16 && (m324::tunable(m324::TUN_QKV_RING) & 2) != 0) return 13;
     return 2;
 }
 

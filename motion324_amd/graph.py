@@ -58,7 +58,11 @@ class _Segmenter:
 
     def end(self) -> None:
         if self.cur is not None:
-            self.cur.capture_end()
+            import warnings
+            with warnings.catch_warnings():
+                # the last link may hold no kernel at all (B = 1: the gathered output is already in its final layout)
+                warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+                self.cur.capture_end()
             self.graphs.append(self.cur)
             self.cur = None
 

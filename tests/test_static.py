@@ -24,3 +24,39 @@ def test_no_packed_fp32_instruction_consumes_a_fresh_dpp_move():
     assert r.returncode == 0, r.stdout + r.stderr
     from motion324_amd import build
     assert "-fno-slp-vectorize" in build.FLAGS and "-fno-slp-vectorize" in build.FLAGS_OF["gemm_ring4.hip"]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_hand_placed_attention_stream_owns_its_registers():
+    """attention_pwg.hip names its registers (v32-255, a0-195) inside one asm statement; the compiler keeps out of them only because
+    they are on the clobber list.  Audit the generated code: no spill, no scratch, one wave per SIMD worth of registers, no compiler
+    v_accvgpr_* / v_mfma outside the statement, and the committed .inc files are what the generator writes today."""
+    import re
+    import subprocess as sp
+    sys.path.insert(0, ROOT)
+    from motion324_amd import build as B
+    asm = B.assembly(["attention_pwg.hip"])["attention_pwg.hip"]
+    text = open(asm).read()
+    kernels = re.findall(r"\.amdhsa_kernel (\S*attn_pwg\S*)", text)
+    assert len(kernels) == 2, kernels                                    # lazy-maximum and bounded streams
+    meta = text[text.index("amdhsa.kernels"):]
+    for field, want in ((".vgpr_spill_count", "0"), (".sgpr_spill_count", "0"), (".private_segment_fixed_size", "0")):
+        vals = re.findall(re.escape(field) + r":\s*(\d+)", meta)
+        assert vals and all(v == want for v in vals), (field, vals)
+    assert all(int(v) > 256 for v in re.findall(r"\.vgpr_count:\s*(\d+)", meta))        # VGPRs + AGPRs: one wave per SIMD
+    outside, inside = [], False
+    for line in text.splitlines():
+        if ";;#ASMSTART" in line:
+            inside = True
+        elif ";;#ASMEND" in line:
+            inside = False
+        elif not inside and ("v_accvgpr" in line or "v_mfma" in line):
+            outside.append(line.strip())
+    assert not outside, outside[:5]
+    # the generator is deterministic: regenerating must reproduce the committed streams byte for byte
+    csrc = os.path.join(ROOT, "motion324_amd", "csrc")
+    before = {f: open(os.path.join(csrc, f)).read() for f in ("attn_pwg_asm.inc", "attn_pwg_bounded_asm.inc", "attn_pwg_clobbers.inc")}
+    r = sp.run([sys.executable, os.path.join(csrc, "gen_attn_pwg.py")], capture_output=True, text=True, cwd=csrc)
+    assert r.returncode == 0, r.stdout + r.stderr                        # includes the generator's own hazard checks
+    for f, old in before.items():
+        assert open(os.path.join(csrc, f)).read() == old, f"{f} is stale: run csrc/gen_attn_pwg.py"
