@@ -22,6 +22,7 @@
 // The fp32 parity variant uses v_mfma_f32_32x32x2_f32 on padded fp32 tiles (single buffered).
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -190,152 +191,162 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
     // ~150 VALU instructions of a tile, in a kernel whose VALU time equals its MFMA time).
     const int ko0 = k_off(l31, hi);
 
-    for (int t = 0; t < nt; ++t) {
-        // tile t landed (this wave's 4 pieces; tile t+1's may still fly), then the barrier publishes every
-        // wave's pieces and retires all reads of the stage that tile t+2 is about to overwrite
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < nt) issue_tile(t + 2);
-        const unsigned char* sk = smem + (t % NST) * ASTAGE;
-        const unsigned char* sv = sk + 8192;
-        const int kos = ko0 + (t % NST) * ASTAGE;
+    // Partly filled last query tile (per-frame blocks: L = 257 -> its third 128-row tile holds ONE row, L = 324 -> 68): the waves
+    // whose 32 rows lie past Lq only stage tiles and meet the barriers.  The guard lives in a second copy of the loop that only
+    // those workgroups run (round 2 put the branch into the one loop every workgroup runs: +4 % on the whole kernel).
+    const bool idle = q0 >= Lq;
+    auto tiles = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        for (int t = 0; t < nt; ++t) {
+            // tile t landed (this wave's 4 pieces; tile t+1's may still fly), then the barrier publishes every
+            // wave's pieces and retires all reads of the stage that tile t+2 is about to overwrite
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 2 < nt) issue_tile(t + 2);
+            if (GUARD && idle) continue;      // a wave without query rows stages its pieces and meets the barriers, nothing else
+            const unsigned char* sk = smem + (t % NST) * ASTAGE;
+            const unsigned char* sv = sk + 8192;
+            const int kos = ko0 + (t % NST) * ASTAGE;
 
-        // ---- S'^T = K Q^T - m_ref : two 32-key blocks per query block
-        f32x16 s[NQ][2];
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            const float init = PRESCALED ? -m_ref[n] : -m_ref[n] / scale_log2e;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[n][kb][r] = init;
-        }
-        if constexpr (NQ == 1 && !VROW && NWV == 8) {
-            // all eight K fragments in flight before the first MFMA (the compiler's order -- two reads, wait, two MFMAs -- waits
-            // out an LDS round trip four times per tile; in-kernel stamps, tools/attn_trace.py)
-            bf16x8 kfa[8];          // in MFMA order: (kb, ks) = (i & 1, i >> 1)
-            auto rd = [&](int i) { kfa[i] = *reinterpret_cast<const bf16x8*>(smem + (i & 1) * 4096 + (kos ^ ((i >> 1) << 5))); };
-            rd(0); rd(1); rd(2); rd(3);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s[0][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[i], qf[0][i >> 1], s[0][i & 1], 0, 0, 0);
-                if (i + 4 < 8) rd(i + 4);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i + 4 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        } else {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kb * 4096 + (kos ^ (ks << 5)));
-#pragma unroll
-                for (int n = 0; n < NQ; ++n)
-                    s[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[n][ks], s[n][kb], 0, 0, 0);
-            }
-        }
-        if (!PRESCALED) {
-#pragma unroll
-            for (int n = 0; n < NQ; ++n)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[n][kb][r] *= scale_log2e;
-        }
-        const int kv0 = t * KV;
-        if (kv0 + KV > Lk) {   // ragged last tile: mask keys >= Lk (wave-uniform branch)
-#pragma unroll
-            for (int n = 0; n < NQ; ++n)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[n][kb][r] = -INFINITY;
-        }
-        // each lane checks its own half of the row against THR; the wave-wide vote combines the halves, so the
-        // cross-half exchange (an LDS round trip and a wait in the middle of the tile) is only paid when the reference moves
-        float mx[NQ];
-        bool calm = true;
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            float v = -INFINITY;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v = fmaxf(v, s[n][kb][r]);
-            mx[n] = v;
-            calm = calm && (v <= THR);
-        }
-        // move the reference only when needed (wave-uniform decision)
-        if (first || !__all(calm)) {
-#pragma unroll
+            // ---- S'^T = K Q^T - m_ref : two 32-key blocks per query block
+            f32x16 s[NQ][2];
+    #pragma unroll
             for (int n = 0; n < NQ; ++n) {
-                mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], 32, 64));
-                const float shift = first ? mx[n] : fmaxf(mx[n], 0.f);     // m_ref never decreases
-                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-shift);
-                m_ref[n] += shift;
-                l_run[n] *= alpha;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[n][i][r] *= alpha;
-#pragma unroll
+                const float init = PRESCALED ? -m_ref[n] : -m_ref[n] / scale_log2e;
+    #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[n][kb][r] -= shift;
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) s[n][kb][r] = init;
             }
-            first = false;
-        }
-        bf16x8 pf[NQ][4];   // P^T fragments, k-step j = kb*2 + (r>>3)
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            f32x2 rs2 = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                uint32_t pk[8];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2 p = {__builtin_amdgcn_exp2f(s[n][kb][r]), __builtin_amdgcn_exp2f(s[n][kb][r + 1])};
-                    rs2 += p;
-                    pk[r >> 1] = pack_bf16x2(p[0], p[1]);
+            if constexpr (NQ == 1 && !VROW && NWV == 8) {
+                // all eight K fragments in flight before the first MFMA (the compiler's order -- two reads, wait, two MFMAs -- waits
+                // out an LDS round trip four times per tile; in-kernel stamps, tools/attn_trace.py)
+                bf16x8 kfa[8];          // in MFMA order: (kb, ks) = (i & 1, i >> 1)
+                auto rd = [&](int i) { kfa[i] = *reinterpret_cast<const bf16x8*>(smem + (i & 1) * 4096 + (kos ^ ((i >> 1) << 5))); };
+                rd(0); rd(1); rd(2); rd(3);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s[0][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[i], qf[0][i >> 1], s[0][i & 1], 0, 0, 0);
+                    if (i + 4 < 8) rd(i + 4);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i + 4 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-                pf[n][kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
-                pf[n][kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
+            } else {
+    #pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kb * 4096 + (kos ^ (ks << 5)));
+    #pragma unroll
+                    for (int n = 0; n < NQ; ++n)
+                        s[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[n][ks], s[n][kb], 0, 0, 0);
+                }
             }
-            l_run[n] += rs2[0] + rs2[1];
-        }
-
-        // ---- O^T += Vt P^T.  k-step j contracts keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}: with the permuted
-        //      key order of Vt that is the single 16-byte chunk 2j + hi of row d
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                bf16x8 vf;
-                if constexpr (VROW) {
-                    // lane (group g = lane >> 4, i = lane & 15) supplies key row j*16 + 4 hi + 8 rd + (i >> 2), d columns
-                    // db*32 + 16 (g & 1) + 4 (i & 3) .. + 3; it receives keys {4hi..4hi+3} (rd 0) and {8+4hi..} (rd 1) of d = l31
-                    const int li = lane & 15, gg = lane >> 4;
-                    const int d0 = db * 32 + 16 * (gg & 1) + 4 * (li & 3);
-                    const int off = (j * 16 + 4 * hi + (li >> 2)) * 128 + (((d0 >> 3) ^ (4 * ((li >> 3) & 1))) << 4) + ((d0 & 7) << 1);
-                    const a_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s16x4_t*)(sv + off));
-                    const a_s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s16x4_t*)(sv + off + 8 * 128));
-                    const a_s16x8_t v8 = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-                    vf = __builtin_bit_cast(bf16x8, v8);
-                } else {
-                    vf = *reinterpret_cast<const bf16x8*>(smem + 8192 + db * 4096 + (kos ^ (j << 5)));
-                }
-#pragma unroll
+            if (!PRESCALED) {
+    #pragma unroll
                 for (int n = 0; n < NQ; ++n)
-                    o[n][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[n][j], o[n][db], 0, 0, 0);
+    #pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) s[n][kb][r] *= scale_log2e;
             }
-        }
+            const int kv0 = t * KV;
+            if (kv0 + KV > Lk) {   // ragged last tile: mask keys >= Lk (wave-uniform branch)
+    #pragma unroll
+                for (int n = 0; n < NQ; ++n)
+    #pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[n][kb][r] = -INFINITY;
+            }
+            // each lane checks its own half of the row against THR; the wave-wide vote combines the halves, so the
+            // cross-half exchange (an LDS round trip and a wait in the middle of the tile) is only paid when the reference moves
+            float mx[NQ];
+            bool calm = true;
+    #pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                float v = -INFINITY;
+    #pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) v = fmaxf(v, s[n][kb][r]);
+                mx[n] = v;
+                calm = calm && (v <= THR);
+            }
+            // move the reference only when needed (wave-uniform decision)
+            if (first || !__all(calm)) {
+    #pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], 32, 64));
+                    const float shift = first ? mx[n] : fmaxf(mx[n], 0.f);     // m_ref never decreases
+                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-shift);
+                    m_ref[n] += shift;
+                    l_run[n] *= alpha;
+    #pragma unroll
+                    for (int i = 0; i < 2; ++i)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) o[n][i][r] *= alpha;
+    #pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) s[n][kb][r] -= shift;
+                }
+                first = false;
+            }
+            bf16x8 pf[NQ][4];   // P^T fragments, k-step j = kb*2 + (r>>3)
+    #pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                f32x2 rs2 = {0.f, 0.f};
+    #pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    uint32_t pk[8];
+    #pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 p = {__builtin_amdgcn_exp2f(s[n][kb][r]), __builtin_amdgcn_exp2f(s[n][kb][r + 1])};
+                        rs2 += p;
+                        pk[r >> 1] = pack_bf16x2(p[0], p[1]);
+                    }
+                    uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                    pf[n][kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
+                    pf[n][kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
+                }
+                l_run[n] += rs2[0] + rs2[1];
+            }
 
-    }
+            // ---- O^T += Vt P^T.  k-step j contracts keys j*16 + {4hi..4hi+3, 8+4hi..8+4hi+3}: with the permuted
+            //      key order of Vt that is the single 16-byte chunk 2j + hi of row d
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+    #pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    bf16x8 vf;
+                    if constexpr (VROW) {
+                        // lane (group g = lane >> 4, i = lane & 15) supplies key row j*16 + 4 hi + 8 rd + (i >> 2), d columns
+                        // db*32 + 16 (g & 1) + 4 (i & 3) .. + 3; it receives keys {4hi..4hi+3} (rd 0) and {8+4hi..} (rd 1) of d = l31
+                        const int li = lane & 15, gg = lane >> 4;
+                        const int d0 = db * 32 + 16 * (gg & 1) + 4 * (li & 3);
+                        const int off = (j * 16 + 4 * hi + (li >> 2)) * 128 + (((d0 >> 3) ^ (4 * ((li >> 3) & 1))) << 4) + ((d0 & 7) << 1);
+                        const a_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s16x4_t*)(sv + off));
+                        const a_s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((a_lds_s16x4_t*)(sv + off + 8 * 128));
+                        const a_s16x8_t v8 = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        vf = __builtin_bit_cast(bf16x8, v8);
+                    } else {
+                        vf = *reinterpret_cast<const bf16x8*>(smem + 8192 + db * 4096 + (kos ^ (j << 5)));
+                    }
+    #pragma unroll
+                    for (int n = 0; n < NQ; ++n)
+                        o[n][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[n][j], o[n][db], 0, 0, 0);
+                }
+            }
+
+        }
+    };
+    if (NWV == 4 && NQ == 1 && NST == 3 && (qt + 1) * NWV * QW > Lq && !(xflags & 4)) tiles(std::true_type{});      // M324_ATTN_EXP bit 2: A/B
+    else tiles(std::false_type{});
 
     // ---- normalise and store.  o[n][db][r]: d = db*32 + (r&3) + 8*(r>>2) + 4*hi, q = l31
 #pragma unroll
