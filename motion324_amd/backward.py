@@ -22,6 +22,7 @@ from .prepared import Prepared
 
 RMS_EPS = 1e-5
 DIRECT_GRADS = switches.get("M324_DIRECT_GRADS") != "0"
+ACC_GRADS = switches.flag("M324_ACC_GRADS")
 
 
 class GradStore:
@@ -36,6 +37,7 @@ class GradStore:
         self.grads: Dict[int, torch.Tensor] = {}
         self.params: Dict[int, torch.nn.Parameter] = {}
         self.sink = sink
+        self._late = []             # (gradient, addend) pairs of small tensors, summed by ONE multi-tensor launch (flush)
         if sink is not None:
             sink.begin_step()
 
@@ -45,7 +47,14 @@ class GradStore:
         g = g.reshape(param.shape)
         k = id(param)
         if k in self.grads:
-            self.grads[k] += g          # accumulation of a few small tensors (shared weights): torch add on fp32
+            # accumulation of small tensors (norm weights, biases of shared modules: a dozen per decoder sample).  One torch add
+            # each was ~85 launches per c3 step; they are collected and summed by torch._foreach_add_ before anyone reads them.
+            if ACC_GRADS and g.dtype == torch.float32 and self.grads[k].dtype == torch.float32 and g.numel() <= 65536:
+                self._late.append((self.grads[k], g if g.is_contiguous() else g.contiguous()))
+                if len(self._late) >= 128:
+                    self.flush()
+            else:
+                self.grads[k] += g
             return
         if self.sink is not None and self.sink.owns(param):
             view = self.sink.grad_of(param)
@@ -54,6 +63,13 @@ class GradStore:
         else:
             self.grads[k] = g.float().clone() if g.dtype != torch.float32 or not g.is_contiguous() else g.clone()
         self.params[k] = param
+
+    def existing(self, param: Optional[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+        """The fp32 gradient `param` already holds (contiguous), for kernels that can add into it; None: use add()."""
+        if not ACC_GRADS or param is None or not param.requires_grad:
+            return None
+        g = self.grads.get(id(param))
+        return g if g is not None and g.dtype == torch.float32 and g.is_contiguous() else None
 
     def target(self, param: Optional[torch.nn.Parameter]) -> Optional[torch.Tensor]:
         """Where the FIRST gradient of `param` may be written directly: its slice of the optimizer's flat gradient buffer
@@ -67,12 +83,19 @@ class GradStore:
         self.grads[id(param)] = view
         self.params[id(param)] = param
 
+    def flush(self) -> None:
+        if self._late:
+            torch._foreach_add_([t for t, _ in self._late], [g for _, g in self._late])
+            self._late = []
+
     def get(self, param) -> Optional[torch.Tensor]:
+        self.flush()
         return self.grads.get(id(param))
 
     def done(self, params) -> None:
         """No further add() will touch these parameters in this step (parameters that received no gradient get zeros,
         what autograd would deliver)."""
+        self.flush()
         if self.sink is None:
             return
         params = [p for p in params if p is not None and p.requires_grad]
@@ -103,10 +126,10 @@ def _wgrad(dYt: torch.Tensor, At: torch.Tensor) -> torch.Tensor:
     return ops.gemm_splitk(dYt, At, slices)
 
 
-def weight_grad(dy: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def weight_grad(dy: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """dW [N, Ka] fp32 = dy[M, N]^T a[M, Ka].  bf16: m324_gemm_tn straight from the token-major operands (transposing LDS
     reads); fp32 parity mode: two transposed copies + the NN kernel with split-K.  out (bf16 path): see ops.gemm_tn; the
-    returned tensor IS out when it was used."""
+    returned tensor IS out when it was used.  accumulate (bf16 path, with out): out += dW."""
     M, N = dy.shape
     Ka = a.shape[1]
     if dy.dtype == torch.bfloat16 and N % 8 == 0 and Ka % 8 == 0:
@@ -120,7 +143,10 @@ def weight_grad(dy: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] =
         ld = max(dy.stride(0), a.stride(0))
         while slices < 4096 and (M // slices + 64 + 1) * ld * 2 >= (1 << 31):
             slices *= 2
-        return ops.gemm_tn(dy, a, slices, out=out)
+        return ops.gemm_tn(dy, a, slices, out=out, accumulate=accumulate)
+    if accumulate:
+        out += _wgrad(ops.transpose(dy), ops.transpose(a)).reshape(out.shape)
+        return out
     return _wgrad(ops.transpose(dy), ops.transpose(a))
 
 
@@ -137,18 +163,25 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
     M, N = dy.shape
     if bias is not None:
         tb = G.target(bias) if dy_colsum is None else None
+        eb = G.existing(bias) if tb is None and dy_colsum is None else None
         if tb is not None:                                    # column sums straight into the flat gradient buffer
             ops.colsum(dy, out=tb.view(-1))
             G.wrote(bias, tb)
+        elif eb is not None:
+            ops.colsum(dy, out=eb.view(-1), accumulate=True)
         else:
             G.add(bias, dy_colsum if dy_colsum is not None else ops.colsum(dy))
     k_true = weight[0].numel()
     tw = G.target(weight) if k_true == a.shape[1] else None
-    dW = weight_grad(dy, a, out=tw)
-    if tw is not None and dW is tw:
-        G.wrote(weight, tw)
+    ex = G.existing(weight) if tw is None and k_true == a.shape[1] else None
+    if ex is not None:                                       # a later pass over a shared weight (the decoder's per-sample loop):
+        weight_grad(dy, a, out=ex, accumulate=True)          # summed into the gradient it already holds, no temporary, no add
     else:
-        G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
+        dW = weight_grad(dy, a, out=tw)
+        if tw is not None and dW is tw:
+            G.wrote(weight, tw)
+        else:
+            G.add(weight, dW[:, :k_true] if k_true != a.shape[1] else dW)
     if not need_da:
         return None
     Wt = _wt(P, weight)                                       # [Kp, N_pad]

@@ -106,7 +106,8 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, slices: int) -> torch.Tensor:
     return colsum(part.reshape(part.shape[0], M * N)).reshape(M, N)
 
 
-def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1, out: Optional[torch.Tensor] = None,
+            accumulate: bool = False) -> torch.Tensor:
     """out[N, Kc] fp32 = x[M, N]^T @ y[M, Kc] (bf16, token-major operands): the weight gradient dW = dY^T A without
     transposed copies (m324_gemm_tn).  The M tokens are cut into `slices` ranges whose partials m324_colsum adds.
     out: contiguous fp32 [N, Kc] (or any view of N * Kc contiguous floats) that receives the result -- the optimizer's flat
@@ -120,17 +121,22 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1, out: Optional[tor
         slices -= 1                                   # no empty slice
     if out is not None and (out.dtype != torch.float32 or out.numel() != N * Kc or not out.is_contiguous()):
         raise L.M324Error("gemm_tn: out must be N * Kc contiguous fp32 values")
-    direct = out is not None and slices == 1
+    # accumulate (out += x^T y: a shared weight's gradient over the decoder's per-sample passes): the slice partials are summed
+    # INTO out by the same m324_colsum launch that would have produced a temporary (a single slice goes through it too)
+    if accumulate and out is None:
+        raise L.M324Error("gemm_tn: accumulate needs out")
+    direct = out is not None and slices == 1 and not accumulate
     part = out.view(1, N, Kc) if direct else torch.empty((slices, N, Kc), dtype=torch.float32, device=x.device)
     px, ldx = _rows(x, "x")
     py, ldy = _rows(y, "y")
     with span("gemm_bf16", 2.0 * M * N * Kc, 2.0 * M * (N + Kc) + 4.0 * slices * N * Kc,
               f"TN M={N} N={Kc} K={M} slices={slices}" if _timing() else ""):
         L.check(L.load().m324_gemm_tn(px, ldx, py, ldy, _p(part), Kc, M, N, Kc, slices, N * Kc, _stream()), "m324_gemm_tn")
-    if slices == 1:
+    if slices == 1 and not accumulate:
         return out if direct else part[0]
     if out is not None:
-        colsum(part.reshape(slices, N * Kc), out=out.view(-1))
+        colsum(part.reshape(slices, N * Kc), out=out.view(-1), accumulate=accumulate)
+        _wrote(out)
         return out
     return colsum(part.reshape(slices, N * Kc)).reshape(N, Kc)
 

@@ -25,6 +25,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_FUSE_QKV_VT": ("1", "transformer.FUSE_QKV_VT", "the same for long sequences: the epilogue writes the transposed, key-permuted V"),
     "M324_TRAIN_STORE": ("1", "training.TRAIN_STORE", "training: the forward keeps block internals while they fit half of the free HBM (0: always recompute, the reference's checkpoint policy)"),
     "M324_DIRECT_GRADS": ("1", "backward.DIRECT_GRADS", "training: weight / bias gradients are written straight into the optimizer's flat gradient buffer (0: temporary + copy)"),
+    "M324_ACC_GRADS": ("1", "backward.ACC_GRADS", "training: later gradients of a shared weight (the decoder's per-sample passes) are summed into the one it holds by the weight-gradient kernel's own reduction (0: temporary + torch add)"),
     "M324_PRECISION": ("", "prepared.compute_dtype()", "force bf16 / fp32 (default: follow torch.autocast like the reference)"),
     "M324_LIB": ("", "lib.LIB_PATH", "path of an alternative libm324.so (lab builds)"),
     "M324_RCCL_LIB": ("", "csrc/comm.hip", "m324_comm_*: path of the RCCL library to bind (default: the copy already loaded, else librccl.so)"),
