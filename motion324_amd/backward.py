@@ -37,7 +37,6 @@ class GradStore:
         self.grads: Dict[int, torch.Tensor] = {}
         self.params: Dict[int, torch.nn.Parameter] = {}
         self.sink = sink
-        self._late = []             # (gradient, addend) pairs of small tensors, summed by ONE multi-tensor launch (flush)
         if sink is not None:
             sink.begin_step()
 
@@ -47,14 +46,7 @@ class GradStore:
         g = g.reshape(param.shape)
         k = id(param)
         if k in self.grads:
-            # accumulation of small tensors (norm weights, biases of shared modules: a dozen per decoder sample).  One torch add
-            # each was ~85 launches per c3 step; they are collected and summed by torch._foreach_add_ before anyone reads them.
-            if ACC_GRADS and g.dtype == torch.float32 and self.grads[k].dtype == torch.float32 and g.numel() <= 65536:
-                self._late.append((self.grads[k], g if g.is_contiguous() else g.contiguous()))
-                if len(self._late) >= 128:
-                    self.flush()
-            else:
-                self.grads[k] += g
+            self.grads[k] += g          # accumulation of a few small tensors (shared weights): torch add on fp32
             return
         if self.sink is not None and self.sink.owns(param):
             view = self.sink.grad_of(param)
@@ -83,19 +75,12 @@ class GradStore:
         self.grads[id(param)] = view
         self.params[id(param)] = param
 
-    def flush(self) -> None:
-        if self._late:
-            torch._foreach_add_([t for t, _ in self._late], [g for _, g in self._late])
-            self._late = []
-
     def get(self, param) -> Optional[torch.Tensor]:
-        self.flush()
         return self.grads.get(id(param))
 
     def done(self, params) -> None:
         """No further add() will touch these parameters in this step (parameters that received no gradient get zeros,
         what autograd would deliver)."""
-        self.flush()
         if self.sink is None:
             return
         params = [p for p in params if p is not None and p.requires_grad]
