@@ -331,7 +331,7 @@ def _event_time_ms(fn, steps: int) -> float:
     return e0.elapsed_time(e1) / steps
 
 
-def decoder_block_replay(model, sample, steps: int):
+def decoder_block_replay(model, sample, steps: int, q_branch: bool = True):
     """The north-star block (decoder cross-attention: k|v and q projections, attention, out-projection, MLP -- reference
     transformer.py:365-377 via Pcd_motion.py:556-561) as the product runs it: its launches captured into a hipGraph of their
     own and replayed back to back between two HIP events.  The block reads the trunk's REAL output stream of this clip
@@ -363,6 +363,10 @@ def decoder_block_replay(model, sample, steps: int):
             # as in the product's graph (Pcd_motion._forward, HOIST_DECODER_Q): the q projection depends on the mesh points
             # only and runs on a second branch, here beside the k|v projection of the latent tokens
             main = torch.cuda.current_stream()
+            if not q_branch:
+                Q = dec.project_q(P, pf, 1, N)
+                Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))
+                return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q)
             branch.wait_stream(main)
             with torch.cuda.stream(branch):
                 Q = dec.project_q(P, pf, 1, N)

@@ -193,7 +193,8 @@ int m324_qkv_split(const void* q_src, long ldq, const void* k_src, long ldk, con
 enum { M324_ATTN_Q_PRESCALED = 1, M324_ATTN_V_ROWMAJOR = 2, M324_ATTN_SCORES_BOUNDED = 4 };
 int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo,
                    int B, int H, int Lq, int Lk, float scale, int q_prescaled, float* lse, int dtype, void* stream);
-/* Host-only twin of m324_gemm_plan for m324_attention (flags = the q_prescaled flag word). */
+/* Host-only twin of m324_gemm_plan for m324_attention (flags = the q_prescaled flag word; | 256: q_bstride == 0, one query
+ * set shared by every batch, which the plan cannot see otherwise). */
 int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int dtype, char* buf, int n);
 /*   lse (optional, [B,H,Lq] fp32): log2-domain log-sum-exp of every score row, saved for the backward pass. */
 

@@ -398,6 +398,137 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? (VROW ? 2 : 4) : (NST == 1 ? 4
     }
 }
 
+// One key tile (Lk <= 64), ONE query set shared by every batch (q_bstride == 0), FB consecutive batches per workgroup: the
+// decoder's cross-attention (the same 2048 mesh points under each of the 32 frames' 64 latent tokens, Pcd_motion.py:556-560).
+// The one-tile form of attn_bf16_kernel starts 6144 workgroups that each load the SAME query fragments, wait out one LDS-DMA
+// round trip, compute one tile and store 16 KiB.  Here a workgroup keeps its 128 queries' fragments in registers and walks FB
+// frames: K / Vt of frame j + 1 fly (second LDS stage) while frame j is computed, and frame j - 1's output rows -- parked in the
+// wave's LDS block -- are stored behind the wait at the top of iteration j, so that wait (vmcnt(0): loads and stores share the
+// counter and retire out of order with respect to each other) never sees a store younger than one whole iteration.
+// Measured on the decoder's shape (T = 32, H = 12, 2048 x 64; us, interleaved A/B, two boxes): one workgroup per frame 38.1 / 39.5,
+// FB = 8: 34.7 / 36.1, FB = 4: 35.3 / 37.2, FB = 2: 32.8 / 34.3, FB = 2 with nontemporal stores 32.0 / 32.5 (NT: the 100 MB of
+// output rows are read next by the out projection, from HBM / MALL either way; a 100-MB fill takes 16 us).
+template <int FB, bool NT>
+__global__ __launch_bounds__(256, 3) void attn_frames_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                             const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, long ldo, int H, int Lq,
+                                                             int Lk, int Lkp, float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * ASTAGE + 4 * 4096];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, qt = blockIdx.x, b0 = blockIdx.z * FB;
+    const int q0 = (qt * 4 + wave) * QW;
+    const int q = q0 + l31;
+    const bf16_t* Qh = Q + (long)h * Lq * 64;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = q < Lq ? *reinterpret_cast<const uint4*>(Qh + (long)q * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+        qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    unsigned vk[2], vv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int srow = (wave * 2 + i) * 8 + (lane >> 3);
+        const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * 8;
+        vk[i] = (unsigned)((srow * 64 + scol) * 2);
+        vv[i] = (unsigned)((srow * Lkp + scol) * 2);
+    }
+    auto issue = [&](int j) {                                       // K rows past Lk read as zeros (masked below), Vt is zero padded
+        const long bh = (long)(b0 + j) * H + h;
+        const __amdgpu_buffer_rsrc_t rk = dma_rsrc(K + bh * (long)Lk * 64, (long)Lk * 128);
+        const __amdgpu_buffer_rsrc_t rv = dma_rsrc(Vt + bh * 64 * Lkp, 64l * Lkp * 2);
+        unsigned char* sk = smem + (j & 1) * ASTAGE + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma_piece(rk, sk + i * 1024, vk[i], 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma_piece(rv, sk + 8192 + i * 1024, vv[i], 0u);
+    };
+    unsigned char* scr = smem + 2 * ASTAGE + wave * 4096;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    auto flush = [&](int j) {                                       // frame j's 32 rows of this wave: 8 whole 128-byte rows per store
+        bf16_t* obase = O + ((long)(b0 + j) * Lq + q0) * ldo + h * 64 + c8 * 8;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = p * 8 + r8;
+            const uint4 v = *reinterpret_cast<const uint4*>(scr + r * 128 + ((c8 ^ (r & 7)) << 4));
+            if (q0 + r < Lq) {
+                if (NT) __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(&v), reinterpret_cast<f32x4*>(obase + (long)r * ldo));
+                else *reinterpret_cast<uint4*>(obase + (long)r * ldo) = v;
+            }
+        }
+    };
+    const int ko0 = k_off(l31, hi);
+    issue(0);
+#pragma unroll 1
+    for (int j = 0; j < FB; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // frame j's pieces (issued an iteration ago); stores of frame j - 2
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 1 < FB) issue(j + 1);
+        if (j > 0) flush(j - 1);
+        const int kos = ko0 + (j & 1) * ASTAGE;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kb * 4096 + (kos ^ (ks << 5)));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        if (Lk < KV) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) s[kb][r] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                    // the row's maximum (one tile: the plain softmax)
+        f32x2 rs2 = {0.f, 0.f};
+        bf16x8 pf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint32_t pk[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 p = {__builtin_amdgcn_exp2f(s[kb][r] - mx), __builtin_amdgcn_exp2f(s[kb][r + 1] - mx)};
+                rs2 += p;
+                pk[r >> 1] = pack_bf16x2(p[0], p[1]);
+            }
+            uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi4 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            pf[kb * 2] = *reinterpret_cast<bf16x8*>(&lo);
+            pf[kb * 2 + 1] = *reinterpret_cast<bf16x8*>(&hi4);
+        }
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(smem + 8192 + db * 4096 + (kos ^ (jj << 5)));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jj], o[db], 0, 0, 0);
+            }
+        }
+        float l_tot = rs2[0] + rs2[1];
+        l_tot += __shfl_xor(l_tot, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (lse && q < Lq && hi == 0) lse[((long)(b0 + j) * H + h) * Lq + q] = mx + log2f(l_tot);
+        store_row_chunks(o, inv, hi, true, [&](int chunk, uint4 v) {
+            *reinterpret_cast<uint4*>(scr + l31 * 128 + ((chunk ^ (l31 & 7)) << 4)) = v;
+        });
+    }
+    flush(FB - 1);
+}
+
 // Two other forms of the eight-wave kernel were built and measured in round 3 and are not kept (DESIGN.md section 6,
 // "what limits the global attention"; tools/coissue_lab, tools/attn_trace.py):
 //  * ping-pong: matrix phase {P.V of tile t, S of tile t + 1} / vector phase {softmax}, waves 4-7 one phase behind waves 0-3,
@@ -894,6 +1025,14 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         if (vrow) {
             if (q_prescaled) { if (w8) M324_ATTN_VR(true, 8); else M324_ATTN_VR(true, 4); }
             else { if (w8) M324_ATTN_VR(false, 8); else M324_ATTN_VR(false, 4); }
+        } else if (q_prescaled && !w8 && !nq2 && !vrow && Lk <= KV && q_bstride == 0 && B % 2 == 0 && Lq >= 512 && !(xfl & 8)) {
+            // shared queries under several batches of one key tile (the decoder): two frames per workgroup (M324_ATTN_EXP bit 3: A/B)
+            if (xfl & 16)       // plain stores
+                hipLaunchKernelGGL((attn_frames_kernel<2, false>), dim3(ceil_div(Lq, QB), H, B / 2), dim3(256), 0, s, (const bf16_t*)Q,
+                                   (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, lse);
+            else
+                hipLaunchKernelGGL((attn_frames_kernel<2, true>), dim3(ceil_div(Lq, QB), H, B / 2), dim3(256), 0, s, (const bf16_t*)Q,
+                                   (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, lse);
         } else if (q_prescaled && !w8 && !nq2 && Lk <= KV && m324::tunable(m324::TUN_ATTN_OCC) != 1) {      // one tile (M324_ATTN_OCC=1: A/B)
             hipLaunchKernelGGL((attn_bf16_kernel<true, 1, 4, false, 1>), g2, dim3(256), 0, s, (const bf16_t*)Q, q_bstride,
                                (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt, xfl);
@@ -935,6 +1074,8 @@ extern "C" int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int 
     if (flat != 0 && (w8 || (flat != 2 && !nq2 && !one_tile && gx > 1 && gx * H * B >= 512)))
         snprintf(buf, (size_t)n, "attn_bf16_kernel<%s, %d, %d, %s, 3> grid=%ldx1x1", ps ? "true" : "false", nq2 ? 2 : 1, nwv,
                  vrow ? "true" : "false", gx * H * B * nwv * 64);
+    else if (one_tile && (flags & 256) && B % 2 == 0 && Lq >= 512 && !(m324::tunable(m324::TUN_ATTN_EXP) & 8))
+        snprintf(buf, (size_t)n, "attn_frames_kernel<2, %s> grid=%ldx%dx%d", (m324::tunable(m324::TUN_ATTN_EXP) & 16) ? "false" : "true", gx * 256, H, B / 2);
     else if (ps && !vrow && !w8 && !nq2 && Lk <= KV && m324::tunable(m324::TUN_ATTN_OCC) != 1)
         snprintf(buf, (size_t)n, "attn_bf16_kernel<true, 1, 4, false, 1> grid=%ldx%dx%d", gx * nwv * 64, H, B);
     else

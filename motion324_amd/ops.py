@@ -381,7 +381,7 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     esz = Q.element_size()
     with span(f"attention_{'bf16' if esz == 2 else 'f32'}", 4.0 * B * H * Lq * Lk * 64,
               esz * 64.0 * H * ((1 if shared_q else B) * Lq + 2 * B * Lk + B * Lq),
-              f"{_attn_plan(B, H, Lq, Lk, int(prescaled) | (2 if v_rowmajor else 0) | (4 if bounded else 0), code_of(Q.dtype))} | B={B} H={H} Lq={Lq} Lk={Lk}"
+              f"{_attn_plan(B, H, Lq, Lk, int(prescaled) | (2 if v_rowmajor else 0) | (4 if bounded else 0) | (256 if shared_q else 0), code_of(Q.dtype))} | B={B} H={H} Lq={Lq} Lk={Lk}"
               if _timing() else ""):
         L.check(L.load().m324_attention(_p(Q), qbs, _p(K), _p(Vt), po, ldo, B, H, Lq, Lk, scale,
                                         int(prescaled) | (2 if v_rowmajor else 0) | (4 if bounded else 0), _p(lse), code_of(Q.dtype), _stream()),

@@ -625,6 +625,36 @@ def test_attention_shared_q(dtype):
     assert rel_err(out.float(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
 
 
+@pytest.mark.parametrize("T,H,Lq,Lk", [(8, 3, 2048, 64), (4, 2, 700, 64), (6, 1, 513, 37), (32, 12, 2048, 64)])
+def test_attention_shared_q_frame_loop(tune, T, H, Lq, Lk):
+    """The decoder's cross-attention kernel (one query set in registers, two frames per workgroup, frame j + 1's K / Vt in flight
+    under frame j): ragged query tiles, fewer than 64 keys, the LSE, and the SAME bits as the one-workgroup-per-frame form
+    (M324_ATTN_EXP bit 3), whose arithmetic it repeats.  Reference Pcd_motion.py:539-560."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    q, k, v = _rand((1, H, Lq, 64), 122, 1.5), _rand((T, H, Lk, 64), 123, 1.5), _rand((T, H, Lk, 64), 124)
+    k[3 % T, 0, Lk // 2] = q[0, 0, 11] * 3.0
+    k, v = _q(k, dtype), _q(v, dtype)
+    qs = _q(q * ops.Q_PRESCALE, dtype)
+    qd, kd, vd = qs.to(dtype).to(DEV), k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV)
+    outs, lses = [], []
+    for bits in ("0", "8"):
+        tune("M324_ATTN_EXP", bits)
+        plan = ops._attn_plan(T, H, Lq, Lk, 1 | 256, ops.code_of(dtype))
+        assert ("attn_frames_kernel" in plan) == (bits == "0"), plan
+        out = torch.full((T * Lq, H * 64), float("nan"), dtype=dtype, device=DEV)
+        lse = torch.full((T, H, Lq), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(qd, kd, vd, out, prescaled=True, shared_q=True, lse=lse)
+        outs.append(out), lses.append(lse)
+    sc = torch.einsum("bhqd,bhkd->bhqk", qs.expand(T, -1, -1, -1).double(), k.double())
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc * math.log(2.0), dim=-1), v.double()).reshape(T * Lq, H * 64)
+    assert torch.isfinite(outs[0].float()).all()
+    assert rel_err(outs[0].float(), ref) < 8e-3
+    assert (lses[0].double().cpu() - torch.logsumexp(sc * math.log(2.0), dim=-1) / math.log(2.0)).abs().max() < 2e-3
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(lses[0], lses[1])
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_attention_online_softmax_rescale(dtype):
     """A late key with a much larger score forces the running-max rescale of every earlier tile."""
