@@ -108,6 +108,10 @@ typedef struct {
     const float* ln_rowstat; const float* ln_colsum;
     float* ln_stats_out;
     void* ln_copy_out; long ln_ldcopy;
+    /*   consumer, unmerged table (ln_ncb > 0): ln_rowstat is not the merged table but the producer's ln_stats_out itself,
+     *     [ln_ncb][M] (sum, M2) with ln_ncb = K / 64 even and <= 16, and the consumer merges the blocks of its tiles' rows (the arithmetic
+     *     of m324_rowstats_finish, eps = ln_eps) while its first operand tiles are in flight -- no launch between the two GEMMs. */
+    int ln_ncb; float ln_eps;
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
 /* Host-only: writes the kernel symbol (as rocprofv3 prints the template) and its grid in threads that m324_gemm would

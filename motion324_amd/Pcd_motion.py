@@ -573,7 +573,7 @@ class Motion_Latent_Model(nn.Module):
                 if fold_d is not None:
                     # the head's LayerNorm rides in its first GEMM: statistics left by the MLP's last epilogue
                     hw, hcs, hb = P.folded(head_ln.weight, head_ln.bias, head_fc1.weight, head_fc1.bias)
-                    h, lnk = fold_d.xb, dict(ln=(fold_d.ready(head_ln.eps), hcs))
+                    h, lnk = fold_d.xb, dict(ln=fold_d.ln(head_ln.eps, hcs))
                 else:
                     h = torch.empty(x.shape, dtype=P.dtype, device=dev)
                     ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)

@@ -161,9 +161,10 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const TIN* __restrict
 
     const int nk = K / BK;
     const int arow0 = wm * 64 + l31, brow0 = wn * 64 + l31;
-    LnPre ln_pre;
+    LnPreT<2> ln_pre;
     ln_prefetch<ACT, 2>(ep, M, N, m0 + wm * 64, n0 + wn * 64, lane, ln_pre);
     issue_tile(0, 0);
+    ln_finish<ACT, 2>(ep, lane, ln_pre);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (never left to __syncthreads()'s fence)
         __syncthreads();
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
 
     const int nk = K / BK;
     const int arow0 = wm * 128 + l31, brow0 = wn * 64 + l31;
-    const LnPre* const ln_pre_ptr = nullptr;
+    const LnPreT<4>* const ln_pre_ptr = nullptr;
     issue_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (never left to __syncthreads()'s fence)
@@ -376,15 +377,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 1);
     };
 
-    // prologue of the FIRST tile: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile
-    // (12 in all at K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue
+    // LayerNorm fold, consumer (gemm_tile.h ln_prefetch / ln_finish): a wave fetches -- unmerged table: and merges -- 32 of its row of
+    // waves' 128 rows where registers are free: the FIRST tile's around the ring prologue (entries requested in front of the pieces,
+    // merged behind them), the NEXT tile's behind this tile's epilogue, in front of the drain that ends it anyway.  Only (rstd,
+    // -rstd mean) of one row and one colsum travel through the main loop (the accumulators leave no room for the entries: held
+    // across it they spilled, and a scratch reload inside the loop waits out every LDS-DMA piece older than itself).
+    float2* const ln_table = reinterpret_cast<float2*>(reinterpret_cast<float*>(smem + 2 * CHUNK10) + (wm * 4) * ep_wave_floats(ACT) + EP_WAVE_FLOATS);
+    float2 ln_rs;
+    float ln_cs;
     {
+        LnPreT<4> first;
+        ln_prefetch<ACT, 4>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, first, wn, ln_table);
+        // prologue of the FIRST tile: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile
+        // (12 in all at K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue
         const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
         issue2a(0, 0, 0); issue2a(2, 0, 0);
         issue2b(0, 0, 1); issue2b(2, 0, 1);
         issue2a(0, s1, 2); issue2a(2, s1, 2);
         issue2b(0, s1, 3); issue2b(2, s1, 3);
         issue2a(0, s2, 4); issue2a(2, s2, 4);
+        ln_finish<ACT, 4>(ep, lane, first);
+        ln_rs = first.rs, ln_cs = first.cs;
     }
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (A_1, W_1, A_2 may fly)
     M324_BARRIER();
@@ -419,8 +432,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int mt = m0, nt = n0;                         // this tile's origin (m0 / n0 move on in front of the epilogue)
         const bool more = t + (int)gridDim.x < ntiles;
-        LnPre ln_pre;
-        ln_prefetch<ACT, 4>(ep, M, N, mt + wm * 128, nt + wn * 64, lane, ln_pre);
+        LnPreT<4> ln_pre;
+        ln_pre.rs = ln_rs, ln_pre.cs = ln_cs, ln_pre.table = ln_table, ln_pre.slot = 32 * wn;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -452,6 +465,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem + 2 * CHUNK10) + wave * ep_wave_floats(ACT), C, ldc, M, N,
                                           mt + wm * 128, nt + wn * 64, lane, ep, &ln_pre);
         if (more) {
+            LnPreT<4> next;                                 // m0 / n0 are the next tile's already
+            ln_prefetch<ACT, 4>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, next, wn, ln_table);
+            ln_finish<ACT, 4>(ep, lane, next);
+            ln_rs = next.rs, ln_cs = next.cs;
             // everything this wave has in flight -- the two prefetched chunks and the epilogue's stores (loads and stores share
             // vmcnt and may retire out of order with respect to each other) -- must be done before the next tile starts.  The
             // builtin, not inline asm: hipcc's own wait-count pass must see the drain (gemm_ring4.hip has the story).
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __rest
         M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 2);
     };
 
-    LnPre ln_pre;
+    LnPreT<2> ln_pre;
     ln_prefetch<ACT, 2>(ep, M, N, m0 + wm * 64, n0 + wn * 64, lane, ln_pre);
     {
         const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
@@ -547,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __rest
         issue2(gb, 0, s1, 3); issue2(gb, 2, s1, 3);
         issue2(ga, 0, s2, 4); issue2(ga, 2, s2, 4);
     }
+    ln_finish<ACT, 2>(ep, lane, ln_pre);                    // the table entries are older than the ring's 20 pieces
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (A_1, W_1, A_2 may fly)
     M324_BARRIER();
     int pa = 0, pw = 1;
@@ -1024,7 +1042,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                 (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > (128l << 20)) ? 1 : 0,
                 (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0,
                 reinterpret_cast<const float2*>(a->ln_rowstat), a->ln_colsum, reinterpret_cast<float2*>(a->ln_stats_out),
-                static_cast<bf16_t*>(a->ln_copy_out), a->ln_ldcopy};
+                static_cast<bf16_t*>(a->ln_copy_out), a->ln_ldcopy, a->ln_rowstat ? a->ln_ncb : 0, a->ln_eps};
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
     const bool lnf = a->ln_rowstat || a->ln_stats_out || a->ln_copy_out;     // LayerNorm fold: the ACT | 8 instantiations
@@ -1286,6 +1304,10 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
         }
         M324_REQUIRE(!a->ln_rowstat || (a->ln_colsum && ((uintptr_t)a->ln_rowstat % 8) == 0 && ((uintptr_t)a->ln_colsum % 16) == 0),
                      "m324_gemm: ln_rowstat needs ln_colsum (16-byte aligned) and an 8-byte aligned row table");
+        M324_REQUIRE(!a->ln_rowstat || a->ln_ncb <= 0 || (a->ln_ncb <= 16 && a->ln_ncb % 2 == 0 && a->ln_ncb * 64 == a->K && a->ln_eps >= 0.f &&
+                                                           (long)a->ln_ncb * a->M * 8 < (1l << 32)),
+                     "m324_gemm: an unmerged row table has K / 64 blocks of 64 columns, an even count <= 16, and less than 4 GiB "
+                     "(ln_ncb=%d K=%d M=%d)", a->ln_ncb, a->K, a->M);
         M324_REQUIRE((!a->ln_stats_out && !a->ln_copy_out) || (a->row_gin <= 0 && a->aux_mode == M324_AUX_NONE),
                      "m324_gemm: ln_stats_out / ln_copy_out describe the rows of C: no row remap, no aux mode");
         M324_REQUIRE(!a->ln_stats_out || ((uintptr_t)a->ln_stats_out % 8) == 0, "m324_gemm: ln_stats_out misaligned");

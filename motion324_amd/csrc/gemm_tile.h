@@ -1,6 +1,7 @@
 // Shared by the GEMM translation units (gemm.hip, gemm_ring4.hip): epilogue descriptor, GELU forms, LDS swizzles, the
 // MFMA k-tile of the 128 x 128 kernels and the LDS-transposed epilogue every LDS-DMA kernel ends with.
 #pragma once
+#include <utility>
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -34,6 +35,8 @@ struct Epilogue {
     float2* stats;               // [N / 64][M] (sum, sum of squared deviations from the block mean), or null
     bf16_t* copy;                // [M, ldcopy] bf16 copy of the stored values (fp32 outputs), or null
     long ldcopy;
+    int ncb;                     // > 0: rowstat is the producer's UNMERGED table [ncb][M] (sum, M2 per 64-column block); the consumer merges its rows' blocks
+    float eps;                   // ... with this LayerNorm epsilon (what m324_rowstats_finish does in a launch of its own)
 };
 
 // gemm_ring4.hip (own translation unit: built WITHOUT -amdgpu-mfma-vgpr-form, its 256 accumulators live in AGPRs).
@@ -428,19 +431,127 @@ constexpr int EP_LN_FLOATS = 512;
 constexpr int ep_wave_floats(int actx) { return (actx & 8) ? EP_WAVE_FLOATS + EP_LN_FLOATS : EP_WAVE_FLOATS; }
 // Consumer side: the wave's rows' table entries, one (MI = 2) or two (MI = 4) per lane; kernels call this before their
 // prologue's LDS-DMA (older than every piece, so the counted vmcnt waits of the main loop retire it for free).
-struct LnPre {
-    float2 rs[2];                // (rstd, -rstd mean) of rows mw + lane, mw + 64 + lane
+// ep.ncb > 0: the table is the producer's unmerged one and the consumer merges the blocks of its rows between issuing its
+// prologue's LDS-DMA and the main loop (ln_finish: the table loads are older than every piece, the counted wait the compiler puts
+// in front of the merge leaves the pieces in flight).  Chan's update, block after block (blocks of 64 values):
+//   mean += (mean_b - mean) / (b + 1),  M2 += M2_b + (mean_b - mean)^2 * 64 b / (b + 1).
+// MI = 2 (128 x 128 tiles, 64 rows per wave): a lane fetches / merges its row alone (up to 16 table entries in flight).
+// MI = 4 (v10: 128 rows per wave, the same rows under the four waves of a row of waves, 255 registers): wave wn fetches / merges
+// rows 32 wn .. 32 wn + 31 (unmerged table: the lane halves take half of the blocks each and combine); the epilogue exchanges the
+// 4 x 32 rows through one LDS table per row of waves (LnPreT::table) behind a workgroup barrier -- three registers held across
+// the main loop instead of five.
+constexpr int LN_MAX_NCB = 16;
+typedef float ln_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ln_f32x8 __attribute__((ext_vector_type(8)));
+template <int MI>
+struct LnPreT {
+    float2 rs;                   // (rstd, -rstd mean) of row mw + lane (MI = 2) / mw + slot + (lane & 31) (MI = 4)
     float cs;                    // colsum of column nw + lane
+    // ncb > 0: the row's (half of the) block entries until ln_finish -- vector VALUES, not an array member: an array's
+    // `#pragma unroll` loops are unrolled after the pass that turns arrays into registers, and the entries went through scratch
+    std::conditional_t<(MI > 2), ln_f32x8, ln_f32x16> raw_sum, raw_m2;
+    float2* table;               // MI = 4: the row of waves' shared (rstd, -rstd mean) table in LDS
+    int slot;                    // ... and this wave's first row in it
 };
+// one block more (cnt blocks merged so far); `take` false leaves the pair as it is (no branch: the lane halves of MI = 4 differ)
+__device__ __forceinline__ void ln_chan_step(const float2 pb, float inv_cnt1, float w, bool take, float& mean, float& m2) {
+    const float d = pb.x * (1.0f / 64.0f) - mean;                   // inv_cnt1 = 1 / (cnt + 1), w = 64 cnt / (cnt + 1)
+    const float nm = fmaf(d, inv_cnt1, mean);
+    const float n2 = m2 + fmaf(d * d, w, pb.y);
+    mean = take ? nm : mean;
+    m2 = take ? n2 : m2;
+}
+// entry (block, row) of the unmerged table: uniform base + uniform block offset + ONE 32-bit per-lane offset (64-bit per-lane
+// pointers, one per block, were hoisted out of the tile loop and spilled).  Host: the table is smaller than 4 GiB.
+__device__ __forceinline__ float2 ln_entry(const char* table, unsigned block_bytes, int block, unsigned lane_off) {
+    return *reinterpret_cast<const float2*>(table + (size_t)((unsigned)block * block_bytes) + lane_off);
+}
+// MI = 4: `table` is the row of waves' LDS table, wn the wave's column (it owns rows 32 wn .. 32 wn + 31 of the 128).  Unmerged
+// table: the lower lane half reads blocks 0 .. h - 1, the upper h .. ncb - 1, h = ncb / 2 (the host sends odd counts -- no width
+// of the product -- through m324_rowstats_finish).
 template <int ACTX, int MI>
-__device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, int mw, int nw, int lane, LnPre& pre) {
-    pre.rs[0] = pre.rs[1] = make_float2(0.f, 0.f);
+__device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, int mw, int nw, int lane, LnPreT<MI>& pre, int wn = 0,
+                                            float2* table = nullptr) {
+    pre.rs = make_float2(0.f, 0.f);
     pre.cs = 0.f;
+    pre.table = table;
+    pre.slot = 32 * wn;
     if constexpr ((ACTX & 8) != 0) {
-        pre.rs[0] = ep.rowstat[min(mw + lane, M - 1)];
-        if (MI > 2) pre.rs[1] = ep.rowstat[min(mw + 64 + lane, M - 1)];
         pre.cs = ep.colsum[min(nw + lane, N - 1)];
+        const int row = MI > 2 ? min(mw + 32 * wn + (lane & 31), M - 1) : min(mw + lane, M - 1);
+        if (ep.ncb <= 0) {
+            pre.rs = ep.rowstat[row];
+        } else if constexpr (MI > 2) {
+            // v10 calls this once per tile inside its persistent loop with 250 registers live.  Written as compiler-visible loads, the
+            // (tile-invariant) per-block addresses were hoisted out of that loop into registers it does not have and came back
+            // from scratch one by one; so: eight loads from uniform block bases + ONE 32-bit lane offset and their wait in one block.
+            // vmcnt(0): at both call sites nothing else this wave has in flight is wanted later than these entries.
+            const char* const tbl = reinterpret_cast<const char*>(ep.rowstat);
+            const unsigned bb = (unsigned)M * 8u;
+            const int h = ep.ncb >> 1;                      // host: an even block count
+            const unsigned off = (unsigned)((lane >> 5) ? h : 0) * bb + (unsigned)row * 8u;
+            const char* b[LN_MAX_NCB / 2];
+#pragma unroll
+            for (int i = 0; i < LN_MAX_NCB / 2; ++i) b[i] = tbl + (size_t)((unsigned)min(i, h - 1) * bb);
+            f32x2 e0, e1, e2, e3, e4, e5, e6, e7;
+            asm volatile("global_load_dwordx2 %0, %8, %9\n\t"
+                         "global_load_dwordx2 %1, %8, %10\n\t"
+                         "global_load_dwordx2 %2, %8, %11\n\t"
+                         "global_load_dwordx2 %3, %8, %12\n\t"
+                         "global_load_dwordx2 %4, %8, %13\n\t"
+                         "global_load_dwordx2 %5, %8, %14\n\t"
+                         "global_load_dwordx2 %6, %8, %15\n\t"
+                         "global_load_dwordx2 %7, %8, %16\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7)
+                         : "v"(off), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "s"(b[4]), "s"(b[5]), "s"(b[6]), "s"(b[7])
+                         : "memory");
+            pre.raw_sum = ln_f32x8{e0[0], e1[0], e2[0], e3[0], e4[0], e5[0], e6[0], e7[0]};
+            pre.raw_m2 = ln_f32x8{e0[1], e1[1], e2[1], e3[1], e4[1], e5[1], e6[1], e7[1]};
+        } else {
+            const char* const tbl = reinterpret_cast<const char*>(ep.rowstat);
+#pragma unroll
+            for (int i = 0; i < LN_MAX_NCB; ++i) {
+                const float2 p = ln_entry(tbl, (unsigned)M * 8u, min(i, ep.ncb - 1), (unsigned)row * 8u);
+                pre.raw_sum[i] = p.x, pre.raw_m2[i] = p.y;
+            }
+        }
     }
+}
+template <int ACTX, int MI>
+__device__ __forceinline__ void ln_finish(const Epilogue& ep, int lane, LnPreT<MI>& pre) {
+    if constexpr ((ACTX & 8) != 0) {
+        if (ep.ncb <= 0) return;
+        float mean = 0.f, m2 = 0.f;
+        if constexpr (MI > 2) {
+            const int h = ep.ncb >> 1;                      // both lane halves merge h blocks (host: an even count)
+            mean = pre.raw_sum[0] * (1.0f / 64.0f), m2 = pre.raw_m2[0];
+#pragma unroll
+            for (int i = 1; i < LN_MAX_NCB / 2; ++i)
+                ln_chan_step(make_float2(pre.raw_sum[i], pre.raw_m2[i]), 1.0f / (float)(i + 1), 64.0f * (float)i / (float)(i + 1), i < h, mean, m2);
+            // the other half's (count, mean, M2): Chan's pairwise form
+            const float omean = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
+            const float d = omean - mean;                   // equal counts n = 64 h: d^2 n n / 2n = 32 h d^2
+            m2 = m2 + om2 + d * d * (32.0f * (float)h);
+            mean = mean + 0.5f * d;
+        } else {
+            mean = pre.raw_sum[0] * (1.0f / 64.0f), m2 = pre.raw_m2[0];
+#pragma unroll
+            for (int i = 1; i < LN_MAX_NCB; ++i)
+                ln_chan_step(make_float2(pre.raw_sum[i], pre.raw_m2[i]), 1.0f / (float)(i + 1), 64.0f * (float)i / (float)(i + 1), i < ep.ncb, mean, m2);
+        }
+        const float rstd = rsqrtf(m2 / (64.0f * (float)ep.ncb) + ep.eps);
+        pre.rs = make_float2(rstd, -rstd * mean);
+    }
+}
+// the rows a kernel without prefetch needs (v11 / v12: no folded consumer of the product reaches them; tests do)
+__device__ __forceinline__ float2 ln_row_direct(const Epilogue& ep, int M, int row) {
+    if (ep.ncb <= 0) return ep.rowstat[row];
+    float mean = 0.f, m2 = 0.f;
+    for (int b = 0; b < ep.ncb; ++b)
+        ln_chan_step(ep.rowstat[(long)b * M + row], 1.0f / (float)(b + 1), 64.0f * (float)b / (float)(b + 1), true, mean, m2);
+    const float rstd = rsqrtf(m2 / (64.0f * (float)ep.ncb) + ep.eps);
+    return make_float2(rstd, -rstd * mean);
 }
 
 // ACTX: the low bits are the activation / aux code (0 none, 1 GELU, 2 GELU + pre-activation, 3 x gelu', 4 q|k|v heads,
@@ -451,7 +562,7 @@ __device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, in
 // untouched.
 template <typename TOUT, int ACTX, int RES, int MI>
 __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float* scr, TOUT* C, long ldc, int M, int N, int mw,
-                                               int nw, int lane, const Epilogue& ep, const LnPre* pre = nullptr) {
+                                               int nw, int lane, const Epilogue& ep, const LnPreT<MI>* pre = nullptr) {
     constexpr int ACT = ACTX & 7;
     constexpr bool fold = (ACTX & 8) != 0, STATS = (ACTX & 16) != 0, COPY = (ACTX & 32) != 0;
     const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
@@ -467,12 +578,18 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
     float* wr = scr + l31 * EP_LD + 4 * hi;
     const float* rd = scr + rr * EP_LD + cc;
     const bool wave_in = nw + 64 <= N;                       // producer side needs whole 64-column blocks (host: N % 64 == 0)
-    float2* const rsl = reinterpret_cast<float2*>(scr + EP_WAVE_FLOATS);   // [128] (rstd, -rstd mean) of rows mw .. (consumers)
+    float2* rsl = reinterpret_cast<float2*>(scr + EP_WAVE_FLOATS);         // [128] (rstd, -rstd mean) of rows mw .. (consumers)
     float* const csl = scr + EP_WAVE_FLOATS + 256;                          // [64] colsum of columns nw ..
     if (fold) {                                              // DS operations of a wave execute in order: no barrier needed
-        rsl[lane] = pre ? pre->rs[0] : ep.rowstat[min(mw + lane, M - 1)];
-        if (MI > 2) rsl[64 + lane] = pre ? pre->rs[1] : ep.rowstat[min(mw + 64 + lane, M - 1)];
         csl[lane] = pre ? pre->cs : ep.colsum[min(nw + lane, N - 1)];
+        if (MI > 2 && pre) {                                 // the four waves of a row of waves fetched / merged 32 rows each (ln_prefetch)
+            rsl = pre->table;
+            if (lane < 32) rsl[pre->slot + lane] = pre->rs;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave of the workgroup runs this epilogue
+        } else {
+            rsl[lane] = pre ? pre->rs : ln_row_direct(ep, M, min(mw + lane, M - 1));
+            if (MI > 2) rsl[64 + lane] = ln_row_direct(ep, M, min(mw + 64 + lane, M - 1));
+        }
     }
     float2* const stats_wave = (STATS && wave_in) ? ep.stats + (long)(nw >> 6) * M : nullptr;
     // interior tiles (all but the last row / column of tiles) take a copy without per-store predicates, so the 8 LDS

@@ -169,7 +169,7 @@ class DinoEncoder(nn.Module):
             r = slice(f0 * Lt, f1 * Lt)
             if fold is not None:
                 src, (wq, csq, bq) = fold.xb, w["f_qkv"]
-                lnk = dict(ln=(fold.ready(DINO_EPS), csq))
+                lnk = dict(ln=fold.ln(DINO_EPS, csq))
             else:
                 ops.layernorm(x[r], *w["n1"], DINO_EPS, h[r])
                 src, wq, bq, lnk = h[r], w["qkv"][0], w["qkv"][1], {}
@@ -186,7 +186,7 @@ class DinoEncoder(nn.Module):
                      **(fold.producer() if fold is not None else {}))
             if fold is not None:
                 w1, cs1, b1 = w["f_fc1"]
-                ops.gemm(fold.xb, w1, h1[r], bias=b1, act=ACT_GELU, ln=(fold.ready(DINO_EPS), cs1))
+                ops.gemm(fold.xb, w1, h1[r], bias=b1, act=ACT_GELU, ln=fold.ln(DINO_EPS, cs1))
             else:
                 ops.layernorm(x[r], *w["n2"], DINO_EPS, h[r])
                 ops.gemm(h[r], w["fc1"][0], h1[r], bias=w["fc1"][1], act=ACT_GELU)

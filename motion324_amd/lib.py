@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class M324Error(RuntimeError):
@@ -41,7 +41,7 @@ class GemmArgs(C.Structure):
         ("qkv_eps", C.c_float), ("qkv_qscale", C.c_float), ("qkv_L", C.c_int), ("qkv_H", C.c_int),
         ("ln_rowstat", C.c_void_p), ("ln_colsum", C.c_void_p),
         ("ln_stats_out", C.c_void_p),
-        ("ln_copy_out", C.c_void_p), ("ln_ldcopy", C.c_long),
+        ("ln_copy_out", C.c_void_p), ("ln_ldcopy", C.c_long), ("ln_ncb", C.c_int), ("ln_eps", C.c_float),
     ]
 
 

@@ -154,7 +154,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     A V of shape [B, H, 64, L] selects M324_AUX_QKV_HEADS_VT: V leaves transposed and key-permuted, the operand
     attention() reads by default (L % 128 == 0).
     LayerNorm fold (include/m324.h): ln = (rowstat fp32 [M, 2], colsum fp32 [N]) -- `a` is the raw stream, `w` carries the
-    LayerNorm scale; stats_out fp32 [N / 64, M, 2] receives the per-block row statistics of the stored values and copy_out
+    LayerNorm scale; ln = (part fp32 [K / 64, M, 2], colsum, eps): the producer's stats_out itself, merged by this GEMM; stats_out fp32 [N / 64, M, 2] receives the per-block row statistics of the stored values and copy_out
     bf16 [M, N] their bf16 twin (fp32 `out` only)."""
     M, K = a.shape
     N = w.shape[0]
@@ -164,7 +164,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     args.A, args.lda = _rows(a, "a")
     args.W, args.ldw = _rows(w, "w")
     args.M, args.N, args.K = M, N, K
-    if ln is not None:
+    if ln is not None and len(ln) == 3:
+        part, colsum, eps = ln                       # the producer's unmerged table: the consumer merges its rows' blocks itself
+        if (part.dtype != torch.float32 or not part.is_contiguous() or K % 64 or tuple(part.shape) != (K // 64, M, 2) or a.dtype != torch.bfloat16):
+            raise L.M324Error(f"gemm: ln block table {part.dtype}{tuple(part.shape)} (want contiguous fp32 [{K // 64}, {M}, 2], bf16 operands)")
+        args.ln_rowstat, args.ln_colsum = _p(part), _vec(colsum, N, "ln colsum")
+        args.ln_ncb, args.ln_eps = K // 64, float(eps)
+    elif ln is not None:
         rowstat, colsum = ln
         if (rowstat.dtype != torch.float32 or not rowstat.is_contiguous() or rowstat.numel() != 2 * M or a.dtype != torch.bfloat16):
             raise L.M324Error(f"gemm: ln rowstat {rowstat.dtype}{tuple(rowstat.shape)} (want contiguous fp32 [{M}, 2], bf16 operands)")

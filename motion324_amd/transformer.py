@@ -117,14 +117,19 @@ class QK_Norm_CrossAttention(_AttnBase):
 # LayerNorm fold (bf16 inference, include/m324.h): the GEMM that writes a residual stream leaves the row statistics of
 # what it stored (and, next to an fp32 stream, its bf16 twin); the GEMM behind the LayerNorm reads that twin with the
 # LayerNorm's scale folded into its weight and applies mean / rstd in its epilogue; the LayerNorm pass itself disappears.
-# Measured on the c2 clip (round 3, interleaved A/B, profiles/r03_ln_fold_ab.md):
+# Between producer and consumer the per-block statistics of a row are merged into (rstd, -rstd mean): by the consumer itself
+# (M324_FOLD_MERGE=1, round 4: table entries requested in front of its first operand tiles, Chan's update behind them) or by
+# m324_rowstats_finish in a launch of its own (round 3; =0).
+# Measured on the c2 clip, interleaved A/B (profiles/r03_ln_fold_ab.md, profiles/r04_ln_fold_merge.md):
 #   * bf16 streams (the decoder: 65 536 rows, 8-wave GEMMs, no twin to write): two 46-us passes go for +2.5 us (fc2's
-#     statistics), +4.5 us (fc1's epilogue) and two 4-us merges: decoder block 0.903 -> 0.874 ms.  ON by default.
-#   * fp32 streams (trunk, DINO: 10 368 / 8 224 rows): a 9.6-us pass goes for +4 us in the producer (statistics on a
-#     one-wave-per-SIMD kernel, 50 % more store bytes for the twin), +2 us in the consumer and a 2.5-us merge + its launch
-#     boundary: break-even within +-0.5 % of the clip.  OFF by default; M324_FOLD_LN=2 folds them too (tests do).
-# M324_FOLD_LN=0 restores every separate pass.
+#     statistics), +4.5 us (fc1's epilogue) and two 4-us merges: decoder block 0.903 -> 0.874 ms (round 3).
+#   * fp32 streams (trunk, DINO: 10 368 / 8 224 rows, 56 LayerNorms per clip): a 9.6-us pass goes for +4 us in the producer
+#     (statistics on a one-wave-per-SIMD kernel, 50 % more store bytes for the twin) and +2 us in the consumer -- and, round 3,
+#     a 2.5-us merge launch + its boundary: break-even, left off.  With the merge inside the consumer: 8.82 -> 8.69 ms per clip
+#     (the launch form: 8.98), so M324_FOLD_LN=2, every stream, is the default since round 4.
+# M324_FOLD_LN=1 folds the bf16 streams only, =0 restores every separate pass.
 FOLD_LN = int(switches.get("M324_FOLD_LN"))
+FOLD_MERGE = switches.flag("M324_FOLD_MERGE")      # folded consumers merge the producer's per-block statistics themselves
 ATTN_BOUNDED = switches.flag("M324_ATTN_BOUNDED")
 
 
@@ -159,6 +164,13 @@ class LNFold:
         self.pending = True
         return dict(stats_out=self.part, copy_out=self.xb if self.own_copy else None)
 
+    def ln(self, eps: float, colsum: torch.Tensor) -> tuple:
+        """The `ln` argument of the ops.gemm call that consumes the stream: the merged table, or -- statistics still in the
+        producer's per-block form and M324_FOLD_MERGE on -- that table itself, merged by the consumer (no launch in between)."""
+        if self.pending and FOLD_MERGE and self.C <= 1024 and self.C % 128 == 0:      # m324_gemm: an even block count <= 16
+            return (self.part, colsum, eps)
+        return (self.ready(eps), colsum)
+
     def ready(self, eps: float) -> torch.Tensor:
         if self.pending:
             ops.rowstats_finish(self.part, eps, self.stat)
@@ -175,7 +187,7 @@ def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor, f
     h1 = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=x.device)
     if fold is not None:
         w1, cs1, b1 = P.folded(norm2.weight, norm2.bias, fc1.weight, fc1.bias)
-        ops.gemm(fold.xb, w1, h1, bias=b1, act=ACT_GELU, ln=(fold.ready(norm2.eps), cs1))
+        ops.gemm(fold.xb, w1, h1, bias=b1, act=ACT_GELU, ln=fold.ln(norm2.eps, cs1))
         ops.gemm(h1, P.mat(fc2.weight), x, bias=P.vec(fc2.bias), residual=x, **(fold.producer() if feed_next else {}))
         return x
     h = torch.empty((rows, C), dtype=P.dtype, device=x.device)
@@ -249,7 +261,7 @@ class QK_Norm_TransformerBlock(nn.Module):
         qw, kw = a._qk_w(P)
         if fold is not None:
             w, cs, bias = P.folded(self.norm1.weight, self.norm1.bias, a.to_qkv.weight, a.to_qkv.bias)
-            src, lnk = fold.xb, (lambda lo, hi: dict(ln=(fold.ready(self.norm1.eps), cs[lo:hi])))
+            src, lnk = fold.xb, (lambda lo, hi: dict(ln=fold.ln(self.norm1.eps, cs[lo:hi])))
         else:
             ops.layernorm(x, P.vec(self.norm1.weight), P.vec(self.norm1.bias), self.norm1.eps, h)
             w, bias = P.mat(a.to_qkv.weight), P.vec(a.to_qkv.bias)

@@ -993,6 +993,58 @@ def _folded(lnw, lnb, w, b):
     return wf, colsum, bias
 
 
+def _block_table(xb: torch.Tensor) -> torch.Tensor:
+    """What a producer GEMM leaves for the rows of its output: [K / 64, M, 2] (sum, sum of squared deviations from the block mean)."""
+    M, K = xb.shape
+    blocks = xb.double().reshape(M, K // 64, 64)
+    s = blocks.sum(2)
+    m2 = ((blocks - s[..., None] / 64) ** 2).sum(2)
+    return torch.stack([s, m2], dim=2).permute(1, 0, 2).contiguous().float()
+
+
+@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13"])
+@pytest.mark.parametrize("M,N,K", [(470, 192, 256), (513, 3072, 768), (1100, 768, 1024)])
+def test_gemm_ln_fold_consumer_merges_block_table(tune, variant, M, N, K):
+    """ln = (part, colsum, eps): the consumer merges the producer's per-block statistics of its rows itself (no m324_rowstats_finish
+    launch between the two GEMMs).  Same result as the merged table -- the two merges differ by fp32 rounding only -- on every
+    schedule, with ragged last tiles, several tiles per persistent workgroup (v10) and rows whose mean dwarfs their deviation."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    if variant != "v0":
+        tune("M324_GEMM", variant)
+    x = _rand((M, K), 321)
+    x[::7] += 5.0
+    x[3::11] *= 0.01
+    xb = x.to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * _rand((K,), 322), 0.1 * _rand((K,), 323)
+    w, b = _rand((N, K), 324, 0.05), _rand((N,), 325)
+    wf, colsum, bias = _folded(lnw, lnb, w, b)
+    part = _block_table(xb).to(DEV)
+    stat = torch.empty((M, 2), device=DEV)
+    ops.rowstats_finish(part, 1e-5, stat)
+    outs = []
+    for ln in ((stat, colsum.to(DEV)), (part, colsum.to(DEV), 1e-5)):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(xb.to(DEV), wf.to(DEV), out, bias=bias.to(DEV), act=ACT_GELU, ln=ln)
+        outs.append(out.float().cpu())
+    ref = _ln_ref(xb.float(), lnw, lnb, 1e-5) @ w.double().T + b.double()
+    ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2.0)))
+    assert torch.isfinite(outs[1]).all()
+    assert rel_err(outs[1], ref) < 5e-3
+    assert rel_err(outs[1], outs[0]) < 2e-4                  # bf16 outputs: a last-bit flip here and there
+
+
+def test_gemm_ln_fold_block_table_rejects_odd_block_counts():
+    ops = _ops()
+    from motion324_amd.lib import M324Error
+    M, N, K = 256, 128, 192
+    a = torch.zeros((M, K), dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros((N, K), dtype=torch.bfloat16, device=DEV)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(M324Error, match="even count"):
+        ops.gemm(a, w, out, ln=(torch.zeros((3, M, 2), device=DEV), torch.zeros((N,), device=DEV), 1e-5))
+
+
 @pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("mode", ["plain", "gelu", "f32out"])
 @pytest.mark.parametrize("M,N,K", [(3 * 256, 768, 192), (470, 192, 256), (513, 3072, 768)])
@@ -1049,6 +1101,9 @@ def test_gemm_ln_fold_qkv_heads(L, vt):
     want = run(h, w.to(torch.bfloat16), b, None)
     for g, r in zip(got, want):
         assert torch.isfinite(g).all() and rel_err(g, r) < 8e-3     # two bf16 roundings apart (h vs W')
+    # C = 192 is three blocks: m324_gemm takes even block counts only -- the per-block table goes through the launch of its own
+    with pytest.raises(Exception, match="even count"):
+        run(xb, wf, bias, (_block_table(xb).to(DEV), colsum.to(DEV), 1e-5))
 
 
 def test_gemm_ln_fold_n3_head():
@@ -1071,6 +1126,13 @@ def test_gemm_ln_fold_n3_head():
     v = _ln_ref(xb.float(), lnw, lnb, 1e-5) @ w.double().T + b.double()
     v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
     assert rel_err(out, v @ w3.double().T + b3.double()) < 3e-3
+    # the same with the consumer merging the per-block table itself
+    part2 = torch.empty((C // 64, M, 3), device=DEV)
+    ops.gemm(xb.to(DEV), wf.to(DEV), None, bias=bias.to(DEV), act=ACT_GELU, n3=(w3.to(DEV), part2),
+             ln=(_block_table(xb).to(DEV), colsum.to(DEV), 1e-5))
+    out2 = torch.empty((M, 3), device=DEV)
+    ops.n3_finish(part2, b3.to(DEV), out2)
+    assert rel_err(out2, out.double()) < 1e-4
 
 
 def test_gemm_ln_fold_rejects_unsupported_shapes():

@@ -102,23 +102,31 @@ def test_forward_bf16_band(case):
 
 @pytest.mark.parametrize("case", ["tiny", "c1"])
 def test_layernorm_fold_is_invisible_within_the_bf16_band(case, monkeypatch):
-    """bf16 inference with the LayerNorms folded into the GEMMs around them (M324_FOLD_LN=1, the default: the decoder's bf16
-    stream; =2: trunk and DINO too) against the same forward with the separate LayerNorm passes (=0): all inside the band of
+    """bf16 inference with the LayerNorms folded into the GEMMs around them (M324_FOLD_LN=2, the default: every stream; =1: the
+    decoder's bf16 stream only) against the same forward with the separate LayerNorm passes (=0): all inside the band of
     the reference goldens, and closer to each other than either is to the fp32 reference."""
     import motion324_amd.transformer as tr
     model, dm = build(case)
     gold = load_golden(case)
     sample = inputs(case, with_target=False)
-    assert tr.FOLD_LN == 1                            # default: the bf16 streams (decoder); 2 folds trunk and DINO as well
+    assert tr.FOLD_LN == 2                            # default: every stream; 1 folds the bf16 streams (decoder) only
+    folded, cap_f = run(model, sample, "bf16")
+    monkeypatch.setattr(tr, "FOLD_LN", 1)
     default, _ = run(model, sample, "bf16")
     monkeypatch.setattr(tr, "FOLD_LN", 2)
-    folded, cap_f = run(model, sample, "bf16")
+    assert tr.FOLD_MERGE                              # default: the consumer GEMMs merge the producers' block statistics themselves
+    monkeypatch.setattr(tr, "FOLD_MERGE", False)      # ... against the m324_rowstats_finish launch between producer and consumer
+    launched, _ = run(model, sample, "bf16")
+    dm_ = rel_err(folded.pcd_moved, launched.pcd_moved)          # fp32 rounding of the two merges, through 40 bf16 blocks
+    print(f"[{case}] merged by the consumers vs by m324_rowstats_finish {dm_:.2e}")
+    assert dm_ < BF16_TOL
+    monkeypatch.setattr(tr, "FOLD_MERGE", True)
     monkeypatch.setattr(tr, "FOLD_LN", 0)
     plain, cap_p = run(model, sample, "bf16")
     ref = torch.from_numpy(gold["pcd_moved"])
     ef, ep, d = rel_err(folded.pcd_moved, ref), rel_err(plain.pcd_moved, ref), rel_err(folded.pcd_moved, plain.pcd_moved)
     ed = rel_err(default.pcd_moved, ref)
-    print(f"[{case}] default (decoder folded) {ed:.2e}  everything folded {ef:.2e}  separate LayerNorm passes {ep:.2e}  "
+    print(f"[{case}] decoder folded only {ed:.2e}  everything folded (default) {ef:.2e}  separate LayerNorm passes {ep:.2e}  "
           f"folded vs separate {d:.2e}")
     assert ed < BF16_TOL and ef < BF16_TOL and ep < BF16_TOL and d < BF16_TOL
     assert ed < 1.25 * ep + 5e-4
