@@ -1006,8 +1006,9 @@ static int pick_variant(const m324_gemm_args* a) {
     // tile's 12 K-stages are pure latency -- the ring's 2.5 stages of look-ahead: 11.4 -> 9.2 us, 10.5 -> 8.3 us)
     const bool heads = a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT;   // cross-attention q / k|v
     if (ring_ok && (!a->aux_mode || heads) && (long)ceil_div(a->N, BN) * ceil_div(a->M, BM) <= 512) return 13;
-    // M324_QKV_RING=1 (A/B): v13 for every fused q|k|v epilogue.  Round 3: alone v13 runs the trunk's fused q|k|v GEMM in 46.3 us
-    // against v2's 51.9 (DINO: 39.0 / 42.8), in the clip it was 9.77 ms against 9.63 (three interleaved rounds).
+    // bit 0 of M324_QKV_RING (default on): v13 for every fused q|k|v epilogue.  Alone v13 always ran the trunk's fused q|k|v GEMM
+    // faster than v2 (46.3 us against 51.9, DINO 39.0 / 42.8); inside the clip it lost in round 3 (9.77 ms against 9.63) and wins
+    // since the LayerNorm passes around it are folded (round 4, interleaved: 8.683 -> 8.618 ms; 256 frames 183.96 -> 183.77).
     if (ring_ok && heads && (m324::tunable(m324::TUN_QKV_RING) & 1) != 0) return 13;
     // bit 1 (A/B): v13 for every plain bf16 output as well (the training step's projections and dgrad GEMMs; microbench round 4:
     // M = 10368, N = 2304, K = 768 plain 46.9 us against v2's 50.9)

@@ -43,7 +43,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup (4 | 8); 0 = 8 from 256 keys on"),
     "M324_ATTN_EXP": ("0", "attention A/B bits: 1 static priority for the younger half of an 8-wave workgroup, 2 direct stores in the one-tile form, 4 no idle-wave skip in partly filled query tiles, 8 one workgroup per frame in the shared-query one-tile form, 16 its frame-pair form with plain (not nontemporal) stores"),
     "M324_ATTN_PWG": ("1", "attention forward, long sequences: 1 = one wave per SIMD with the hand-placed stream (attention_pwg.hip), 0 = the eight-wave kernel"),
-    "M324_QKV_RING": ("0", "128 x 128 chunk ring (v13) instead of the two-stage v2: bit 0 for the fused q|k|v projection (head-major epilogue), bit 1 for plain bf16 outputs (A/B)"),
+    "M324_QKV_RING": ("1", "128 x 128 chunk ring (v13) instead of the two-stage v2: bit 0 for the fused q|k|v projection (head-major epilogue), bit 1 for plain bf16 outputs (A/B)"),
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
     "M324_GEMM_PERSIST": ("1", "256 x 256 chunk-ring GEMM (v10): 1 = one persistent workgroup per CU, next tile's first chunks under the epilogue; 0 = one workgroup per tile"),
 }
