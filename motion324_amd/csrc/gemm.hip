@@ -999,8 +999,7 @@ static int pick_variant(const m324_gemm_args* a) {
     const double e12 = (double)t12 / (double)(((t12 + 255) / 256) * 256);
     if (ring_ok && a->K >= 1024 && t12 >= 180 && e12 >= 0.70) return 12;
     // 128 x 128 tiles: the chunk-ring pipeline (v13) for the fp32 residual outputs at K = 768 (22.3 -> 21.4 us,
-    // 20.2 -> 19.1 us; 10.35 -> 10.31 ms per clip).  The fused q|k|v epilogues stay on v2: v13 wins them in isolation
-    // (43.6 -> 42.3 us) but the clip got 0.9 % slower with it.
+    // 20.2 -> 19.1 us; 10.35 -> 10.31 ms per clip)
     if (ring_ok && a->out_dtype == M324_F32 && !a->aux_mode) return 13;
     // ... and for small plain bf16 problems (the decoder's k|v and q projections, 2048 rows: <= one round of tiles, so a
     // tile's 12 K-stages are pure latency -- the ring's 2.5 stages of look-ahead: 11.4 -> 9.2 us, 10.5 -> 8.3 us)
