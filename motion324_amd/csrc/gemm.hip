@@ -1039,7 +1039,7 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
                 a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode,
                 {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
                 a->qkv_L, a->qkv_H, a->aux_mode == M324_AUX_QKV_HEADS_VT ? 1 : 0,
-                (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > (128l << 20)) ? 1 : 0,
+                (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > ((long)m324::tunable(m324::TUN_NT_MB) << 20)) ? 1 : 0,
                 (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0,
                 reinterpret_cast<const float2*>(a->ln_rowstat), a->ln_colsum, reinterpret_cast<float2*>(a->ln_stats_out),
                 static_cast<bf16_t*>(a->ln_copy_out), a->ln_ldcopy, a->ln_rowstat ? a->ln_ncb : 0, a->ln_eps};

@@ -45,6 +45,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_ATTN_PWG": ("1", "attention forward, long sequences: 1 = one wave per SIMD with the hand-placed stream (attention_pwg.hip), 0 = the eight-wave kernel"),
     "M324_QKV_RING": ("1", "128 x 128 chunk ring (v13) instead of the two-stage v2: bit 0 for the fused q|k|v projection (head-major epilogue), bit 1 for plain bf16 outputs (A/B)"),
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
+    "M324_NT_MB": ("128", "GEMM: bf16 outputs (no residual) larger than this many MiB are stored nontemporal"),
     "M324_GEMM_PERSIST": ("1", "256 x 256 chunk-ring GEMM (v10): 1 = one persistent workgroup per CU, next tile's first chunks under the epilogue; 0 = one workgroup per tile"),
 }
 
