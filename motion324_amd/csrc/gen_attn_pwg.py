@@ -147,7 +147,7 @@ def ds_read(dst_a, addr_v, off):
 
 
 # ------------------------------------------------------------------------------------------------ filler streams
-OPT = {"bounded": False, "lsum_mfma": False, "trace": False, "noexp": False, "nomax": False, "nobarrier": False, "nodma": False, "nofill": False, "lookahead": 1}
+OPT = {"bounded": False, "lsum_mfma": False, "trace": False, "noexp": False, "nomax": False, "nobarrier": False, "nodma": False, "nofill": False, "lookahead": 1, "pk_sum": False}
 
 
 def stream_exp(x):
@@ -165,9 +165,14 @@ def stream_exp(x):
                 kind = valu if OPT["noexp"] else trans
                 head = [kind(f"{op} {v(s0)}, {v(s0)}", [f"v{s0}"], [f"v{s0}"]), kind(f"{op} {v(s1)}, {v(s1)}", [f"v{s1}"], [f"v{s1}"])]
                 l0, l1 = LSUM + n * 2, LSUM + n * 2 + 1
-                tail_ = [] if OPT["lsum_mfma"] else [
-                    valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(s0)}", [f"v{l0}", f"v{s0}"], [f"v{l0}"]),
-                    valu(f"v_add_f32_e32 {v(l1)}, {v(l1)}, {v(s1)}", [f"v{l1}", f"v{s1}"], [f"v{l1}"])]
+                if OPT["lsum_mfma"]:
+                    tail_ = []
+                elif OPT["pk_sum"]:           # one packed add for the pair: the same two sums (even / odd scores), half the issue slots
+                    assert l0 % 2 == 0 and s0 % 2 == 0 and s1 == s0 + 1
+                    tail_ = [valu(f"v_pk_add_f32 {v(l0, 2)}, {v(l0, 2)}, {v(s0, 2)}", [f"v{l0}", f"v{l1}", f"v{s0}", f"v{s1}"], [f"v{l0}", f"v{l1}"])]
+                else:
+                    tail_ = [valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(s0)}", [f"v{l0}", f"v{s0}"], [f"v{l0}"]),
+                             valu(f"v_add_f32_e32 {v(l1)}, {v(l1)}, {v(s1)}", [f"v{l1}", f"v{s1}"], [f"v{l1}"])]
                 tail_.append(valu(f"v_cvt_pk_bf16_f32 {v(PF(n, j, p))}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{PF(n, j, p)}"]))
                 pairs.append((head, tail_))
     la = OPT["lookahead"]
@@ -631,8 +636,9 @@ def main():
             OPT[key] = True
             write(f"attn_pwg_lab{i + 1}.inc", program())
             OPT[key] = False
-        OPT["lookahead"] = 2
+        OPT["pk_sum"] = not OPT["pk_sum"]            # the other form of the row sums (A/B)
         write("attn_pwg_lab6.inc", program())
+        OPT["pk_sum"] = not OPT["pk_sum"]
         OPT["lookahead"] = 3
         write("attn_pwg_lab7.inc", program())
         OPT["lookahead"] = 1

@@ -28,7 +28,8 @@ s = synth.synth_inputs(1, args.frames, 2048, 4096, 512, seed=1)
 sample = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
 HOST = {"M324_ATTN_BOUNDED": ("motion324_amd.transformer", "ATTN_BOUNDED"), "M324_FOLD_LN": ("motion324_amd.transformer", "FOLD_LN"),
         "M324_FOLD_MERGE": ("motion324_amd.transformer", "FOLD_MERGE"),
-        "M324_BF16_DECODER": ("motion324_amd.Pcd_motion", "BF16_DECODER_STREAM"), "M324_FUSE_HEAD": ("motion324_amd.Pcd_motion", "FUSE_HEAD_N3")}
+        "M324_BF16_DECODER": ("motion324_amd.Pcd_motion", "BF16_DECODER_STREAM"), "M324_FUSE_HEAD": ("motion324_amd.Pcd_motion", "FUSE_HEAD_N3"),
+        "M324_OVERLAP": ("motion324_amd.Pcd_motion", "OVERLAP_SHAPE_ENCODER"), "M324_HOIST_Q": ("motion324_amd.Pcd_motion", "HOIST_DECODER_Q")}
 
 
 def set_switch(k, v):
