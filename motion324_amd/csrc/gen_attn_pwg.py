@@ -147,7 +147,7 @@ def ds_read(dst_a, addr_v, off):
 
 
 # ------------------------------------------------------------------------------------------------ filler streams
-OPT = {"bounded": False, "lsum_mfma": False, "trace": False, "noexp": False, "nomax": False, "nobarrier": False, "nodma": False, "nofill": False, "lookahead": 1, "pk_sum": False}
+OPT = {"bounded": False, "lsum_mfma": False, "trace": False, "noexp": False, "nomax": False, "nobarrier": False, "nodma": False, "nofill": False, "lookahead": 1, "pk_sum": False, "trunc_pack": False}
 
 
 def stream_exp(x):
@@ -173,7 +173,10 @@ def stream_exp(x):
                 else:
                     tail_ = [valu(f"v_add_f32_e32 {v(l0)}, {v(l0)}, {v(s0)}", [f"v{l0}", f"v{s0}"], [f"v{l0}"]),
                              valu(f"v_add_f32_e32 {v(l1)}, {v(l1)}, {v(s1)}", [f"v{l1}", f"v{s1}"], [f"v{l1}"])]
-                tail_.append(valu(f"v_cvt_pk_bf16_f32 {v(PF(n, j, p))}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{PF(n, j, p)}"]))
+                if OPT["trunc_pack"]:         # lab, timing only: the pair's high halves by v_perm_b32 (truncation; selector in s60)
+                    tail_.append(valu(f"v_perm_b32 {v(PF(n, j, p))}, {v(s1)}, {v(s0)}, s60", [f"v{s0}", f"v{s1}"], [f"v{PF(n, j, p)}"]))
+                else:
+                    tail_.append(valu(f"v_cvt_pk_bf16_f32 {v(PF(n, j, p))}, {v(s0)}, {v(s1)}", [f"v{s0}", f"v{s1}"], [f"v{PF(n, j, p)}"]))
                 pairs.append((head, tail_))
     la = OPT["lookahead"]
     out = []
@@ -471,6 +474,8 @@ def prologue():
     # ring: tiles 0, 1, 2 (s54 counts the tile being issued)
     if OPT["trace"]:
         L += [salu(f"s_mov_b32 s{i}, 0") for i in range(64, 86)]
+    if OPT["trunc_pack"]:
+        L.append(salu("s_mov_b32 s60, 0x07060302"))
     L += [salu("s_mov_b32 s52, 0"), salu("s_mov_b32 s53, 0"), salu("s_mov_b32 s50, 0"), salu("s_sub_u32 s51, %[nt], 1")]
     for st in range(3):
         L += stream_dma(st, force=True)
@@ -639,8 +644,9 @@ def main():
         OPT["pk_sum"] = not OPT["pk_sum"]            # the other form of the row sums (A/B)
         write("attn_pwg_lab6.inc", program())
         OPT["pk_sum"] = not OPT["pk_sum"]
-        OPT["lookahead"] = 3
+        OPT["trunc_pack"] = True
         write("attn_pwg_lab7.inc", program())
+        OPT["trunc_pack"] = False
         OPT["lookahead"] = 1
         OPT["trace"] = True
         write("attn_pwg_lab8.inc", program())

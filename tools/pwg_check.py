@@ -122,7 +122,7 @@ if args.time:
         print(f"round {rnd}: pwg {a:.1f} us = {fl / a / 1e6:.0f} TF/s   bounded {c:.1f} us = {fl / c / 1e6:.0f} TF/s   8-wave {b:.1f} us = {fl / b / 1e6:.0f} TF/s", flush=True)
     if args.ablate:
         names = {1: "product", 11: "no exp (v_mov)", 12: "no max / vote", 13: "no barrier", 14: "no LDS-DMA in the loop", 15: "MFMAs + reads only",
-                 16: "row sums: the other form (v_add_f32 pairs / v_pk_add_f32)", 17: "exp lookahead 3", 19: "row sums by MFMA", 0: "8-wave kernel"}
+                 16: "row sums: the other form (v_add_f32 pairs / v_pk_add_f32)", 17: "bf16 pack by v_perm_b32 (truncation, timing only)", 19: "row sums by MFMA", 0: "8-wave kernel"}
         for rnd in range(3):
             print("  ".join(f"[{names[k]}] {t(k, 10):.1f}" for k in names), flush=True)
     if args.trace:
