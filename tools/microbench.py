@@ -52,6 +52,7 @@ GEMMS = [  # name, M, N, K, mode
     ("trunk fc1 gelu", 10368, 3072, 768, "gelu"), ("trunk fc2+res", 10368, 768, 3072, "res"),
     ("dino qkv", 8224, 2304, 768, "bias"), ("dino fc1 gelu", 8224, 3072, 768, "gelu"), ("dino fc2+res", 8224, 768, 3072, "res"),
     ("dec fc+res", 65536, 768, 768, "res"), ("dec fc1 gelu", 65536, 3072, 768, "gelu"), ("dec fc2+res", 65536, 768, 3072, "res"),
+    ("dec fc2 bf16 stream", 65536, 768, 3072, "resb"), ("dec fc bf16 stream", 65536, 768, 768, "resb"),
     ("pcd fc2 M=64", 64, 768, 3072, "res"), ("pcd qkv M=64", 64, 2304, 768, "plain"),
     ("square 4096", 4096, 4096, 4096, "plain"),
 ]
@@ -64,6 +65,9 @@ if args.what in ("gemm", "all"):
         bias = torch.randn(N, device=dev)
         if mode == "res":
             out = torch.randn(M, N, device=dev)
+            fn = lambda: ops.gemm(a, w, out, residual=out)
+        elif mode == "resb":                  # the decoder's bf16 residual stream, updated in place
+            out = torch.randn(M, N, device=dev).to(dt)
             fn = lambda: ops.gemm(a, w, out, residual=out)
         elif mode == "gelu":
             out = torch.empty(M, N, device=dev, dtype=dt)
