@@ -429,8 +429,8 @@ constexpr int EP_WAVE_FLOATS = 32 * EP_LD;     // 8704 bytes per wave
 // colsum of its 64 columns.
 constexpr int EP_LN_FLOATS = 512;
 constexpr int ep_wave_floats(int actx) { return (actx & 8) ? EP_WAVE_FLOATS + EP_LN_FLOATS : EP_WAVE_FLOATS; }
-// Consumer side: the wave's rows' table entries, one (MI = 2) or two (MI = 4) per lane; kernels call this before their
-// prologue's LDS-DMA (older than every piece, so the counted vmcnt waits of the main loop retire it for free).
+// Consumer side: the table entry of one row per lane; kernels call this before their prologue's LDS-DMA (older than every piece,
+// so the counted vmcnt waits of the main loop retire it for free).
 // ep.ncb > 0: the table is the producer's unmerged one and the consumer merges the blocks of its rows between issuing its
 // prologue's LDS-DMA and the main loop (ln_finish: the table loads are older than every piece, the counted wait the compiler puts
 // in front of the merge leaves the pieces in flight).  Chan's update, block after block (blocks of 64 values):
