@@ -378,8 +378,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     };
 
     // LayerNorm fold, consumer (gemm_tile.h ln_prefetch / ln_finish): a wave fetches -- unmerged table: and merges -- 32 of its row of
-    // waves' 128 rows where registers are free: the FIRST tile's in front of the ring prologue (unmerged table: one exposed load
-    // round trip per workgroup), the NEXT tile's behind this tile's epilogue, in front of the drain that ends it anyway.  Only (rstd,
+    // waves' 128 rows where registers are free: the FIRST tile's around the ring prologue (entries requested in front of the pieces,
+    // merged behind them), the NEXT tile's behind this tile's epilogue, in front of the drain that ends it anyway.  Only (rstd,
     // -rstd mean) of one row and one colsum travel through the main loop (the accumulators leave no room for the entries: held
     // across it they spilled, and a scratch reload inside the loop waits out every LDS-DMA piece older than itself).
     float2* const ln_table = reinterpret_cast<float2*>(reinterpret_cast<float*>(smem + 2 * CHUNK10) + (wm * 4) * ep_wave_floats(ACT) + EP_WAVE_FLOATS);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     float ln_cs;
     {
         LnPreT<4> first;
-        ln_prefetch<ACT, 4>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, first, wn, ln_table);
+        ln_prefetch<ACT, 4, false>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, first, wn, ln_table);
         // prologue of the FIRST tile: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile
         // (12 in all at K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue
         const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;

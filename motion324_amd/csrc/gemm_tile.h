@@ -469,7 +469,9 @@ __device__ __forceinline__ float2 ln_entry(const char* table, unsigned block_byt
 // MI = 4: `table` is the row of waves' LDS table, wn the wave's column (it owns rows 32 wn .. 32 wn + 31 of the 128).  Unmerged
 // table: the lower lane half reads blocks 0 .. h - 1, the upper h .. ncb - 1, h = ncb / 2 (the host sends odd counts -- no width
 // of the product -- through m324_rowstats_finish).
-template <int ACTX, int MI>
+// IN_LOOP (MI = 4): the call sits inside v10's persistent tile loop (below); false: in front of it, where plain loads are safe and
+// their latency runs beside the ring prologue's pieces.
+template <int ACTX, int MI, bool IN_LOOP = true>
 __device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, int mw, int nw, int lane, LnPreT<MI>& pre, int wn = 0,
                                             float2* table = nullptr) {
     pre.rs = make_float2(0.f, 0.f);
@@ -481,6 +483,15 @@ __device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, in
         const int row = MI > 2 ? min(mw + 32 * wn + (lane & 31), M - 1) : min(mw + lane, M - 1);
         if (ep.ncb <= 0) {
             pre.rs = ep.rowstat[row];
+        } else if constexpr (MI > 2 && !IN_LOOP) {
+            const char* const tbl = reinterpret_cast<const char*>(ep.rowstat);
+            const int h = ep.ncb >> 1;
+            const unsigned bb = (unsigned)M * 8u, off = (unsigned)((lane >> 5) ? h : 0) * bb + (unsigned)row * 8u;
+#pragma unroll
+            for (int i = 0; i < LN_MAX_NCB / 2; ++i) {
+                const float2 p = ln_entry(tbl, bb, min(i, h - 1), off);
+                pre.raw_sum[i] = p.x, pre.raw_m2[i] = p.y;
+            }
         } else if constexpr (MI > 2) {
             // v10 calls this once per tile inside its persistent loop with 250 registers live.  Written as compiler-visible loads, the
             // (tile-invariant) per-block addresses were hoisted out of that loop into registers it does not have and came back
