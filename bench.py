@@ -331,7 +331,7 @@ def _event_time_ms(fn, steps: int) -> float:
     return e0.elapsed_time(e1) / steps
 
 
-def decoder_block_replay(model, sample, steps: int, q_branch: bool = True):
+def decoder_block_replay(model, sample, steps: int, q_mode: str = "pair"):
     """The north-star block (decoder cross-attention: k|v and q projections, attention, out-projection, MLP -- reference
     transformer.py:365-377 via Pcd_motion.py:556-561) as the product runs it: its launches captured into a hipGraph of their
     own and replayed back to back between two HIP events.  The block reads the trunk's REAL output stream of this clip
@@ -360,10 +360,16 @@ def decoder_block_replay(model, sample, steps: int, q_branch: bool = True):
         branch = torch.cuda.Stream()
 
         def block():
-            # as in the product's graph (Pcd_motion._forward, HOIST_DECODER_Q): the q projection depends on the mesh points
-            # only and runs on a second branch, here beside the k|v projection of the latent tokens
+            # q_mode "pair" (default): the block as the product's forward runs it when the q projection is inside the block (every
+            # eager forward; under graph capture Pcd_motion._forward hoists it onto the shape-encoder branch instead, where it costs
+            # the block nothing): norm_q + norm_kv in one launch, the q + k|v projections in one launch (transformer.project_q_kv).
+            # "branch": round 3's stand-in for the hoist -- the q side on a second graph branch beside the k|v side;
+            # "serial": four launches on one stream.
             main = torch.cuda.current_stream()
-            if not q_branch:
+            if q_mode == "pair":
+                Q, Kd, Vd = dec.project_q_kv(P, pf, N, tok, B * T, K, row_map=(K, Lt, 4))
+                return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q)
+            if q_mode == "serial":
                 Q = dec.project_q(P, pf, 1, N)
                 Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))
                 return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q)
@@ -394,8 +400,9 @@ def decoder_block_replay(model, sample, steps: int, q_branch: bool = True):
             "frac_of_bf16_peak": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
             "executed_gflop": round(fexe / 1e9, 1), "frac_executed_flops": round(fexe / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
             "rounds_ms": [round(r, 4) for r in rounds],
-            "timing": "hipGraph of the block alone (k|v projection with the q projection on a second branch as in the product's "
-                      "graph, attention, out-projection, MLP), replayed back to back between two HIP events (median of five rounds); input = this "
+            "q_mode": q_mode,
+            "timing": "hipGraph of the block alone (norm_q + norm_kv, q + k|v projections -- one launch each, as in the product's forward "
+                      "when the q projection is not hoisted --, attention, out-projection, MLP), replayed back to back between two HIP events (median of five rounds); input = this "
                       "clip's trunk output"}
 
 

@@ -114,6 +114,11 @@ typedef struct {
     int ln_ncb; float ln_eps;
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
+/* Two independent GEMMs in ONE launch (horizontal fusion of small latency-bound problems).  Built for the pair the hot path has:
+ * two bf16 projections with the head-major q|k|v epilogue that m324_gemm would run on the 128 x 128 chunk ring -- the decoder's
+ * q projection of the mesh points and k|v projection of the latent tokens (transformer.py:112-132 under Pcd_motion.py:556-560).
+ * Any other pair returns M324_ERR_UNSUPPORTED without launching anything: issue two m324_gemm calls. */
+int m324_gemm_pair(const m324_gemm_args* a, const m324_gemm_args* b, void* stream);
 /* Host-only: writes the kernel symbol (as rocprofv3 prints the template) and its grid in threads that m324_gemm would
  * launch for `a` into buf; returns the schedule number.  bench.py labels its per-launch HIP-event rows with it so that
  * they can be matched against the committed rocprofv3 summaries (profiles/). */
@@ -152,6 +157,11 @@ int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, float* C, lon
 int m324_layernorm(const float* x, long ldx, const float* w, const float* b, float eps,
                    void* y, long ldy, int out_dtype, int rows, int C,
                    int gin, int gout, int off, void* stream);
+/* Two of them (same C, same out_dtype) in one launch: problem 0 without row map, problem 1 with (gin1, gout1, off1) -- the decoder's
+ * norm_q over the mesh points and norm_kv over the gathered latent tokens (transformer.py:365-369). */
+int m324_layernorm_pair(const float* x0, long ldx0, const float* w0, const float* b0, float eps0, void* y0, long ldy0, int rows0,
+                        int gin0, int gout0, int off0, const float* x1, long ldx1, const float* w1, const float* b1, float eps1,
+                        void* y1, long ldy1, int rows1, int gin1, int gout1, int off1, int C, int out_dtype, void* stream);
 /* The same with the input's dtype given: x_dtype = M324_BF16 (bf16 output only) reads a bf16 residual stream -- the
  * decoder's in bf16 inference, where x is two additions deep and its LayerNorm output is rounded to bf16 anyway. */
 int m324_layernorm_in(const void* x, int x_dtype, long ldx, const float* w, const float* b, float eps,

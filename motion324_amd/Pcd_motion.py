@@ -554,20 +554,31 @@ class Motion_Latent_Model(nn.Module):
         w3, b3 = P.f32(head_fc2.weight), P.vec(head_fc2.bias)
         # reference FLOPs of the decoder cross-attention block (to_q counted once per frame as the
         # reference computes it) -- attached to the stage span bench.py reports the 40 % MFMA target on
-        with span("stage:decoder_cross_attn_block", self.decoder_block_flops(B, T, N)):
-            Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))       # latent tokens 4..4+K of every frame
         nchunk = max(1, min(N, DECODE_ROWS // T))
         pcd, nrm, rgb = (self._f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
+        paired = None
+        if hoisted is None and B == 1 and nchunk == N:
+            # one sample in one pass and the q projection inside the block: its LayerNorm / projection share their launches
+            # with the k|v side's (transformer.project_q_kv)
+            pf0 = self._point_features(P, pcd[0], nrm[0].contiguous(), rgb[0].contiguous())
+            with span("stage:decoder_cross_attn_block", self.decoder_block_flops(B, T, N)):
+                Q0, Kd, Vd = dec.project_q_kv(P, pf0, N, tok, B * T, K, row_map=(K, Lt, 4))
+            paired = (pf0, Q0)
+        else:
+            with span("stage:decoder_cross_attn_block", self.decoder_block_flops(B, T, N)):
+                Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))       # latent tokens 4..4+K of every frame
         for b in range(B):
             for n0 in range(0, N, nchunk):
                 n1 = min(N, n0 + nchunk)
                 if hoisted is not None:
                     pf, Q = hoisted[b]
+                elif paired is not None:
+                    pf, Q = paired
                 else:
                     pf = self._point_features(P, pcd[b, n0:n1], nrm[b, n0:n1].contiguous(), rgb[b, n0:n1].contiguous())
                 with span("stage:decoder_cross_attn_block", 0.0):
                     x, fold_d = self.decoder_block(P, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf,
-                                                   None if hoisted is None else Q)
+                                                   None if (hoisted is None and paired is None) else Q)
                 if cap is not None and n0 == 0 and n1 == N:
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
                 if fold_d is not None:

@@ -78,11 +78,10 @@ __global__ __launch_bounds__(256) void layernorm1_kernel(const TX* __restrict__ 
 }
 
 template <typename T, typename TX = float>
-__global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
-                                                        int rows, int C, int gin, int gout, int off) {
+__device__ __forceinline__ void ln_rows2(const TX* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                         float eps, T* __restrict__ y, long ldy, int rows, int C, int gin, int gout, int off, int block) {
     const int lane = threadIdx.x & 63;
-    const long row0 = (long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2;
+    const long row0 = (long)block * 8 + (threadIdx.x >> 6) * 2;
     if (row0 >= rows) return;
     const bool two = row0 + 1 < rows;
     const long row1 = two ? row0 + 1 : row0;                 // a lone last row is simply done twice (same values stored twice)
@@ -113,6 +112,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x
         store4<T>(yb + c, (vb[i].x - mb) * rb * ww.x + bb.x, (vb[i].y - mb) * rb * ww.y + bb.y,
                   (vb[i].z - mb) * rb * ww.z + bb.z, (vb[i].w - mb) * rb * ww.w + bb.w);
     }
+}
+
+template <typename T, typename TX = float>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
+                                                        int rows, int C, int gin, int gout, int off) {
+    ln_rows2<T, TX>(x, ldx, w, b, eps, y, ldy, rows, C, gin, gout, off, (int)blockIdx.x);
+}
+
+// Two LayerNorms of the same width in one launch (m324_layernorm_pair: the decoder's norm_q and norm_kv, 2048 rows each -- two
+// launches of a few microseconds whose cost is the launch).
+struct LnProblem {
+    const float* x; long ldx;
+    const float* w; const float* b; float eps;
+    void* y; long ldy;
+    int rows, gin, gout, off;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_pair_kernel(LnProblem p0, LnProblem p1, int C, int blocks0) {
+    if ((int)blockIdx.x < blocks0)
+        ln_rows2<T, float>(p0.x, p0.ldx, p0.w, p0.b, p0.eps, (T*)p0.y, p0.ldy, p0.rows, C, p0.gin, p0.gout, p0.off, (int)blockIdx.x);
+    else
+        ln_rows2<T, float>(p1.x, p1.ldx, p1.w, p1.b, p1.eps, (T*)p1.y, p1.ldy, p1.rows, C, p1.gin, p1.gout, p1.off, (int)blockIdx.x - blocks0);
 }
 
 // ----------------------------------------------------------------------------------- LayerNorm fold: row statistics
@@ -806,6 +828,22 @@ extern "C" int m324_layernorm(const float* x, long ldx, const float* w, const fl
                                           (T*)y, ldy, rows, C, gin, gout, off));
     }
     M324_CHECK_LAUNCH("m324_layernorm");
+    return M324_OK;
+}
+
+extern "C" int m324_layernorm_pair(const float* x0, long ldx0, const float* w0, const float* b0, float eps0, void* y0, long ldy0, int rows0,
+                                   int gin0, int gout0, int off0, const float* x1, long ldx1, const float* w1, const float* b1, float eps1,
+                                   void* y1, long ldy1, int rows1, int gin1, int gout1, int off1, int C, int out_dtype, void* stream) {
+    M324_REQUIRE(x0 && w0 && y0 && x1 && w1 && y1, "m324_layernorm_pair: null pointer");
+    M324_REQUIRE(rows0 > 0 && rows1 > 0, "m324_layernorm_pair: rows=%d, %d", rows0, rows1);
+    M324_REQUIRE(C % 4 == 0 && C > 0 && C <= 256 * LN_MAXV, "m324_layernorm_pair: C=%d unsupported", C);
+    M324_REQUIRE(ldx0 % 4 == 0 && ldy0 % 4 == 0 && ldx1 % 4 == 0 && ldy1 % 4 == 0, "m324_layernorm_pair: leading dims must be multiples of 4");
+    const LnProblem p0{x0, ldx0, w0, b0, eps0, y0, ldy0, rows0, gin0, gout0, off0}, p1{x1, ldx1, w1, b1, eps1, y1, ldy1, rows1, gin1, gout1, off1};
+    const int blocks0 = ceil_div(rows0, 8);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(out_dtype, "m324_layernorm_pair",
+                   hipLaunchKernelGGL(layernorm_pair_kernel<T>, dim3(blocks0 + ceil_div(rows1, 8)), dim3(256), 0, s, p0, p1, C, blocks0));
+    M324_CHECK_LAUNCH("m324_layernorm_pair");
     return M324_OK;
 }
 

@@ -489,17 +489,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
 // 2 x 2 accumulator block per wave (a phase is 4 MFMAs, 4 fragment reads and 2 LDS-DMA pieces).
 constexpr int CHUNK13 = 128 * ROWB;               // 16 KiB
 
+// (the body of one workgroup = one tile; gemm_ring2_kernel runs it on its own grid, gemm_ring2_pair_kernel on one of two problems)
 template <typename TOUT, int ACT, int RES>
-__global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
-                                                            long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
-                                                            int xcd_remap) {
+__device__ __forceinline__ void ring2_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw, TOUT* C, long ldc,
+                                           int M, int N, int K, const Epilogue& ep, int ntn, int xcd_remap, int tile, int ntiles) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * CHUNK13];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, (M + BM - 1) / BM, ntn, xcd_remap, tm, tn);
+    tile_of(tile, ntiles, (M + BM - 1) / BM, ntn, xcd_remap, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // LDS-DMA: a wave-instruction fills 8 rows x 128 B; wave w moves row groups 4w .. 4w+3 of A and of W
@@ -603,6 +603,32 @@ __global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __rest
     M324_BARRIER();
     store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 64,
                                       n0 + wn * 64, lane, ep, &ln_pre);
+}
+
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(256, 2) void gemm_ring2_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                            long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
+                                                            int xcd_remap) {
+    ring2_tile<TOUT, ACT, RES>(A, lda, W, ldw, C, ldc, M, N, K, ep, ntn, xcd_remap, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two independent problems in one launch (m324_gemm_pair: the decoder's q and k|v projections -- 96 and 192 tiles, each a 12-stage
+// latency chain at 2048 rows; two launches run them one after the other at the clock the MLP before them left behind).
+struct Ring2Problem {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    void* C; long ldc;
+    int M, N, K;
+    Epilogue ep;
+    int ntn, xcd_remap, tiles;
+};
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(256, 2) void gemm_ring2_pair_kernel(Ring2Problem p0, Ring2Problem p1) {
+    if ((int)blockIdx.x < p0.tiles)
+        ring2_tile<TOUT, ACT, RES>(p0.A, p0.lda, p0.W, p0.ldw, (TOUT*)p0.C, p0.ldc, p0.M, p0.N, p0.K, p0.ep, p0.ntn, p0.xcd_remap, (int)blockIdx.x, p0.tiles);
+    else
+        ring2_tile<TOUT, ACT, RES>(p1.A, p1.lda, p1.W, p1.ldw, (TOUT*)p1.C, p1.ldc, p1.M, p1.N, p1.K, p1.ep, p1.ntn, p1.xcd_remap,
+                                   (int)blockIdx.x - p0.tiles, p1.tiles);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1033,16 +1059,20 @@ static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& e
     M324_FAIL(M324_ERR_UNSUPPORTED, "m324_gemm: no pipelined kernel for schedule %d", variant);
 }
 
+static Epilogue make_epilogue(const m324_gemm_args* a) {
+    return Epilogue{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off,
+                    a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode,
+                    {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
+                    a->qkv_L, a->qkv_H, a->aux_mode == M324_AUX_QKV_HEADS_VT ? 1 : 0,
+                    (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > ((long)m324::tunable(m324::TUN_NT_MB) << 20)) ? 1 : 0,
+                    (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0,
+                    reinterpret_cast<const float2*>(a->ln_rowstat), a->ln_colsum, reinterpret_cast<float2*>(a->ln_stats_out),
+                    static_cast<bf16_t*>(a->ln_copy_out), a->ln_ldcopy, a->ln_rowstat ? a->ln_ncb : 0, a->ln_eps};
+}
+
 template <typename TIN, typename TOUT>
 int launch(const m324_gemm_args* a, hipStream_t s) {
-    Epilogue ep{a->bias, a->gamma, a->residual, a->ldr, a->res_rows, a->act, a->row_gin, a->row_gout, a->row_off,
-                a->strideA, a->strideW, a->strideC, a->aux, a->ldaux, a->aux_mode,
-                {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
-                a->qkv_L, a->qkv_H, a->aux_mode == M324_AUX_QKV_HEADS_VT ? 1 : 0,
-                (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > ((long)m324::tunable(m324::TUN_NT_MB) << 20)) ? 1 : 0,
-                (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0,
-                reinterpret_cast<const float2*>(a->ln_rowstat), a->ln_colsum, reinterpret_cast<float2*>(a->ln_stats_out),
-                static_cast<bf16_t*>(a->ln_copy_out), a->ln_ldcopy, a->ln_rowstat ? a->ln_ncb : 0, a->ln_eps};
+    const Epilogue ep = make_epilogue(a);
     dim3 grid(ceil_div(a->N, BN), ceil_div(a->M, BM));
     const int nbatch = a->batch > 1 ? a->batch : 1;
     const bool lnf = a->ln_rowstat || a->ln_stats_out || a->ln_copy_out;     // LayerNorm fold: the ACT | 8 instantiations
@@ -1226,7 +1256,7 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
     return M324_OK;
 }
 
-extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
+static int gemm_validate(const m324_gemm_args* a) {
     const bool qkv_mode = a && (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT);
     const bool n3_mode = a && a->aux_mode == M324_AUX_N3;
     M324_REQUIRE(a && a->A && a->W && (a->C || qkv_mode || n3_mode), "m324_gemm: null pointer");
@@ -1315,10 +1345,40 @@ extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
                                          ((uintptr_t)a->ln_copy_out % 8) == 0),
                      "m324_gemm: ln_copy_out is the bf16 twin of an fp32 output (ldcopy >= N, multiple of 4, 8-byte aligned)");
     }
+    return M324_OK;
+}
+
+extern "C" int m324_gemm(const m324_gemm_args* a, void* stream) {
+    const int rc = gemm_validate(a);
+    if (rc != M324_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_BF16) return launch<bf16_t, bf16_t>(a, s);
     if (a->in_dtype == M324_BF16 && a->out_dtype == M324_F32) return launch<bf16_t, float>(a, s);
     if (a->in_dtype == M324_F32 && a->out_dtype == M324_F32) return launch<float, float>(a, s);
     M324_FAIL(M324_ERR_UNSUPPORTED, "m324_gemm: unsupported dtype pair in=%d out=%d", a->in_dtype, a->out_dtype);
+}
+
+// Two GEMMs in ONE launch (horizontal fusion).  Built for the pair that needs it: two bf16 projections with the head-major q|k|v
+// epilogue that the chooser sends to the 128 x 128 chunk ring (the decoder's q and k|v projections).  Any other pair:
+// M324_ERR_UNSUPPORTED and nothing launched -- the caller issues two m324_gemm calls.
+extern "C" int m324_gemm_pair(const m324_gemm_args* a, const m324_gemm_args* b, void* stream) {
+    int rc = gemm_validate(a);
+    if (rc != M324_OK) return rc;
+    rc = gemm_validate(b);
+    if (rc != M324_OK) return rc;
+    auto heads = [](const m324_gemm_args* g) {
+        return (g->aux_mode == M324_AUX_QKV_HEADS || g->aux_mode == M324_AUX_QKV_HEADS_VT) && g->in_dtype == M324_BF16 && g->out_dtype == M324_BF16 &&
+               !g->residual && !g->ln_rowstat && !g->ln_stats_out && !g->ln_copy_out && g->batch <= 1 && g->act == M324_ACT_NONE;
+    };
+    if (!heads(a) || !heads(b) || pick_variant(a) != 13 || pick_variant(b) != 13)
+        M324_FAIL(M324_ERR_UNSUPPORTED, "m324_gemm_pair: built for two bf16 head-major projections on the 128 x 128 chunk ring");
+    auto problem = [](const m324_gemm_args* g) {
+        return Ring2Problem{(const bf16_t*)g->A, g->lda, (const bf16_t*)g->W, g->ldw, g->C, g->ldc, g->M, g->N, g->K, make_epilogue(g),
+                            ceil_div(g->N, BN), xcd_mode(g), ceil_div(g->N, BN) * ceil_div(g->M, BM)};
+    };
+    const Ring2Problem p0 = problem(a), p1 = problem(b);
+    hipLaunchKernelGGL((gemm_ring2_pair_kernel<bf16_t, 4, 0>), dim3(p0.tiles + p1.tiles), dim3(256), 0, (hipStream_t)stream, p0, p1);
+    M324_CHECK_LAUNCH("m324_gemm_pair");
+    return M324_OK;
 }
 

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
+ERR_UNSUPPORTED = -3          # m324_status M324_ERR_UNSUPPORTED
 
 
 class M324Error(RuntimeError):
@@ -55,6 +56,7 @@ SIGNATURES = {
     "m324_set_tunable": [C.c_char_p, _I],
     "m324_gemm": [C.POINTER(GemmArgs), _P],
     "m324_gemm_plan": [C.POINTER(GemmArgs), C.c_char_p, _I],
+    "m324_gemm_pair": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _P],
     "m324_attention_plan": [_I, _I, _I, _I, _I, _I, C.c_char_p, _I],
     "m324_gemm_tn": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _L, _P],
     "m324_n3_finish": [_P, _I, _I, _P, _P, _P],
@@ -62,6 +64,7 @@ SIGNATURES = {
     "m324_rowstats": [_P, _L, _I, _I, _F, _P, _P, _L, _P],
     "m324_layernorm": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_layernorm_in": [_P, _I, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "m324_layernorm_pair": [_P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _P, _L, _P, _P, _F, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "m324_qkv_split": [_P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m324_attention": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _I, _P, _I, _P],
     "m324_patchify": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -145,7 +145,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
          residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0),
          preact_out: Optional[torch.Tensor] = None, gelu_grad_of: Optional[torch.Tensor] = None,
          qkv_heads: Optional[tuple] = None, n3: Optional[tuple] = None, ln: Optional[tuple] = None,
-         stats_out: Optional[torch.Tensor] = None, copy_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         stats_out: Optional[torch.Tensor] = None, copy_out: Optional[torch.Tensor] = None, defer: Optional[list] = None) -> torch.Tensor:
     """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm.
     preact_out [M, N] (out's dtype) also receives the value the activation is applied to (M324_AUX_STORE_PREACT);
     gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only.
@@ -153,6 +153,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     [B, H, L, 64] with per-head RMSNorm and the q pre-scale (M324_AUX_QKV_HEADS); `out` is ignored (may be None).
     A V of shape [B, H, 64, L] selects M324_AUX_QKV_HEADS_VT: V leaves transposed and key-permuted, the operand
     attention() reads by default (L % 128 == 0).
+    defer (qkv_heads only): a list that receives the prepared call instead of a launch; gemm_pair(list) then runs two of them
+    as ONE launch (m324_gemm_pair).
     LayerNorm fold (include/m324.h): ln = (rowstat fp32 [M, 2], colsum fp32 [N]) -- `a` is the raw stream, `w` carries the
     LayerNorm scale; ln = (part fp32 [K / 64, M, 2], colsum, eps): the producer's stats_out itself, merged by this GEMM; stats_out fp32 [N / 64, M, 2] receives the per-block row statistics of the stored values and copy_out
     bf16 [M, N] their bf16 twin (fp32 `out` only)."""
@@ -205,6 +207,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
         args.qkv_qw, args.qkv_kw = _vec(qw, 64, "q_w"), _vec(kw, 64, "k_w")
         first = next(t for t in (Qo, Ko, Vo) if t is not None)
         args.qkv_eps, args.qkv_qscale, args.qkv_L, args.qkv_H = eps, q_scale, Lh, Hh
+        if defer is not None:                       # gemm_pair() launches it together with another one
+            defer.append((args, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), f"M={M} N={N} K={K} qkv-heads", (a, w, bias, Qo, Ko, Vo, qw, kw)))
+            return first
         with span("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N),
                   f"{_gemm_plan(args)} | M={M} N={N} K={K} qkv-heads" if _timing() else ""):
             L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
@@ -266,6 +271,45 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     with span(f"gemm_{'bf16' if esz == 2 else 'f32'}", 2.0 * M * N * K, nbytes, tag):
         L.check(L.load().m324_gemm(C.byref(args), _stream()), "m324_gemm")
     return out
+
+
+def gemm_pair(deferred: list) -> None:
+    """Launch the two projections prepared with gemm(..., qkv_heads=..., defer=deferred) as one kernel (m324_gemm_pair: horizontal
+    fusion of two small latency-bound GEMMs); pairs the library does not build run as two m324_gemm launches."""
+    if len(deferred) != 2:
+        raise L.M324Error("gemm_pair: exactly two deferred projections")
+    (a0, f0, b0, t0, _), (a1, f1, b1, t1, _) = deferred
+    lib = L.load()
+    with span("gemm_bf16", f0 + f1, b0 + b1, f"gemm_ring2_pair_kernel<unsigned short, 4, 0> | {t0} + {t1}" if _timing() else ""):
+        rc = lib.m324_gemm_pair(C.byref(a0), C.byref(a1), _stream())
+    if rc == L.ERR_UNSUPPORTED:
+        for args, fl, by, tag, _ in deferred:
+            with span("gemm_bf16", fl, by, f"{_gemm_plan(args)} | {tag}" if _timing() else ""):
+                L.check(lib.m324_gemm(C.byref(args), _stream()), "m324_gemm")
+    else:
+        L.check(rc, "m324_gemm_pair")
+    deferred.clear()
+
+
+def layernorm_pair(x0, w0, b0, eps0, out0, x1, w1, b1, eps1, out1, row_map1=(0, 0, 0)) -> None:
+    """Two fp32 -> out-dtype LayerNorms of the same width in one launch (m324_layernorm_pair); the second may gather its rows
+    (row_map1 as in layernorm)."""
+    Cdim = x0.shape[1]
+    if (x0.dtype != torch.float32 or x1.dtype != torch.float32 or x1.shape[1] != Cdim or out0.shape[1] != Cdim or out1.shape[1] != Cdim
+            or out0.dtype != out1.dtype or out0.shape[0] > x0.shape[0]):
+        raise L.M324Error("layernorm_pair: two fp32 inputs of one width, outputs of one dtype")
+    gin, gout, off = row_map1
+    rows1 = out1.shape[0]
+    need = ((rows1 - 1) // gin * gout + (rows1 - 1) % gin + off + 1) if gin > 0 else rows1
+    if x1.shape[0] < need:
+        raise L.M324Error("layernorm_pair: shape mismatch")
+    (p0, l0), (q0, m0), (p1, l1), (q1, m1) = _rows(x0, "x0"), _rows(out0, "out0"), _rows(x1, "x1"), _rows(out1, "out1")
+    tag = f"layernorm_pair_kernel | rows={out0.shape[0]}+{rows1} C={Cdim}" if _timing() else ""
+    with span("hbm_pass", 0.0, float(out0.shape[0] + rows1) * Cdim * (4 + out0.element_size()), tag):
+        L.check(L.load().m324_layernorm_pair(p0, l0, _vec(w0, Cdim, "w0"), _vec(b0, Cdim, "b0"), eps0, q0, m0, out0.shape[0], 0, 0, 0,
+                                             p1, l1, _vec(w1, Cdim, "w1"), _vec(b1, Cdim, "b1"), eps1, q1, m1, rows1, gin, gout, off,
+                                             Cdim, code_of(out0.dtype), _stream()), "m324_layernorm_pair")
+    _wrote(out0, out1)
 
 
 def rowstats_finish(part: torch.Tensor, eps: float, rowstat: torch.Tensor) -> torch.Tensor:

@@ -21,6 +21,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_OVERLAP": ("1", "Pcd_motion.OVERLAP_SHAPE_ENCODER", "inference: shape encoder on a second HIP stream under the image encoder"),
     "M324_FOLD_LN": ("2", "transformer.FOLD_LN", "LayerNorm fold: 0 off, 1 bf16 streams only (the decoder), 2 every stream (trunk, DINO too)"),
     "M324_FOLD_MERGE": ("1", "transformer.FOLD_MERGE", "LayerNorm fold: the consumer GEMM merges the producer's per-block row statistics itself (0: m324_rowstats_finish launch between them)"),
+    "M324_PAIR_PROJ": ("1", "transformer.PAIR_PROJ", "bf16 inference, decoder: norm_q + norm_kv in one launch and the q + k|v projections in one launch when the q projection runs inside the block (0: four launches)"),
     "M324_ATTN_BOUNDED": ("1", "transformer.ATTN_BOUNDED", "bf16 inference, long sequences: softmax without a reference maximum when the q / k RMSNorm weights bound every score (M324_ATTN_SCORES_BOUNDED)"),
     "M324_FUSE_QKV": ("1", "transformer.FUSE_QKV", "bf16 inference: q|k|v projection epilogue writes head-major Q / K / V (RMSNorm, pre-scale)"),
     "M324_FUSE_QKV_VT": ("1", "transformer.FUSE_QKV_VT", "the same for long sequences: the epilogue writes the transposed, key-permuted V"),

@@ -129,6 +129,7 @@ class QK_Norm_CrossAttention(_AttnBase):
 #     (the launch form: 8.98), so M324_FOLD_LN=2, every stream, is the default since round 4.
 # M324_FOLD_LN=1 folds the bf16 streams only, =0 restores every separate pass.
 FOLD_LN = int(switches.get("M324_FOLD_LN"))
+PAIR_PROJ = switches.flag("M324_PAIR_PROJ")         # the decoder's q and k|v LayerNorms / projections as two launches instead of four
 FOLD_MERGE = switches.flag("M324_FOLD_MERGE")      # folded consumers merge the producer's per-block statistics themselves
 ATTN_BOUNDED = switches.flag("M324_ATTN_BOUNDED")
 
@@ -355,6 +356,34 @@ class QK_Norm_CrossAttentionBlock(nn.Module):
         ops.gemm(kn, w_kv, kvp, bias=b_kv)
         _, K, Vt = ops.qkv_split(None, kvp[:, :a.dim], kvp[:, a.dim:], None, kw, RMS_EPS, B, Lk, a.num_heads, P.dtype)
         return K, Vt
+
+    def project_q_kv(self, P: Prepared, query: torch.Tensor, Lq: int, kv: torch.Tensor, Bk: int, Lk: int, row_map=(0, 0, 0)):
+        """project_q(query, 1, Lq) and project_kv(kv, Bk, Lk, row_map) as TWO launches instead of four: both LayerNorms in one
+        (m324_layernorm_pair), both projections in one (m324_gemm_pair).  At 2048 rows each of the four is a latency chain of a
+        few microseconds of work; the decoder runs them back to back when the q projection is not hoisted out of the block
+        (eager forward, M324_HOIST_Q=0, bench.py's block).  Same kernels' arithmetic: results are bit-identical to the two calls."""
+        a = self.attn
+        if not (PAIR_PROJ and fuse_proj(P, Lq) and fuse_proj(P, Bk * Lk) and Lk % 64 == 0 and query.shape[1] == kv.shape[1]
+                and query.dtype == torch.float32 and kv.dtype == torch.float32):
+            Q = self.project_q(P, query, 1, Lq)
+            K, Vt = self.project_kv(P, kv, Bk, Lk, row_map=row_map)
+            return Q, K, Vt
+        dev = query.device
+        qn = torch.empty(query.shape, dtype=P.dtype, device=dev)
+        kn = torch.empty((Bk * Lk, kv.shape[1]), dtype=P.dtype, device=dev)
+        ops.layernorm_pair(query, P.vec(self.norm_q.weight), P.vec(self.norm_q.bias), self.norm_q.eps, qn,
+                           kv, P.vec(self.norm_kv.weight), P.vec(self.norm_kv.bias), self.norm_kv.eps, kn, row_map1=row_map)
+        qw, kw = a._qk_w(P)
+        Q = torch.empty((1, a.num_heads, Lq, 64), dtype=P.dtype, device=dev)
+        K = torch.empty((Bk, a.num_heads, Lk, 64), dtype=P.dtype, device=dev)
+        Vt = torch.empty((Bk, a.num_heads, 64, Lk), dtype=P.dtype, device=dev)
+        w_kv, b_kv = P.cat_rows((a.to_k.weight, a.to_v.weight)), P.cat_vecs((a.to_k.bias, a.to_v.bias))
+        pair: list = []
+        ops.gemm(qn, P.mat(a.to_q.weight), None, bias=P.vec(a.to_q.bias),
+                 qkv_heads=(Q, None, None, qw, None, RMS_EPS, ops.Q_PRESCALE, Lq, a.num_heads), defer=pair)
+        ops.gemm(kn, w_kv, None, bias=b_kv, qkv_heads=(None, K, Vt, None, kw, RMS_EPS, 1.0, Lk, a.num_heads, True), defer=pair)
+        ops.gemm_pair(pair)
+        return Q, K, Vt
 
     def attend(self, P: Prepared, Q, K, Vt, residual: torch.Tensor, res_rows: int, shared_q: bool,
                bf16_stream: bool = False, want_fold: bool = False):

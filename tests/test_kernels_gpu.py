@@ -993,6 +993,53 @@ def _folded(lnw, lnb, w, b):
     return wf, colsum, bias
 
 
+def test_layernorm_pair_and_gemm_pair_equal_the_separate_launches():
+    """m324_layernorm_pair / m324_gemm_pair (horizontal fusion of the decoder's norm_q + norm_kv and q + k|v projections): the
+    same bits as four separate launches, including the gathered rows of the second LayerNorm; a pair the library does not build
+    falls back to two launches.  Reference transformer.py:112-132,365-369."""
+    ops = _ops()
+    dt = torch.bfloat16
+    C, H, N, T, K, Lt = 768, 12, 2048, 8, 64, 324
+    pf, tok = _rand((N, C), 401).to(DEV), _rand((T * Lt, C), 402).to(DEV)
+    lw = [(1 + 0.1 * _rand((C,), 403 + i)).to(DEV) for i in range(2)]
+    lb = [(0.1 * _rand((C,), 405 + i)).to(DEV) for i in range(2)]
+    wq, wkv = _rand((C, C), 407, 0.05).to(dt).to(DEV), _rand((2 * C, C), 408, 0.05).to(dt).to(DEV)
+    bq, bkv = _rand((C,), 409, 0.1).to(DEV), _rand((2 * C,), 410, 0.1).to(DEV)
+    qw, kw = (1 + 0.1 * _rand((64,), 411)).to(DEV), (1 + 0.1 * _rand((64,), 412)).to(DEV)
+    rm = (K, Lt, 4)
+
+    def outs():
+        return (torch.full((1, H, N, 64), float("nan"), dtype=dt, device=DEV), torch.full((T, H, K, 64), float("nan"), dtype=dt, device=DEV),
+                torch.full((T, H, 64, K), float("nan"), dtype=dt, device=DEV))
+    # separate launches
+    qn, kn = torch.empty((N, C), dtype=dt, device=DEV), torch.empty((T * K, C), dtype=dt, device=DEV)
+    ops.layernorm(pf, lw[0], lb[0], 1e-5, qn)
+    ops.layernorm(tok, lw[1], lb[1], 1e-5, kn, row_map=rm)
+    Q0, K0, V0 = outs()
+    ops.gemm(qn, wq, None, bias=bq, qkv_heads=(Q0, None, None, qw, None, 1e-5, ops.Q_PRESCALE, N, H))
+    ops.gemm(kn, wkv, None, bias=bkv, qkv_heads=(None, K0, V0, None, kw, 1e-5, 1.0, K, H, True))
+    # paired
+    qn2, kn2 = torch.full_like(qn, float("nan")), torch.full_like(kn, float("nan"))
+    ops.layernorm_pair(pf, lw[0], lb[0], 1e-5, qn2, tok, lw[1], lb[1], 1e-5, kn2, row_map1=rm)
+    assert torch.equal(qn2, qn) and torch.equal(kn2, kn)
+    Q1, K1, V1 = outs()
+    pair = []
+    ops.gemm(qn2, wq, None, bias=bq, qkv_heads=(Q1, None, None, qw, None, 1e-5, ops.Q_PRESCALE, N, H), defer=pair)
+    ops.gemm(kn2, wkv, None, bias=bkv, qkv_heads=(None, K1, V1, None, kw, 1e-5, 1.0, K, H, True), defer=pair)
+    assert torch.isnan(Q1.float()).all()                     # nothing launched yet
+    ops.gemm_pair(pair)
+    assert torch.equal(Q1, Q0) and torch.equal(K1, K0) and torch.equal(V1, V0)
+    # a pair the library does not build (K = 64: the two-stage kernel, not the chunk ring): two launches, same results
+    a64, w64 = _rand((256, 64), 413).to(dt).to(DEV), _rand((C, 64), 414, 0.1).to(dt).to(DEV)
+    Qa, Qb, Qc = (torch.full((1, H, 256, 64), float("nan"), dtype=dt, device=DEV) for _ in range(3))
+    ops.gemm(a64, w64, None, bias=bq, qkv_heads=(Qa, None, None, qw, None, 1e-5, 1.0, 256, H))
+    pair = []
+    ops.gemm(a64, w64, None, bias=bq, qkv_heads=(Qb, None, None, qw, None, 1e-5, 1.0, 256, H), defer=pair)
+    ops.gemm(a64, w64, None, bias=bq, qkv_heads=(Qc, None, None, qw, None, 1e-5, 1.0, 256, H), defer=pair)
+    ops.gemm_pair(pair)
+    assert torch.equal(Qb, Qa) and torch.equal(Qc, Qa)
+
+
 def _block_table(xb: torch.Tensor) -> torch.Tensor:
     """What a producer GEMM leaves for the rows of its output: [K / 64, M, 2] (sum, sum of squared deviations from the block mean)."""
     M, K = xb.shape
