@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     // merged behind them), the NEXT tile's behind this tile's epilogue, in front of the drain that ends it anyway.  Only (rstd,
     // -rstd mean) of one row and one colsum travel through the main loop (the accumulators leave no room for the entries: held
     // across it they spilled, and a scratch reload inside the loop waits out every LDS-DMA piece older than itself).
-    float2* const ln_table = reinterpret_cast<float2*>(reinterpret_cast<float*>(smem + 2 * CHUNK10) + (wm * 4) * ep_wave_floats(ACT) + EP_WAVE_FLOATS);
+    const int ln_table = EP_WAVE_FLOATS - wn * ep_wave_floats(ACT);      // floats from this wave's scratch to its row of waves' table
     float2 ln_rs;
     float ln_cs;
     {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         const int mt = m0, nt = n0;                         // this tile's origin (m0 / n0 move on in front of the epilogue)
         const bool more = t + (int)gridDim.x < ntiles;
         LnPreT<4> ln_pre;
-        ln_pre.rs = ln_rs, ln_pre.cs = ln_cs, ln_pre.table = ln_table, ln_pre.slot = 32 * wn;
+        ln_pre.rs = ln_rs, ln_pre.cs = ln_cs, ln_pre.table_off = ln_table, ln_pre.slot = 32 * wn;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -450,7 +450,7 @@ struct LnPreT {
     // ncb > 0: the row's (half of the) block entries until ln_finish -- vector VALUES, not an array member: an array's
     // `#pragma unroll` loops are unrolled after the pass that turns arrays into registers, and the entries went through scratch
     std::conditional_t<(MI > 2), ln_f32x8, ln_f32x16> raw_sum, raw_m2;
-    float2* table;               // MI = 4: the row of waves' shared (rstd, -rstd mean) table in LDS
+    int table_off;               // MI = 4: the row of waves' shared (rstd, -rstd mean) table in LDS, in floats from the wave's own scratch
     int slot;                    // ... and this wave's first row in it
 };
 // one block more (cnt blocks merged so far); `take` false leaves the pair as it is (no branch: the lane halves of MI = 4 differ)
@@ -473,11 +473,12 @@ __device__ __forceinline__ float2 ln_entry(const char* table, unsigned block_byt
 // their latency runs beside the ring prologue's pieces.
 template <int ACTX, int MI, bool IN_LOOP = true>
 __device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, int mw, int nw, int lane, LnPreT<MI>& pre, int wn = 0,
-                                            float2* table = nullptr) {
+                                            int table_off = 0) {
     pre.rs = make_float2(0.f, 0.f);
     pre.cs = 0.f;
-    pre.table = table;
+    pre.table_off = table_off;
     pre.slot = 32 * wn;
+    if constexpr (MI > 2 && IN_LOOP) asm volatile("" : "+v"(lane));      // tile-local: see the opaque copies below
     if constexpr ((ACTX & 8) != 0) {
         pre.cs = ep.colsum[min(nw + lane, N - 1)];
         const int row = MI > 2 ? min(mw + 32 * wn + (lane & 31), M - 1) : min(mw + lane, M - 1);
@@ -495,27 +496,30 @@ __device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, in
         } else if constexpr (MI > 2) {
             // v10 calls this once per tile inside its persistent loop with 250 registers live.  Written as compiler-visible loads, the
             // (tile-invariant) per-block addresses were hoisted out of that loop into registers it does not have and came back
-            // from scratch one by one; so: eight loads from uniform block bases + ONE 32-bit lane offset and their wait in one block.
+            // from scratch one by one; so: eight loads from ONE uniform base + 32-bit lane offsets and their wait in one block.
             // vmcnt(0): at both call sites nothing else this wave has in flight is wanted later than these entries.
-            const char* const tbl = reinterpret_cast<const char*>(ep.rowstat);
-            const unsigned bb = (unsigned)M * 8u;
-            const int h = ep.ncb >> 1;                      // host: an even block count
+            const char* tbl = reinterpret_cast<const char*>(ep.rowstat);
+            unsigned bb = (unsigned)M * 8u;
+            int h = ep.ncb >> 1;                            // host: an even block count
+            // opaque copies: nothing below may be hoisted out of the tile loop (the loop has neither the scalar nor the vector
+            // registers for tile-invariant addresses; hoisted, they went to VGPR lanes and from there to scratch)
+            asm volatile("" : "+s"(tbl), "+s"(bb), "+s"(h));
             const unsigned off = (unsigned)((lane >> 5) ? h : 0) * bb + (unsigned)row * 8u;
-            const char* b[LN_MAX_NCB / 2];
+            unsigned o[LN_MAX_NCB / 2];                     // per-block lane offsets: vector registers are free behind the epilogue
 #pragma unroll
-            for (int i = 0; i < LN_MAX_NCB / 2; ++i) b[i] = tbl + (size_t)((unsigned)min(i, h - 1) * bb);
+            for (int i = 0; i < LN_MAX_NCB / 2; ++i) o[i] = off + (unsigned)min(i, h - 1) * bb;
             f32x2 e0, e1, e2, e3, e4, e5, e6, e7;
-            asm volatile("global_load_dwordx2 %0, %8, %9\n\t"
-                         "global_load_dwordx2 %1, %8, %10\n\t"
-                         "global_load_dwordx2 %2, %8, %11\n\t"
-                         "global_load_dwordx2 %3, %8, %12\n\t"
-                         "global_load_dwordx2 %4, %8, %13\n\t"
-                         "global_load_dwordx2 %5, %8, %14\n\t"
-                         "global_load_dwordx2 %6, %8, %15\n\t"
-                         "global_load_dwordx2 %7, %8, %16\n\t"
+            asm volatile("global_load_dwordx2 %0, %8, %16\n\t"
+                         "global_load_dwordx2 %1, %9, %16\n\t"
+                         "global_load_dwordx2 %2, %10, %16\n\t"
+                         "global_load_dwordx2 %3, %11, %16\n\t"
+                         "global_load_dwordx2 %4, %12, %16\n\t"
+                         "global_load_dwordx2 %5, %13, %16\n\t"
+                         "global_load_dwordx2 %6, %14, %16\n\t"
+                         "global_load_dwordx2 %7, %15, %16\n\t"
                          "s_waitcnt vmcnt(0)"
                          : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7)
-                         : "v"(off), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]), "s"(b[4]), "s"(b[5]), "s"(b[6]), "s"(b[7])
+                         : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]), "s"(tbl)
                          : "memory");
             pre.raw_sum = ln_f32x8{e0[0], e1[0], e2[0], e3[0], e4[0], e5[0], e6[0], e7[0]};
             pre.raw_m2 = ln_f32x8{e0[1], e1[1], e2[1], e3[1], e4[1], e5[1], e6[1], e7[1]};
@@ -594,8 +598,12 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
     if (fold) {                                              // DS operations of a wave execute in order: no barrier needed
         csl[lane] = pre ? pre->cs : ep.colsum[min(nw + lane, N - 1)];
         if (MI > 2 && pre) {                                 // the four waves of a row of waves fetched / merged 32 rows each (ln_prefetch)
-            rsl = pre->table;
-            if (lane < 32) rsl[pre->slot + lane] = pre->rs;
+            // opaque offset / lane: addresses into the shared table are rebuilt per tile -- as tile-invariants of v10's persistent
+            // loop they were spilled, and a scratch reload in the epilogue waits out the next tile's chunks in flight (vmcnt)
+            int toff = pre->table_off, lf = lane;
+            asm volatile("" : "+s"(toff), "+v"(lf));
+            rsl = reinterpret_cast<float2*>(scr + toff);
+            if (lf < 32) rsl[pre->slot + lf] = pre->rs;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave of the workgroup runs this epilogue
         } else {
             rsl[lane] = pre ? pre->rs : ln_row_direct(ep, M, min(mw + lane, M - 1));
