@@ -580,6 +580,12 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                                                int nw, int lane, const Epilogue& ep, const LnPreT<MI>* pre = nullptr) {
     constexpr int ACT = ACTX & 7;
     constexpr bool fold = (ACTX & 8) != 0, STATS = (ACTX & 16) != 0, COPY = (ACTX & 32) != 0;
+    // The 256-wide kernels call this once per tile from a persistent loop that runs at the register limit.  Lane-derived
+    // addresses / row indices of the epilogue are tile-invariant, so the compiler hoists them out of that loop -- into registers
+    // the main loop does not have: they were spilled, and every scratch reload in here brings an `s_waitcnt vmcnt(0)` that drains
+    // the epilogue's own stores and the next tile's LDS-DMA chunks in flight (nine drains per tile in the statistics producer).
+    // An opaque copy of the lane index makes all of it tile-local: a few dozen VALU instructions per tile instead.
+    if constexpr (MI > 2) asm volatile("" : "+v"(lane));
     const bool has_res = RES == 0 ? false : (RES == 1 ? true : ep.residual != nullptr);
     const bool res_mod = (RES == 0 || RES == 1) ? false : (ep.res_rows > 0 && ep.res_rows < M);
     const bool remap = (RES == 0 || RES == 1) ? false : ep.row_gin > 0;
