@@ -610,7 +610,10 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
             asm volatile("" : "+s"(toff), "+v"(lf));
             rsl = reinterpret_cast<float2*>(scr + toff);
             if (lf < 32) rsl[pre->slot + lf] = pre->rs;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave of the workgroup runs this epilogue
+            // every wave of the workgroup runs this epilogue.  (The marker exempts this barrier from tools/audit_barriers.py's "vmcnt
+            // wait in front of every barrier" rule: it orders writes / reads of epilogue scratch only; the LDS-DMA chunks in flight
+            // belong to the next tile, which waits for them itself.)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier ; m324-audit: epilogue scratch only" ::: "memory");
         } else {
             rsl[lane] = pre ? pre->rs : ln_row_direct(ep, M, min(mw + lane, M - 1));
             if (MI > 2) rsl[64 + lane] = ln_row_direct(ep, M, min(mw + 64 + lane, M - 1));
