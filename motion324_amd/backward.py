@@ -123,11 +123,18 @@ def weight_grad(dy: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] =
         else:                                                    # 128 x 128 tiles, two workgroups per CU
             tiles = ((N + 127) // 128) * ((Ka + 127) // 128)
             slices = max(1, min(32, (640 + tiles - 1) // tiles, M // 512))
-        # m324_gemm_tn addresses a slice's rows through 32-bit buffer offsets: (rows per slice + 64) * ld * 2 bytes < 2 GiB.
-        # Very long token counts need more slices than the occupancy rule asks for.
+        # m324_gemm_tn addresses a slice's rows through 32-bit buffer offsets and refuses (ks + 64) * ld * 2 bytes >= 2 GiB with
+        # ks = the tokens per slice rounded up to whole 64-row tiles (csrc/gemm.hip); very long token counts need more slices
+        # than the occupancy rule asks for.  Same formula here, so the guard and the library agree at the boundary.
         ld = max(dy.stride(0), a.stride(0))
-        while slices < 4096 and (M // slices + 64 + 1) * ld * 2 >= (1 << 31):
+
+        def _ks(n: int) -> int:
+            return ((M + n - 1) // n + 63) // 64 * 64
+
+        while slices < 4096 and (_ks(slices) + 64) * ld * 2 >= 0x7FFFFFFF:
             slices *= 2
+        while slices > 1 and _ks(slices) * (slices - 1) >= M:       # no slice may be left empty
+            slices -= 1
         return ops.gemm_tn(dy, a, slices, out=out, accumulate=accumulate)
     if accumulate:
         out += _wgrad(ops.transpose(dy), ops.transpose(a)).reshape(out.shape)

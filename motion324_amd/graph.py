@@ -156,9 +156,15 @@ class GraphedForward:
                             g.begin()
                             try:
                                 static_out = run(static_in)
-                            finally:
+                            except BaseException:
                                 _SEGMENTER = None
-                                g.end()
+                                try:                      # close the open capture; an invalidated one raises again --
+                                    g.end()               # the caller must see run()'s error, not this one
+                                except Exception:
+                                    pass
+                                raise
+                            _SEGMENTER = None
+                            g.end()
                         torch.cuda.current_stream().wait_stream(cap_stream)
                     else:
                         g = torch.cuda.CUDAGraph()

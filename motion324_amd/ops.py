@@ -280,8 +280,10 @@ def gemm_pair(deferred: list) -> None:
         raise L.M324Error("gemm_pair: exactly two deferred projections")
     (a0, f0, b0, t0, _), (a1, f1, b1, t1, _) = deferred
     lib = L.load()
-    with span("gemm_bf16", f0 + f1, b0 + b1, f"gemm_ring2_pair_kernel<unsigned short, 4, 0> | {t0} + {t1}" if _timing() else ""):
+    with span("gemm_bf16", f0 + f1, b0 + b1, f"gemm_ring2_pair_kernel<unsigned short, 4, 0> | {t0} + {t1}" if _timing() else "") as sp:
         rc = lib.m324_gemm_pair(C.byref(a0), C.byref(a1), _stream())
+        if rc == L.ERR_UNSUPPORTED:
+            sp.cancel()                          # nothing ran: the two fallback launches below carry the work
     if rc == L.ERR_UNSUPPORTED:
         for args, fl, by, tag, _ in deferred:
             with span("gemm_bf16", fl, by, f"{_gemm_plan(args)} | {tag}" if _timing() else ""):

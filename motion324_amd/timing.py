@@ -71,6 +71,10 @@ class span:
             self.e0.record()
         return self
 
+    def cancel(self) -> None:
+        """Nothing was launched inside (the library refused the call): record no row."""
+        self.e0 = None
+
     def __exit__(self, *exc):
         if self.e0 is not None and _active is not None:
             e1 = torch.cuda.Event(enable_timing=True)

@@ -70,6 +70,7 @@ def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float =
     from .transformer import fusion_disabled
     global TRAIN_STORE
     with fusion_disabled():
+        oom = False
         try:
             return _forward_backward(model, sample, grad_scale, drop_seed, sink)
         except torch.cuda.OutOfMemoryError:
@@ -79,18 +80,21 @@ def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float =
             # other ranks: they would reduce this rank's first attempt.
             if TRAIN_STORE == "0" or (sink is not None and getattr(sink, "step_launches", lambda: 0)() > 0):
                 raise
-            import warnings
-            warnings.warn("motion324_amd.training: out of memory with kept block internals; this step is redone with "
-                          "checkpoint + recompute (M324_TRAIN_STORE=0 makes that the policy)", RuntimeWarning)
-            if drop_seed is None and model.training and float(model.drop_rate) > 0.0:
-                drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            torch.cuda.empty_cache()
-            keep = TRAIN_STORE
-            TRAIN_STORE = "0"
-            try:
-                return _forward_backward(model, sample, grad_scale, drop_seed, sink)
-            finally:
-                TRAIN_STORE = keep
+            oom = True           # only recorded here: the live exception's traceback keeps the failed attempt's frames -- and
+                                 # every activation they hold -- alive until this block is left (PyTorch FAQ on OOM recovery)
+        assert oom
+        import warnings
+        warnings.warn("motion324_amd.training: out of memory with kept block internals; this step is redone with "
+                      "checkpoint + recompute (M324_TRAIN_STORE=0 makes that the policy)", RuntimeWarning)
+        if drop_seed is None and model.training and float(model.drop_rate) > 0.0:
+            drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        torch.cuda.empty_cache()
+        keep = TRAIN_STORE
+        TRAIN_STORE = "0"
+        try:
+            return _forward_backward(model, sample, grad_scale, drop_seed, sink)
+        finally:
+            TRAIN_STORE = keep
 
 
 def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float = 1.0, drop_seed: Optional[int] = None,

@@ -626,6 +626,52 @@ def test_kept_internals_and_recompute_give_the_same_step(precision, monkeypatch)
     assert len(runs["keep"][2]) == len(runs["recompute"][2]) >= 60
 
 
+def test_out_of_memory_step_is_redone_with_recompute_after_the_failed_attempt_is_released(monkeypatch):
+    """training.forward_backward redoes a step that ran out of memory once, with the reference's checkpoint + recompute policy.
+    The retry must start AFTER the failed attempt's activations are gone: while an `except` block is active the exception's
+    traceback keeps the failed frames -- and every tensor they hold -- alive, so the retry runs behind it."""
+    import warnings
+    from motion324_amd import synth, training
+    model, dm = build("tiny")
+    model.train()
+    model.drop_rate = 0.0
+    s_np = synth.synth_inputs(2, 3, 40, 100, 64, seed=1, with_target=True)
+    sample = {k: torch.from_numpy(v).cuda() for k, v in s_np.items()}
+    monkeypatch.setattr(training, "TRAIN_STORE", "0")
+    loss0, out0, G0 = training.forward_backward(model, sample)
+    want = (float(loss0), out0.clone(), {n: G0.get(p).clone() for n, p in model.named_parameters() if p.requires_grad})
+    del loss0, out0, G0
+    monkeypatch.setattr(training, "TRAIN_STORE", "1")
+    real = training._forward_backward
+    state = {"calls": 0, "allocated_at_retry": None}
+    big = 256 << 20
+
+    def flaky(*a, **k):
+        state["calls"] += 1
+        if state["calls"] == 1:
+            hog = torch.empty(big, dtype=torch.uint8, device="cuda")      # a local of the failing frame, like its activations
+            hog.fill_(1)
+            raise torch.cuda.OutOfMemoryError("synthetic: out of memory with kept block internals")
+        state["allocated_at_retry"] = torch.cuda.memory_allocated()
+        assert training.TRAIN_STORE == "0"                    # the retry runs under the recompute policy
+        return real(*a, **k)
+
+    monkeypatch.setattr(training, "_forward_backward", flaky)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        loss, out, G = training.forward_backward(model, sample)
+    torch.cuda.synchronize()
+    assert state["calls"] == 2 and any("redone with" in str(x.message) for x in w)
+    assert state["allocated_at_retry"] < base + big // 2, (state, base)       # the failed attempt's 256 MiB were released first
+    assert training.TRAIN_STORE == "1"                        # policy restored
+    assert float(loss) == want[0] and torch.equal(out, want[1])
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(G.get(p), want[2][n]), n
+
+
 def test_training_mode_dropout_is_seeded_by_torch_and_off_in_eval():
     """pos_drop: p = transformer.drop_rate in train(), identity in eval(); the mask follows torch.manual_seed."""
     from motion324_amd import synth
