@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libm324.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "attention.hip", "attention_pwg.hip", "elementwise.hip", "backward.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "gemm_pp.hip", "attention.hip", "attention_pwg.hip", "elementwise.hip", "backward.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(HERE, "..", "include", "m324.h"),
            os.path.join(CSRC, "attn_pwg_asm.inc"), os.path.join(CSRC, "attn_pwg_bounded_asm.inc"), os.path.join(CSRC, "attn_pwg_clobbers.inc"),
            os.path.join(CSRC, "attn_pwg_kernel.inl")]

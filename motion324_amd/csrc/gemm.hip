@@ -977,7 +977,7 @@ static int xcd_mode(const m324_gemm_args* a) {
     return 1;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13 forces a variant (A/B measurements, tests).  (v7, the half-tile ring
+// Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13|v14 forces a variant (A/B measurements, tests).  (v7, the half-tile ring
 // the chunk-ring kernels replaced, was retired in round 3: no shape reaches it -- K is a multiple of 64 for bf16 -- and its
 // A/B tables are kept in profiles/r01_ab_gemm_schedules.md.)
 static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_GEMM at load / m324_set_tunable
@@ -1004,6 +1004,13 @@ static int pick_variant(const m324_gemm_args* a) {
     const bool ring_ok = bf16 && a->K % 64 == 0 && a->K >= 128;      // v10 / v11: K-stages of 64, at least two
     if (f == 1 || f == 2 || f == 5) return f;
     if (f >= 10 && f <= 13) return ring_ok ? f : (f == 13 ? 2 : 5);
+    // v14 builds the residual-free bf16 epilogues only (gemm_pp.hip launch_pp); a forced v14 leaves the rest to the chooser
+    const bool pp_ok = ring_ok && a->out_dtype == M324_BF16 && !a->residual && a->row_gin <= 0 && !a->ln_stats_out && !a->ln_copy_out &&
+                       a->aux_mode != M324_AUX_N3 && a->M > 64;
+    if (f == 14) {
+        if (pp_ok) return 14;
+        f = 0;
+    }
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
@@ -1011,6 +1018,11 @@ static int pick_variant(const m324_gemm_args* a) {
     // below; of the two, the 4-wave persistent v11 wins when the output is fp32 (residual epilogues: little VALU work,
     // 1.5x the LDS fragment traffic saved), the 8-wave v10 when it is bf16 (GELU / q|k|v epilogues want two waves per
     // SIMD).  K = 64 (a single K-stage) runs on the two-stage 256 x 256 kernel v5.
+    // v14 (round 5): two persistent 256 x 128 workgroups per CU out of phase -- one's epilogue / prologue under the other's main
+    // loop.  Wide bf16 outputs whose epilogue is VALU work (GELU, q|k|v heads, LayerNorm fold) and enough tiles for both slots of
+    // every CU: fc1, q|k|v, the decoder's MLP hidden.  M324_PP=0: the round-4 choice below.
+    const long t14 = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5);
+    if (pp_ok && f == 0 && m324::tunable(m324::TUN_PP) != 0 && a->N % 128 == 0 && a->N >= 1536 && t14 >= 448) return 14;
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
     if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) {
@@ -1044,6 +1056,7 @@ static int pick_variant(const m324_gemm_args* a) {
 template <typename TOUT, int ACT, int RES>
 static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
     if (variant == 11 || variant == 12) return m324::launch_ring4(a, s, ep, ACT, RES, xcd_mode(a), variant);
+    if (variant == 14) return m324::launch_pp(a, s, ep, ACT, RES, xcd_mode(a));
     if (variant == 13) {
         hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN) * ceil_div(a->M, BM)), dim3(256), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
@@ -1127,6 +1140,9 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
     do {                                                                                                                 \
         if (variant == 11 || variant == 12) {                                                                            \
             const int rc_ = m324::launch_ring4(a, s, ep, ACT, RES, xcd_mode(a), variant);                                \
+            if (rc_ != M324_OK) return rc_;                                                                              \
+        } else if (variant == 14) {                                                                                      \
+            const int rc_ = m324::launch_pp(a, s, ep, ACT, RES, xcd_mode(a));                                            \
             if (rc_ != M324_OK) return rc_;                                                                              \
         } else if (variant == 13)                                                                                        \
             hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(grid.x * grid.y), dim3(256), 0, s,              \
@@ -1214,6 +1230,7 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
         case 11: name = "gemm_ring4_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;
         case 12: name = "gemm_ring3_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); break;
         case 13: name = "gemm_ring2_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
+        case 14: name = "gemm_pp_kernel"; wg = m324::pp_grid(a); break;
         default: break;
     }
     // grid in threads, as rocprofv3's kernel trace prints it (x, y, z)

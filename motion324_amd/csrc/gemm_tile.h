@@ -1,4 +1,4 @@
-// Shared by the GEMM translation units (gemm.hip, gemm_ring4.hip): epilogue descriptor, GELU forms, LDS swizzles, the
+// Shared by the GEMM translation units (gemm.hip, gemm_ring4.hip, gemm_pp.hip): epilogue descriptor, GELU forms, LDS swizzles, the
 // MFMA k-tile of the 128 x 128 kernels and the LDS-transposed epilogue every LDS-DMA kernel ends with.
 #pragma once
 #include <utility>
@@ -42,6 +42,9 @@ struct Epilogue {
 // gemm_ring4.hip (own translation unit: built WITHOUT -amdgpu-mfma-vgpr-form, its 256 accumulators live in AGPRs).
 // act_code: the ACT template value (0 none, 1 GELU, 2 GELU + pre-activation, 3 x gelu', 4 q|k|v heads); res_code: RES.
 int launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap, int variant);
+// gemm_pp.hip (v14: two persistent 4-wave 256 x 128 workgroups per CU, out of phase); pp_grid: its grid in workgroups
+int launch_pp(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap);
+int pp_grid(const m324_gemm_args* a);
 }  // namespace m324
 
 namespace {

@@ -34,7 +34,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
 }
 # Library switches (C++; read by libm324 once, when it is loaded -- csrc/runtime.hip; m324_set_tunable overrides them)
 LIBRARY: Dict[str, Tuple[str, str]] = {
-    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13); 0 = chooser"),
+    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13 | v14); 0 = chooser"),
     "M324_GEMM_TN": ("0", "128: force the 128 x 128 weight-gradient kernel"),
     "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges, bit 1 4 x 2 group order for wide weights, bit 2 force it"),
     "M324_ATTN_NW": ("0", "attention forward: waves per workgroup (4 | 8); 0 = by sequence length"),
@@ -47,6 +47,8 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_QKV_RING": ("1", "128 x 128 chunk ring (v13) instead of the two-stage v2: bit 0 for the fused q|k|v projection (head-major epilogue), bit 1 for plain bf16 outputs (A/B)"),
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
     "M324_NT_MB": ("128", "GEMM: bf16 outputs (no residual) larger than this many MiB are stored nontemporal"),
+    "M324_PP": ("1", "wide bf16 outputs (fc1, q|k|v, the decoder's MLP hidden) on v14: two persistent 256 x 128 workgroups per CU out of phase, one's epilogue under the other's main loop (0: the 256 x 256 / 128 x 128 chunk rings of round 4)"),
+    "M324_PP_SKEW": ("0", "v14: start offset of a CU's second workgroup in units of 1024 cycles (0 = by epilogue: 7 with GELU / q|k|v heads, else 4; -1 = none)"),
     "M324_GEMM_PERSIST": ("1", "256 x 256 chunk-ring GEMM (v10): 1 = one persistent workgroup per CU, next tile's first chunks under the epilogue; 0 = one workgroup per tile"),
 }
 

@@ -155,7 +155,7 @@ def trained_like(sd_np, seed=11):
     return sd
 
 
-def test_trained_like_weights_at_c1_size():
+def test_trained_like_weights_at_c1_size(monkeypatch):
     from motion324_amd import synth
     dims = CASES["c1"]["dims"]
     sd = trained_like(synth_sd(dims))
@@ -173,6 +173,16 @@ def test_trained_like_weights_at_c1_size():
     refp = torch.from_numpy(s_np["ref_pcd"])[:, None]
     o16 = rel_err(out16.pcd_moved.cpu() - refp, ref - refp)
     print(f"[trained-like c1] fp32 {e32:.2e}  bf16 {e16:.2e}  (offsets alone: bf16 {o16:.2e})")
+    # where the band comes from: the same forward with each bf16-mode shortcut switched off (diagnostics, not gated)
+    import motion324_amd.transformer as tr
+    import motion324_amd.Pcd_motion as pm
+    for name, mod, attr, val in (("LayerNorm fold off", tr, "FOLD_LN", 0), ("fp32 decoder stream", pm, "BF16_DECODER_STREAM", False),
+                                 ("bounded softmax off", tr, "ATTN_BOUNDED", False), ("fused q|k|v epilogue off", tr, "FUSE_QKV", False),
+                                 ("fused head off", pm, "FUSE_HEAD_N3", False)):
+        monkeypatch.setattr(mod, attr, val)
+        o, _ = _run(model, sample, "bf16")
+        print(f"    {name}: bf16 {rel_err(o.pcd_moved, ref):.2e}")
+        monkeypatch.undo()
     assert e32 < FP32_TOL
     assert torch.isfinite(out16.pcd_moved).all()
     assert e16 < TRAINED_LIKE_BF16_TOL
