@@ -213,6 +213,16 @@ int m324_attention_plan(int B, int H, int Lq, int Lk, int flags, int dtype, char
 /*   lse (optional, [B,H,Lq] fp32): log2-domain log-sum-exp of every score row, saved for the backward pass. */
 
 /* ------------------------------------------------------------------------------------------
+ * m324_attention_merge: one softmax attended in two or three disjoint key parts -> the attention over all keys.
+ *   O_i [B*Lq, ldp] (token-major, H*64 columns) and lse_i [B,H,Lq] are what m324_attention left for part i (O2 / lse2 may both
+ *   be NULL); O = sum_i 2^(lse_i - m) O_i / sum_i 2^(lse_i - m).  The frame-parallel global blocks (reference
+ *   model/Pcd_motion.py:401-405 on a clip sharded over ranks, scripts/4D_from_existing.sh:54-64) attend to the rank's own keys
+ *   while the other ranks' k|v rows are still in flight and merge afterwards.
+ * ------------------------------------------------------------------------------------------ */
+int m324_attention_merge(const void* O0, const float* lse0, const void* O1, const float* lse1, const void* O2, const float* lse2,
+                         long ldp, void* O, long ldo, int B, int H, int Lq, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * m324_patchify: video frames -> DINOv2 patch rows.
  *   replaces: permute + F.interpolate(bilinear, align_corners=False) (model/Pcd_motion.py:470-472),
  *             ImageNet normalisation (model/image_encoder/dinov2.py:78-80) and the im2col of the

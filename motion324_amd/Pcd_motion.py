@@ -35,6 +35,7 @@ from .transformer import LN_EPS, LNFold, QK_Norm_CrossAttentionBlock, QK_Norm_Tr
 # A/B switches: one table with defaults and meanings in motion324_amd/switches.py (bench.py echoes non-default values)
 AUTO_GRAPH = switches.flag("M324_AUTO_GRAPH")               # forward(): graph replay for repeated inference shapes
 FUSE_HEAD_N3 = switches.flag("M324_FUSE_HEAD")              # head fc1 + GELU + 768 -> 3 in one GEMM epilogue (bf16 inference)
+KV_OVERLAP = switches.flag("M324_KV_OVERLAP")              # frame-parallel: own keys attended while the K|V all-gather is in flight
 BF16_DECODER_STREAM = switches.flag("M324_BF16_DECODER")    # the decoder's residual stream in bf16 (bf16 inference only)
 HOIST_DECODER_Q = switches.flag("M324_HOIST_Q")             # hoisted decoder q projection (graph capture)
 DECODE_ROWS = int(switches.get("M324_DECODE_ROWS"))         # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
@@ -101,9 +102,14 @@ class _KVGather:
     the gathered rows already are the clip's token order and nothing is copied afterwards.  Uneven shards (or B > 1,
     where the clip order is batch-major) pad to the largest shard and compact once."""
 
-    def __init__(self, B, T_local, Lt, frames, group, dev):
+    def __init__(self, B, T_local, Lt, frames, group, dev, rank=0):
         self.B, self.T, self.Lt, self.frames, self.group, self.dev = B, T_local, Lt, list(frames), group, dev
         self.world = len(self.frames)
+        self.rank = rank
+        # M324_KV_OVERLAP: the block attends to the rank's own keys while the exchange is in flight and merges the remote keys'
+        # partial softmax afterwards (transformer.QK_Norm_SelfAttentionBlock.run); B = 1 (c5): the clip order is frame-major, the
+        # rank's own rows are ONE contiguous range of the gathered rows
+        self.overlap = KV_OVERLAP and B == 1 and self.world > 1
         self.T_full = sum(self.frames)
         self.even = B == 1 and all(f == self.frames[0] for f in self.frames)
         self.comm = torch.cuda.Stream(device=dev)
@@ -116,10 +122,33 @@ class _KVGather:
     def start(self, kv_local: torch.Tensor) -> None:
         """kv_local: contiguous [B * T_local * Lt, 2C]."""
         from . import graph
-        if graph.active_segmenter() is not None:       # segmented hipGraph capture: the exchange runs BETWEEN two graphs, in finish()
+        seg = graph.active_segmenter()
+        if seg is not None and self.overlap:
+            # segmented capture, overlapped form: the collective is STARTED between two graphs (eagerly, on the side stream), the next
+            # graph holds the work that runs beside it (q projection, the rank's own keys), finish() cuts again and joins
+            self._seg_fixed(kv_local)
+            seg.cut(lambda: self._start(kv_local))
+            return
+        if seg is not None:                            # segmented hipGraph capture: the exchange runs BETWEEN two graphs, in finish()
             self._deferred = kv_local
             return
         self._start(kv_local)
+
+    def local_rows(self):
+        """(lo, hi): the rank's own token rows inside the gathered [T_full * Lt] rows (B = 1)."""
+        lo = sum(self.frames[:self.rank]) * self.Lt
+        return lo, lo + self.frames[self.rank] * self.Lt
+
+    def _seg_fixed(self, kv_local: torch.Tensor) -> torch.Tensor:
+        """The buffer a captured graph reads the gathered rows from (fixed address across replays)."""
+        rows, width = kv_local.shape
+        if self.even:
+            if self.buf is None or self.buf.dtype != kv_local.dtype or self.buf.shape[1] != width:
+                self.buf = torch.empty((self.world * rows, width), dtype=kv_local.dtype, device=self.dev)
+            return self.buf
+        if self.full is None or self.full.dtype != kv_local.dtype or self.full.shape[1] != width:
+            self.full = torch.empty((self.B * self.T_full * self.Lt, width), dtype=kv_local.dtype, device=self.dev)
+        return self.full
 
     def _start(self, kv_local: torch.Tensor) -> None:
         rows, width = kv_local.shape
@@ -144,6 +173,15 @@ class _KVGather:
         """-> ([B * T_full * Lt, 2C] in clip order, T_full * Lt)."""
         from . import graph
         seg = graph.active_segmenter()
+        if seg is not None and self.overlap:
+            full = self.buf if self.even else self.full
+
+            def join():
+                got, _ = self._finish()
+                if got.data_ptr() != full.data_ptr():
+                    full.copy_(got)
+            seg.cut(join)
+            return full, self.T_full * self.Lt
         if seg is not None:
             # The captured graph that follows reads the gathered rows at a FIXED address: the even path's reused buffer, or
             # (uneven shards) a buffer this object keeps.  The exchange itself is replayed eagerly between the two graphs.
@@ -531,7 +569,7 @@ class Motion_Latent_Model(nn.Module):
         # D. alternating global / local trunk (reference :394-409)
         if shard is not None and parallel.collectives_on(shard[1]):
             rank, world, group = shard[:3]
-            kv_gather = _KVGather(B, T, Lt, parallel.counts(T_full, world), group, dev)
+            kv_gather = _KVGather(B, T, Lt, parallel.counts(T_full, world), group, dev, rank=rank)
 
         # LayerNorm fold (transformer.LNFold): the statistics of the stream travel from GEMM epilogue to GEMM epilogue
         fold = None

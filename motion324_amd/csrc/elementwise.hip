@@ -766,6 +766,40 @@ __global__ __launch_bounds__(256) void n3_finish_kernel(const float* __restrict_
     out[i] = s;
 }
 
+// m324_attention_merge: the softmax over a key set that was attended in NP disjoint parts.  Part i left its normalised output O_i
+// and the log2-domain log-sum-exp l_i of its scores (m324_attention's lse); the whole softmax is
+//   O = sum_i 2^(l_i - m) O_i / sum_i 2^(l_i - m),  m = max_i l_i
+// (each O_i is sum_k 2^(s_k - l_i) v_k over its own keys).  Token-major rows of H x 64 values, eight columns per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void attention_merge_kernel(const T* __restrict__ O0, const float* __restrict__ l0, const T* __restrict__ O1,
+                                                              const float* __restrict__ l1, const T* __restrict__ O2,
+                                                              const float* __restrict__ l2, long ldp, T* __restrict__ O, long ldo, int B,
+                                                              int H, int Lq) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // (row, 8-column chunk)
+    const int cpr = H * 8;
+    if (i >= (long)B * Lq * cpr) return;
+    const long row = i / cpr;
+    const int c = (int)(i - row * cpr), h = c >> 3;
+    const long b = row / Lq, q = row - b * Lq;
+    const long li = (b * H + h) * Lq + q;
+    const float a0 = l0[li], a1 = l1[li], a2 = O2 ? l2[li] : -INFINITY;
+    const float m = fmaxf(a0, fmaxf(a1, a2));
+    float w0 = exp2f(a0 - m), w1 = exp2f(a1 - m), w2 = O2 ? exp2f(a2 - m) : 0.f;
+    const float inv = 1.0f / (w0 + w1 + w2);
+    w0 *= inv, w1 *= inv, w2 *= inv;
+    float x[8], y[8];
+    load8(O0 + row * ldp + c * 8, x);
+    load8(O1 + row * ldp + c * 8, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = w0 * x[e] + w1 * y[e];
+    if (O2) {
+        load8(O2 + row * ldp + c * 8, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaf(w2, y[e], x[e]);
+    }
+    store8(O + row * ldo + c * 8, x);
+}
+
 }  // namespace
 
 #define DISPATCH_DTYPE(dtype, name, ...)                                  \
@@ -922,6 +956,24 @@ extern "C" int m324_assemble_tokens(const float* dino_x, const float* dino_w, co
     hipLaunchKernelGGL(assemble_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, dino_x, dino_w, dino_b,
                        eps_dino, pos, sp0, spr, mesh, ln_w, eps_in, out, B, T, K, P, C, drop_thr, drop_scale, drop_seed);
     M324_CHECK_LAUNCH("m324_assemble_tokens");
+    return M324_OK;
+}
+
+extern "C" int m324_attention_merge(const void* O0, const float* lse0, const void* O1, const float* lse1, const void* O2, const float* lse2,
+                                    long ldp, void* O, long ldo, int B, int H, int Lq, int dtype, void* stream) {
+    M324_REQUIRE(O0 && lse0 && O1 && lse1 && O && (!O2 == !lse2), "m324_attention_merge: two or three (output, lse) parts");
+    M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && ldp >= (long)H * 64 && ldo >= (long)H * 64, "m324_attention_merge: bad sizes");
+    const int esz = dtype == M324_BF16 ? 2 : 4;
+    M324_REQUIRE((ldp * esz) % 16 == 0 && (ldo * esz) % 16 == 0 && ((uintptr_t)O0 % 16) == 0 && ((uintptr_t)O1 % 16) == 0 &&
+                     ((uintptr_t)O2 % 16) == 0 && ((uintptr_t)O % 16) == 0,
+                 "m324_attention_merge: rows must be 16-byte aligned");
+    const long n = (long)B * Lq * H * 8;
+    M324_REQUIRE((n + 255) / 256 < (1l << 31), "m324_attention_merge: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_DTYPE(dtype, "m324_attention_merge",
+                   hipLaunchKernelGGL(attention_merge_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)O0, lse0,
+                                      (const T*)O1, lse1, (const T*)O2, lse2, ldp, (T*)O, ldo, B, H, Lq));
+    M324_CHECK_LAUNCH("m324_attention_merge");
     return M324_OK;
 }
 

@@ -1018,11 +1018,16 @@ static int pick_variant(const m324_gemm_args* a) {
     // below; of the two, the 4-wave persistent v11 wins when the output is fp32 (residual epilogues: little VALU work,
     // 1.5x the LDS fragment traffic saved), the 8-wave v10 when it is bf16 (GELU / q|k|v epilogues want two waves per
     // SIMD).  K = 64 (a single K-stage) runs on the two-stage 256 x 256 kernel v5.
-    // v14 (round 5): two persistent 256 x 128 workgroups per CU out of phase -- one's epilogue / prologue under the other's main
-    // loop.  Wide bf16 outputs whose epilogue is VALU work (GELU, q|k|v heads, LayerNorm fold) and enough tiles for both slots of
-    // every CU: fc1, q|k|v, the decoder's MLP hidden.  M324_PP=0: the round-4 choice below.
+    // v14 (round 5): two persistent 256 x 128 workgroups per CU.  Measured (profiles/r05_gemm_labs.md): it wins where 256 x 256
+    // tiles quantise badly and the epilogue is light -- plain wide bf16 outputs (the training step's q|k|v projections: 42.8 us
+    // against 47.8-49.0 at 10368 x 2304 x 768) -- and loses with GELU / head-major / LayerNorm-fold epilogues, which do not hide
+    // beside the partner workgroup's MFMA stream.  M324_PP=0: never; bit 1: also where the 256 x 256 tiling fills its rounds (A/B); M324_GEMM=v14 forces it for every epilogue it builds.
     const long t14 = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5);
-    if (pp_ok && f == 0 && m324::tunable(m324::TUN_PP) != 0 && a->N % 128 == 0 && a->N >= 1536 && t14 >= 448) return 14;
+    const long t5q = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
+    const bool plain = a->act == M324_ACT_NONE && a->aux_mode == M324_AUX_NONE && !a->ln_rowstat && !a->gamma;
+    if (pp_ok && f == 0 && plain && m324::tunable(m324::TUN_PP) != 0 && a->N % 128 == 0 && a->N >= 1536 && t14 >= 448 &&
+        ((m324::tunable(m324::TUN_PP) & 2) != 0 || (double)t5q / (double)(((t5q + 255) / 256) * 256) < 0.85))
+        return 14;
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
     if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) {

@@ -464,6 +464,17 @@ __device__ __forceinline__ void ln_chan_step(const float2 pb, float inv_cnt1, fl
     mean = take ? nm : mean;
     m2 = take ? n2 : m2;
 }
+// The two halves of a row's blocks (h blocks = 64 h values each), merged one after the other by ln_chan_step, combined: Chan's
+// pairwise form for equal counts, d^2 n n / 2n = 32 h d^2.  EVERY consumer merges a row this way -- the lane halves of the 256-wide
+// kernels hold one half each, the 128-wide kernels and ln_row_direct walk both -- so that the statistics, and with them the
+// product, do not depend on the schedule the chooser picked (a graph branch with half the rows may pick another one).
+__device__ __forceinline__ float2 ln_combine_halves(float mean_a, float m2_a, float mean_b, float m2_b, int h, int ncb, float eps) {
+    const float d = mean_b - mean_a;
+    const float m2 = (m2_a + m2_b) + (d * d) * (32.0f * (float)h);
+    const float mean = fmaf(0.5f, d, mean_a);
+    const float rstd = rsqrtf(m2 / (64.0f * (float)ncb) + eps);
+    return make_float2(rstd, -rstd * mean);
+}
 // entry (block, row) of the unmerged table: uniform base + uniform block offset + ONE 32-bit per-lane offset (64-bit per-lane
 // pointers, one per block, were hoisted out of the tile loop and spilled).  Host: the table is smaller than 4 GiB.
 __device__ __forceinline__ float2 ln_entry(const char* table, unsigned block_bytes, int block, unsigned lane_off) {
@@ -527,10 +538,14 @@ __device__ __forceinline__ void ln_prefetch(const Epilogue& ep, int M, int N, in
             pre.raw_sum = ln_f32x8{e0[0], e1[0], e2[0], e3[0], e4[0], e5[0], e6[0], e7[0]};
             pre.raw_m2 = ln_f32x8{e0[1], e1[1], e2[1], e3[1], e4[1], e5[1], e6[1], e7[1]};
         } else {
+            // entries 0 .. 7: the first half of the row's blocks (0 .. h - 1), entries 8 .. 15: the second half (h .. ncb - 1) --
+            // both halves then merge with compile-time step constants (ln_finish)
             const char* const tbl = reinterpret_cast<const char*>(ep.rowstat);
+            const int h = ep.ncb >> 1;                      // host: an even block count
 #pragma unroll
             for (int i = 0; i < LN_MAX_NCB; ++i) {
-                const float2 p = ln_entry(tbl, (unsigned)M * 8u, min(i, ep.ncb - 1), (unsigned)row * 8u);
+                const int blk = (i < LN_MAX_NCB / 2 ? 0 : h) + min(i & (LN_MAX_NCB / 2 - 1), h - 1);
+                const float2 p = ln_entry(tbl, (unsigned)M * 8u, blk, (unsigned)row * 8u);
                 pre.raw_sum[i] = p.x, pre.raw_m2[i] = p.y;
             }
         }
@@ -547,24 +562,41 @@ __device__ __forceinline__ void ln_finish(const Epilogue& ep, int lane, LnPreT<M
 #pragma unroll
             for (int i = 1; i < LN_MAX_NCB / 2; ++i)
                 ln_chan_step(make_float2(pre.raw_sum[i], pre.raw_m2[i]), 1.0f / (float)(i + 1), 64.0f * (float)i / (float)(i + 1), i < h, mean, m2);
-            // the other half's (count, mean, M2): Chan's pairwise form
+            // the other half's (mean, M2); lanes < 32 hold the first half of the blocks and are the ones whose pair is used
             const float omean = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
-            const float d = omean - mean;                   // equal counts n = 64 h: d^2 n n / 2n = 32 h d^2
-            m2 = m2 + om2 + d * d * (32.0f * (float)h);
-            mean = mean + 0.5f * d;
+            pre.rs = (lane < 32) ? ln_combine_halves(mean, m2, omean, om2, h, ep.ncb, ep.eps) : ln_combine_halves(omean, om2, mean, m2, h, ep.ncb, ep.eps);
+            return;
         } else {
+            // both halves (ln_prefetch: entries 0 .. 7 and 8 .. 15), each as the 256-wide kernels' lane halves merge theirs
+            const int h = ep.ncb >> 1;
+            constexpr int HB = LN_MAX_NCB / 2;
+            float mean_b = pre.raw_sum[HB] * (1.0f / 64.0f), m2_b = pre.raw_m2[HB];
             mean = pre.raw_sum[0] * (1.0f / 64.0f), m2 = pre.raw_m2[0];
 #pragma unroll
-            for (int i = 1; i < LN_MAX_NCB; ++i)
-                ln_chan_step(make_float2(pre.raw_sum[i], pre.raw_m2[i]), 1.0f / (float)(i + 1), 64.0f * (float)i / (float)(i + 1), i < ep.ncb, mean, m2);
+            for (int i = 1; i < HB; ++i) {
+                ln_chan_step(make_float2(pre.raw_sum[i], pre.raw_m2[i]), 1.0f / (float)(i + 1), 64.0f * (float)i / (float)(i + 1), i < h, mean, m2);
+                ln_chan_step(make_float2(pre.raw_sum[HB + i], pre.raw_m2[HB + i]), 1.0f / (float)(i + 1), 64.0f * (float)i / (float)(i + 1), i < h, mean_b,
+                             m2_b);
+            }
+            pre.rs = ln_combine_halves(mean, m2, mean_b, m2_b, h, ep.ncb, ep.eps);
+            return;
         }
-        const float rstd = rsqrtf(m2 / (64.0f * (float)ep.ncb) + ep.eps);
-        pre.rs = make_float2(rstd, -rstd * mean);
     }
 }
 // the rows a kernel without prefetch needs (v11 / v12: no folded consumer of the product reaches them; tests do)
 __device__ __forceinline__ float2 ln_row_direct(const Epilogue& ep, int M, int row) {
     if (ep.ncb <= 0) return ep.rowstat[row];
+    if ((ep.ncb & 1) == 0) {                                 // the consumers' common arithmetic: two halves, then ln_combine_halves
+        const int h = ep.ncb >> 1;
+        float mean[2], m2[2];
+        for (int half = 0; half < 2; ++half) {
+            const float2 p0 = ep.rowstat[(long)(half * h) * M + row];
+            mean[half] = p0.x * (1.0f / 64.0f), m2[half] = p0.y;
+            for (int i = 1; i < h; ++i)
+                ln_chan_step(ep.rowstat[(long)(half * h + i) * M + row], 1.0f / (float)(i + 1), 64.0f * (float)i / (float)(i + 1), true, mean[half], m2[half]);
+        }
+        return ln_combine_halves(mean[0], m2[0], mean[1], m2[1], h, ep.ncb, ep.eps);
+    }
     float mean = 0.f, m2 = 0.f;
     for (int b = 0; b < ep.ncb; ++b)
         ln_chan_step(ep.rowstat[(long)b * M + row], 1.0f / (float)(b + 1), 64.0f * (float)b / (float)(b + 1), true, mean, m2);

@@ -148,7 +148,10 @@ class GraphedForward:
                 try:
                     if self.segmented:
                         global _SEGMENTER
-                        g = _Segmenter(self.capture_error_mode)
+                        # "thread_local": with M324_KV_OVERLAP an exchange is IN FLIGHT while the next link of the chain is being
+                        # captured, and the transport's own threads (gloo's copies through host memory; RCCL's watchdog) keep
+                        # calling into HIP -- in "global" mode any such call invalidates the capture on this thread
+                        g = _Segmenter("thread_local" if self.capture_error_mode == "global" else self.capture_error_mode)
                         cap_stream = torch.cuda.Stream()
                         cap_stream.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(cap_stream):

@@ -441,6 +441,33 @@ def attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, out: torch.Ten
     return out
 
 
+def attention_merge(parts, out: torch.Tensor, B: int, H: int, Lq: int) -> torch.Tensor:
+    """out[B*Lq, H*64] = the attention over the union of two or three disjoint key sets from the (O_i, lse_i) pairs attention(...,
+    lse=...) left for each of them (m324_attention_merge: log2-domain weights 2^(lse_i - max))."""
+    if not 2 <= len(parts) <= 3:
+        raise L.M324Error("attention_merge: two or three (output, lse) parts")
+    O0 = parts[0][0]
+    p0, ldp = _rows(O0, "O0")
+    ptrs = []
+    for O, lse in parts:
+        po, ld = _rows(O, "part")
+        if (O.dtype != out.dtype or ld != ldp or O.shape[0] < B * Lq or O.shape[1] < H * 64 or lse.dtype != torch.float32
+                or not lse.is_contiguous() or lse.numel() != B * H * Lq):
+            raise L.M324Error(f"attention_merge: part {O.dtype}{tuple(O.shape)} / lse {lse.dtype}{tuple(lse.shape)}")
+        ptrs += [po, _p(lse)]
+    if len(parts) == 2:
+        ptrs += [None, None]
+    po, ldo = _rows(out, "out")
+    if out.shape[0] < B * Lq or out.shape[1] < H * 64:
+        raise L.M324Error("attention_merge: out too small")
+    esz = out.element_size()
+    with span("hbm_pass", 0.0, float(B * Lq) * H * 64 * esz * (len(parts) + 1),
+              f"attention_merge_kernel | rows={B * Lq} parts={len(parts)}" if _timing() else ""):
+        L.check(L.load().m324_attention_merge(*ptrs, ldp, po, ldo, B, H, Lq, code_of(out.dtype), _stream()), "m324_attention_merge")
+    _wrote(out)
+    return out
+
+
 def patchify(video: torch.Tensor, size: int, patch: int, Kp: int, dtype: torch.dtype) -> torch.Tensor:
     """video [F,Hin,Win,3] fp32 -> [F*(size/patch)^2, Kp] normalised, bilinearly resized patch rows."""
     if video.dtype != torch.float32 or not video.is_contiguous() or video.dim() != 4 or video.shape[3] != 3:

@@ -19,6 +19,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_HOIST_Q": ("1", "Pcd_motion.HOIST_DECODER_Q", "graph capture: decoder point features + q projection on the shape-encoder branch"),
     "M324_DECODE_ROWS": (str(1 << 17), "Pcd_motion.DECODE_ROWS", "max (frames x points) rows per decoder pass"),
     "M324_OVERLAP": ("1", "Pcd_motion.OVERLAP_SHAPE_ENCODER", "inference: shape encoder on a second HIP stream under the image encoder"),
+    "M324_KV_OVERLAP": ("1", "Pcd_motion.KV_OVERLAP", "frame-parallel (one sample): every global block attends to the rank's own keys while the k|v all-gather is in flight, then to the gathered remote keys, and merges the partial softmaxes by their log-sum-exps (0: one attention after the gather)"),
     "M324_FOLD_LN": ("2", "transformer.FOLD_LN", "LayerNorm fold: 0 off, 1 bf16 streams only (the decoder), 2 every stream (trunk, DINO too)"),
     "M324_FOLD_MERGE": ("1", "transformer.FOLD_MERGE", "LayerNorm fold: the consumer GEMM merges the producer's per-block row statistics itself (0: m324_rowstats_finish launch between them)"),
     "M324_PAIR_PROJ": ("1", "transformer.PAIR_PROJ", "bf16 inference, decoder: norm_q + norm_kv in one launch and the q + k|v projections in one launch when the q projection runs inside the block (0: four launches)"),
@@ -47,7 +48,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_QKV_RING": ("1", "128 x 128 chunk ring (v13) instead of the two-stage v2: bit 0 for the fused q|k|v projection (head-major epilogue), bit 1 for plain bf16 outputs (A/B)"),
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
     "M324_NT_MB": ("128", "GEMM: bf16 outputs (no residual) larger than this many MiB are stored nontemporal"),
-    "M324_PP": ("1", "wide bf16 outputs (fc1, q|k|v, the decoder's MLP hidden) on v14: two persistent 256 x 128 workgroups per CU out of phase, one's epilogue under the other's main loop (0: the 256 x 256 / 128 x 128 chunk rings of round 4)"),
+    "M324_PP": ("1", "plain wide bf16 outputs whose 256 x 256 tiling fills < 85 % of its rounds (the training step's q|k|v projections) on v14: two persistent 256 x 128 workgroups per CU (0: the chunk rings of round 4)"),
     "M324_PP_SKEW": ("0", "v14: start offset of a CU's second workgroup in units of 1024 cycles (0 = by epilogue: 7 with GELU / q|k|v heads, else 4; -1 = none)"),
     "M324_GEMM_PERSIST": ("1", "256 x 256 chunk-ring GEMM (v10): 1 = one persistent workgroup per CU, next tile's first chunks under the epilogue; 0 = one workgroup per tile"),
 }

@@ -292,6 +292,28 @@ class QK_Norm_TransformerBlock(nn.Module):
             q = torch.empty((rows, C), dtype=P.dtype, device=x.device)
             ops.gemm(src, w[:C], q, bias=None if bias is None else bias[:C], **lnk(0, C))   # ... under the q projection + split
             Q, _, _ = ops.qkv_split(q, None, None, qw, None, RMS_EPS, B, L, a.num_heads, P.dtype, q_scale=ops.Q_PRESCALE)
+            if getattr(kv_gather, "overlap", False):
+                # ... and under the attention over the rank's OWN keys (1 / world of the block's attention work): every attention
+                # kernel leaves the log2-domain log-sum-exp of its rows, so the softmax over all keys is the lse-weighted mean of
+                # the partial outputs (m324_attention_merge).  Remote keys = the gathered rows in front of / behind the own range.
+                H = a.num_heads
+                bounded = a.scores_bounded(P)
+
+                def part(kv_rows, Lk):
+                    _, Kp, Vp = ops.qkv_split(None, kv_rows[:, :C], kv_rows[:, C:], None, kw, RMS_EPS, B, Lk, H, P.dtype)
+                    o = torch.empty((rows, C), dtype=P.dtype, device=x.device)
+                    lse = torch.empty((B, H, L), dtype=torch.float32, device=x.device)
+                    ops.attention(Q, Kp, Vp, o, prescaled=True, bounded=bounded, lse=lse)
+                    return o, lse
+                parts = [part(kv, L)]
+                kv_full, L_full = kv_gather.finish()
+                lo, hi = kv_gather.local_rows()
+                for r0, r1 in ((0, lo), (hi, L_full)):
+                    if r1 > r0:
+                        parts.append(part(kv_full[r0:r1], r1 - r0))
+                ops.attention_merge(parts, h, B, H, L)
+                ops.gemm(h, P.mat(a.fc.weight), x, bias=P.vec(a.fc.bias), residual=x, **out_kw())
+                return _mlp_residual(P, self.norm2, self.mlp, x, fold, feed_next)
             kv_full, L_full = kv_gather.finish()
             _, K, Vt = ops.qkv_split(None, kv_full[:, :C], kv_full[:, C:], None, kw, RMS_EPS, B, L_full, a.num_heads,
                                      P.dtype)

@@ -203,17 +203,21 @@ def _fp_worker(rank, world, port, case, precision, ret):
         torch.cuda.synchronize()
         ret[rank] = out.pcd_moved.cpu()
         ret[f"chain{rank}"] = bool(torch.equal(c1, out.pcd_moved)) and bool(torch.equal(c2, out.pcd_moved))
+        ret[f"chain_diff{rank}"] = (float((c1 - out.pcd_moved).abs().max()), float((c2 - out.pcd_moved).abs().max()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,precision,tol", [(2, "fp32", 5e-6), (3, "bf16", 6e-3)])
-def test_frame_parallel_at_c2_size(world, precision, tol):
+@pytest.mark.parametrize("world,precision,tol,overlap", [(2, "fp32", 5e-6, "1"), (3, "bf16", 6e-3, "1"), (2, "bf16", 6e-3, "0"), (2, "bf16", 6e-3, "1"), (2, "fp32", 5e-6, "0")])
+def test_frame_parallel_at_c2_size(world, precision, tol, overlap, monkeypatch):
     """Frame-parallel forward at the real trunk sizes: 32 frames over 2 ranks (16 + 16: the all_gather_into_tensor fast
     path, 5184 local / 10 368 global tokens) and over 3 ranks (11 + 11 + 10: uneven shards, padded gather) == the
     single-process forward (fp32: summation order only; bf16: the single-process run takes the fused transposed-V
-    projection epilogue, the sharded one m324_qkv_split -- bf16 rounding apart)."""
+    projection epilogue, the sharded one m324_qkv_split -- bf16 rounding apart).  overlap "1" (M324_KV_OVERLAP, default): every
+    global block attends to the rank's own 5184 / 3564 keys while the gather is in flight, then to the remote ranges (one or two),
+    and merges by log-sum-exp -- eagerly and as the chain of hipGraphs with TWO cuts per global block; "0": one attention."""
     import torch.multiprocessing as mp
+    monkeypatch.setenv("M324_KV_OVERLAP", overlap)            # read at import by the spawned ranks
     model, dm = build("c2")
     ref, _ = run(model, inputs("c2", with_target=False), precision)
     ref = ref.pcd_moved.cpu()
@@ -221,13 +225,13 @@ def test_frame_parallel_at_c2_size(world, precision, tol):
     torch.cuda.empty_cache()
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 21000 + (os.getpid() * 11 + world) % 4000
+    port = 21000 + (os.getpid() * 11 + world + 5 * int(overlap)) % 4000
     mp.spawn(_fp_worker, args=(world, port, "c2", precision, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret[r].shape == ref.shape
         assert rel_err(ret[r], ref) < tol, (r, rel_err(ret[r], ref))
     assert all(torch.equal(ret[0], ret[r]) for r in range(1, world))        # every rank holds the same complete result
-    assert all(ret[f"chain{r}"] for r in range(world))                        # the graph chain with sharded frames == eager
+    assert all(ret[f"chain{r}"] for r in range(world)), [ret[f"chain_diff{r}"] for r in range(world)]     # the graph chain with sharded frames == eager
 
 
 # ------------------------------------------------------------------------------------------------------ c4 (2 ranks)

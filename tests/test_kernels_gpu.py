@@ -764,6 +764,46 @@ def test_attention_bounded_scores_stream(tune, B, H, Lq, Lk, amp):
     assert rel_err(out, res[False][0]) < 6e-3
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,Lq,cuts,bounded", [(1, 2, 2100, (0, 700, 1500, 2304), False), (1, 3, 2304, (0, 1152, 2304), True),
+                                                  (2, 2, 300, (0, 64, 200, 333), False), (1, 1, 2048, (0, 520, 2048 + 520), True)])
+def test_attention_merge_of_key_parts_equals_attention_over_all_keys(dtype, B, H, Lq, cuts, bounded):
+    """m324_attention_merge: the keys are attended in two or three disjoint ranges (each attention leaves its normalised output and
+    the log2-domain log-sum-exp of its rows); the merged result must be the attention over all keys -- against fp64 softmax
+    attention and against ONE m324_attention call on the same operands.  Long (the one-wave-per-SIMD streams, lazy and bounded)
+    and short parts, ragged part lengths, a dominant key in one part only (the other parts' weights underflow to ~0)."""
+    ops = _ops()
+    Lk = cuts[-1]
+    q, k, v = (_rand((B, H, L, 64), s_, 1.2) for L, s_ in ((Lq, 261), (Lk, 262), (Lk, 263)))
+    if not bounded:
+        k[0, 0, cuts[1] + 3] = q[0, 0, 7] * 3.0                   # q7's softmax lives in the second part
+    k, v = _q(k, dtype), _q(v, dtype)
+    qs = _q(q * ops.Q_PRESCALE, dtype)
+    dq = qs.to(dtype).to(DEV)
+    flag = bounded and dtype == torch.bfloat16
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        o = torch.full((B * Lq, H * 64), float("nan"), dtype=dtype, device=DEV)
+        lse = torch.full((B, H, Lq), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention(dq, k[:, :, a:b].contiguous().to(dtype).to(DEV), vt_layout(v[:, :, a:b]).to(dtype).to(DEV), o, prescaled=True, lse=lse,
+                      bounded=flag)
+        parts.append((o, lse))
+    out = torch.full((B * Lq + 2, H * 64), float("nan"), dtype=dtype, device=DEV)
+    ops.attention_merge(parts, out, B, H, Lq)
+    assert torch.isnan(out[B * Lq:].float()).all()
+    whole = torch.empty((B * Lq, H * 64), dtype=dtype, device=DEV)
+    ops.attention(dq, k.to(dtype).to(DEV), vt_layout(v).to(dtype).to(DEV), whole, prescaled=True, bounded=flag)
+    sc = torch.einsum("bhqd,bhkd->bhqk", qs.double(), k.double())
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(sc * math.log(2.0), dim=-1), v.double()).reshape(B * Lq, H * 64)
+    got = out[:B * Lq].float().cpu()
+    tol = 8e-3 if dtype == torch.bfloat16 else 2e-5
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < tol and rel_err(got[7], ref[7]) < 1.5 * tol
+    assert rel_err(got, whole.float().cpu()) < (6e-3 if dtype == torch.bfloat16 else 5e-6)
+    with pytest.raises(Exception):
+        ops.attention_merge(parts[:1], out, B, H, Lq)
+
+
 def test_attention_one_wave_per_simd_nan_propagates():
     """a NaN key poisons every row of its (batch, head) in the long-sequence kernel too, and only those"""
     ops = _ops()
@@ -1079,6 +1119,32 @@ def test_gemm_ln_fold_consumer_merges_block_table(tune, variant, M, N, K):
     assert torch.isfinite(outs[1]).all()
     assert rel_err(outs[1], ref) < 5e-3
     assert rel_err(outs[1], outs[0]) < 2e-4                  # bf16 outputs: a last-bit flip here and there
+
+
+@pytest.mark.parametrize("M,N,K", [(513, 3072, 768), (1100, 768, 1024)])
+def test_gemm_ln_fold_consumer_result_does_not_depend_on_the_schedule(tune, M, N, K):
+    """Every consumer merges a row's block statistics with ONE arithmetic (gemm_tile.h ln_combine_halves: two halves by Chan's
+    steps, then the pairwise form), whatever its tile shape keeps in registers: the product must be bit-identical across
+    schedules.  (A hipGraph branch that holds half of the rows may get another schedule than the eager pass over all of them:
+    round 5 found the frame-parallel chain differing from its eager form by a bf16 band because the 256-wide kernels merged in
+    another order than the 128-wide ones.)"""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    x = _rand((M, K), 421)
+    x[::5] += 4.0
+    xb = x.to(torch.bfloat16)
+    lnw, lnb = 1 + 0.2 * _rand((K,), 422), 0.1 * _rand((K,), 423)
+    w, b = _rand((N, K), 424, 0.05), _rand((N,), 425)
+    wf, colsum, bias = _folded(lnw, lnb, w, b)
+    part = _block_table(xb).to(DEV)
+    outs = {}
+    for variant in ("v2", "v10", "v11", "v12", "v13", "v14"):
+        tune("M324_GEMM", variant)
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(xb.to(DEV), wf.to(DEV), out, bias=bias.to(DEV), act=ACT_GELU, ln=(part, colsum.to(DEV), 1e-5))
+        outs[variant] = out.cpu()
+    for variant, out in outs.items():
+        assert torch.equal(out, outs["v2"]), variant
 
 
 def test_gemm_ln_fold_block_table_rejects_odd_block_counts():

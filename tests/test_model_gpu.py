@@ -389,18 +389,23 @@ def _fp_worker(rank, world, port, case, precision, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_frame_parallel_equals_single_gpu(world):
+@pytest.mark.parametrize("case,world,overlap", [("tiny", 2, "1"), ("tiny", 3, "1"), ("tiny", 2, "0"), ("tiny_resize", 2, "1"), ("tiny_resize", 2, "0")])
+def test_frame_parallel_equals_single_gpu(case, world, overlap, monkeypatch):
     """Frames sharded over ranks (uneven for world = 3: T = 3 -> 1+1+1; tiny_resize T = 2 is too short) with the
-    K/V all-gather in every global block == the single-process forward, bit for bit in fp32 up to summation order."""
+    K/V all-gather in every global block == the single-process forward, bit for bit in fp32 up to summation order.
+    overlap "1" (M324_KV_OVERLAP, the default): the rank's own keys are attended while the gather is in flight, the remote
+    ranges afterwards, and the partial softmaxes merged by their log-sum-exps -- case tiny_resize (B = 1, two frames over two
+    ranks); B = 2 (tiny) takes the one-attention form: the own rows are not one range of the batch-major clip order; "0": one
+    attention over the gathered keys."""
     import os
     import torch.multiprocessing as mp
-    model, dm = build("tiny")
-    ref, _ = run(model, inputs("tiny"), "fp32")
+    monkeypatch.setenv("M324_KV_OVERLAP", overlap)            # read at import by the spawned ranks
+    model, dm = build(case)
+    ref, _ = run(model, inputs(case), "fp32")
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 23000 + (os.getpid() * 7 + world) % 4000
-    mp.spawn(_fp_worker, args=(world, port, "tiny", "fp32", ret), nprocs=world, join=True)
+    port = 23000 + (os.getpid() * 7 + world + 3 * int(overlap) + 11 * len(case)) % 4000
+    mp.spawn(_fp_worker, args=(world, port, case, "fp32", ret), nprocs=world, join=True)
     for r in range(world):
         got, loss = ret[r]
         assert got.shape == ref.pcd_moved.shape
