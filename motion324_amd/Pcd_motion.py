@@ -35,6 +35,7 @@ from .transformer import LN_EPS, LNFold, QK_Norm_CrossAttentionBlock, QK_Norm_Tr
 # A/B switches: one table with defaults and meanings in motion324_amd/switches.py (bench.py echoes non-default values)
 AUTO_GRAPH = switches.flag("M324_AUTO_GRAPH")               # forward(): graph replay for repeated inference shapes
 FUSE_HEAD_N3 = switches.flag("M324_FUSE_HEAD")              # head fc1 + GELU + 768 -> 3 in one GEMM epilogue (bf16 inference)
+KV_REHEARSE = int(switches.get("M324_KV_REHEARSE") or 0)       # one-rank rehearsal of the overlapped exchange as rank 0 of W
 KV_OVERLAP = switches.flag("M324_KV_OVERLAP")              # frame-parallel: own keys attended while the K|V all-gather is in flight
 BF16_DECODER_STREAM = switches.flag("M324_BF16_DECODER")    # the decoder's residual stream in bf16 (bf16 inference only)
 HOIST_DECODER_Q = switches.flag("M324_HOIST_Q")             # hoisted decoder q projection (graph capture)
@@ -110,6 +111,12 @@ class _KVGather:
         # partial softmax afterwards (transformer.QK_Norm_SelfAttentionBlock.run); B = 1 (c5): the clip order is frame-major, the
         # rank's own rows are ONE contiguous range of the gathered rows
         self.overlap = KV_OVERLAP and B == 1 and self.world > 1
+        # M324_KV_REHEARSE=W on ONE rank (bench.py --mode frame-parallel with M324_BENCH_COLLECT=1): the block runs the overlapped
+        # form as rank 0 of W would -- the first 1 / W of its frames are "own" keys, the rest arrive by the (identity) gather -- so
+        # that the cost of the split attention + merge can be measured where no second GPU is available
+        self.rehearse = 0
+        if KV_OVERLAP and B == 1 and self.world == 1 and KV_REHEARSE > 1 and T_local >= KV_REHEARSE:
+            self.rehearse, self.overlap = KV_REHEARSE, True
         self.T_full = sum(self.frames)
         self.even = B == 1 and all(f == self.frames[0] for f in self.frames)
         self.comm = torch.cuda.Stream(device=dev)
@@ -136,6 +143,8 @@ class _KVGather:
 
     def local_rows(self):
         """(lo, hi): the rank's own token rows inside the gathered [T_full * Lt] rows (B = 1)."""
+        if self.rehearse:
+            return 0, (self.T // self.rehearse) * self.Lt
         lo = sum(self.frames[:self.rank]) * self.Lt
         return lo, lo + self.frames[self.rank] * self.Lt
 

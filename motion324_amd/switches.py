@@ -20,6 +20,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_DECODE_ROWS": (str(1 << 17), "Pcd_motion.DECODE_ROWS", "max (frames x points) rows per decoder pass"),
     "M324_OVERLAP": ("1", "Pcd_motion.OVERLAP_SHAPE_ENCODER", "inference: shape encoder on a second HIP stream under the image encoder"),
     "M324_KV_OVERLAP": ("1", "Pcd_motion.KV_OVERLAP", "frame-parallel (one sample): every global block attends to the rank's own keys while the k|v all-gather is in flight, then to the gathered remote keys, and merges the partial softmaxes by their log-sum-exps (0: one attention after the gather)"),
+    "M324_KV_REHEARSE": ("0", "Pcd_motion.KV_REHEARSE", "one rank with forced collectives (bench.py M324_BENCH_COLLECT=1): W > 1 runs every global block's overlapped form as rank 0 of W would (own keys = the first 1 / W of the frames), to price the split attention + merge on one GPU"),
     "M324_FOLD_LN": ("2", "transformer.FOLD_LN", "LayerNorm fold: 0 off, 1 bf16 streams only (the decoder), 2 every stream (trunk, DINO too)"),
     "M324_FOLD_MERGE": ("1", "transformer.FOLD_MERGE", "LayerNorm fold: the consumer GEMM merges the producer's per-block row statistics itself (0: m324_rowstats_finish launch between them)"),
     "M324_PAIR_PROJ": ("1", "transformer.PAIR_PROJ", "bf16 inference, decoder: norm_q + norm_kv in one launch and the q + k|v projections in one launch when the q projection runs inside the block (0: four launches)"),

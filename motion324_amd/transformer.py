@@ -305,9 +305,10 @@ class QK_Norm_TransformerBlock(nn.Module):
                     lse = torch.empty((B, H, L), dtype=torch.float32, device=x.device)
                     ops.attention(Q, Kp, Vp, o, prescaled=True, bounded=bounded, lse=lse)
                     return o, lse
-                parts = [part(kv, L)]
-                kv_full, L_full = kv_gather.finish()
                 lo, hi = kv_gather.local_rows()
+                own = kv[lo:hi] if getattr(kv_gather, "rehearse", 0) else kv     # (rehearsal on one rank: a slice of the local rows)
+                parts = [part(own, hi - lo)]
+                kv_full, L_full = kv_gather.finish()
                 for r0, r1 in ((0, lo), (hi, L_full)):
                     if r1 > r0:
                         parts.append(part(kv_full[r0:r1], r1 - r0))

@@ -26,7 +26,7 @@ dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
 import motion324_amd as m
 from motion324_amd import synth, training
-from motion324_amd.optim import FusedAdamW, cosine_with_warmup
+from motion324_amd.optim import FusedAdamW, backward_completion_order, cosine_with_warmup
 
 cfg = synth.make_config(frames=args.frames)
 model = m.Motion_Latent_Model(cfg)
@@ -34,14 +34,14 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict
 model = model.train().to(dev)
 s = synth.synth_inputs(args.batch, args.frames, args.points, args.points, args.hw, seed=1 + rank, with_target=True)
 sample = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
-opt = FusedAdamW(model.named_parameters(), lr=4e-4, betas=(0.9, 0.95), weight_decay=0.05, grad_clip_norm=1.0, allowed_gradnorm_factor=1e9)
+opt = FusedAdamW(model.named_parameters(), lr=4e-4, betas=(0.9, 0.95), weight_decay=0.05, grad_clip_norm=1.0, allowed_gradnorm_factor=1e9,
+                 order=backward_completion_order(model))
 m.set_precision(args.precision)
 
 
 def step(i):
-    loss, _, G = training.forward_backward(model, sample)
-    opt.load_grads(G)
-    opt.all_reduce_mean()
+    loss, _, G = training.forward_backward(model, sample, sink=opt)          # gradients land in the optimizer's flat buffer (as bench.py runs it)
+    opt.finish_reduce()
     info = opt.step(lr=cosine_with_warmup(i, 1000, 30000, 4e-4) or 4e-7)
     return float(loss), info
 
