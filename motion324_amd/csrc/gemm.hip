@@ -333,17 +333,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         rb = dma_rsrc(W + (long)n0 * ldw);
     };
     tile_setup(blockIdx.x);
-    auto issue2a = [&](int i0, int st, int pos) {
+    // (live = false: a look-ahead piece past the end of K -- counted, written, not fetched: gemm_tile.h dma_rsrc_none)
+    const __amdgpu_buffer_rsrc_t rnone = dma_rsrc_none(A);
+    const bool refetch = (xcd_remap & 8) != 0;              // M324_XCD bit 3 (A/B): fetch the last stage again instead, as rounds 1-4 did
+    auto issue2a = [&](int i0, int st, int pos, bool live = true) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            dma_piece(ra, d + i * 1024, va[i0 + i], (unsigned)(st * 128));
+            dma_piece(live ? ra : rnone, d + i * 1024, va[i0 + i], (unsigned)(st * 128));
     };
-    auto issue2b = [&](int i0, int st, int pos) {
+    auto issue2b = [&](int i0, int st, int pos, bool live = true) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            dma_piece(rb, d + i * 1024, vb[i0 + i], (unsigned)(st * 128));
+            dma_piece(live ? rb : rnone, d + i * 1024, vb[i0 + i], (unsigned)(st * 128));
     };
 
     f32x16 acc[4][2];
@@ -408,20 +411,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         pwn = pwn >= 5 ? pwn - 5 : pwn;
         pan = pan >= 5 ? pan - 5 : pan;
         const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
+        const bool wl = s + 1 < NS || refetch, al = s + 2 < NS || refetch;
         load_frags(0, pa, pw, 0);
-        if constexpr (ISSUE) issue2b(0, sw, pwn);
+        if constexpr (ISSUE) issue2b(0, sw, pwn, wl);
         mma8(1);                                            // (s-1, k-step 3); zeros in the first iteration
         sched_kstep();
         load_frags(1, pa, pw, 1);
-        if constexpr (ISSUE) issue2b(2, sw, pwn);
+        if constexpr (ISSUE) issue2b(2, sw, pwn, wl);
         mma8(0);
         sched_kstep();
         load_frags(0, pa, pw, 2);
-        if constexpr (ISSUE) issue2a(0, sa, pan);
+        if constexpr (ISSUE) issue2a(0, sa, pan, al);
         mma8(1);
         sched_kstep();
         load_frags(1, pa, pw, 3);
-        if constexpr (ISSUE) issue2a(2, sa, pan);
+        if constexpr (ISSUE) issue2a(2, sa, pan, al);
         mma8(0);
         sched_kstep();
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -512,11 +516,13 @@ __device__ __forceinline__ void ring2_tile(const bf16_t* __restrict__ A, long ld
         gb[i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + c) * 2);
     }
     const __amdgpu_buffer_rsrc_t ra = dma_rsrc(A + (long)m0 * lda), rb = dma_rsrc(W + (long)n0 * ldw);
-    auto issue2 = [&](const unsigned (&g)[4], int i0, int st, int pos) {
+    const __amdgpu_buffer_rsrc_t rnone = dma_rsrc_none(A);    // look-ahead pieces past the end of K: gemm_tile.h dma_rsrc_none
+    const bool refetch = (xcd_remap & 8) != 0;
+    auto issue2 = [&](const unsigned (&g)[4], int i0, int st, int pos, bool live = true) {
         unsigned char* d = smem + pos * CHUNK13 + wave * 4096 + i0 * 1024;
         const bool isa = &g[0] == &ga[0];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma_piece(isa ? ra : rb, d + i * 1024, g[i0 + i], (unsigned)(st * 128));
+        for (int i = 0; i < 2; ++i) dma_piece(live ? (isa ? ra : rb) : rnone, d + i * 1024, g[i0 + i], (unsigned)(st * 128));
     };
 
     f32x16 acc[2][2];
@@ -574,20 +580,21 @@ __device__ __forceinline__ void ring2_tile(const bf16_t* __restrict__ A, long ld
         pwn = pwn >= 5 ? pwn - 5 : pwn;
         pan = pan >= 5 ? pan - 5 : pan;
         const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
+        const bool wl = s + 1 < NS || refetch, al = s + 2 < NS || refetch;
         load_frags(0, pa, pw, 0);
-        if constexpr (ISSUE) issue2(gb, 0, sw, pwn);
+        if constexpr (ISSUE) issue2(gb, 0, sw, pwn, wl);
         mma4(1);                                            // (s-1, k-step 3); zeros in the first iteration
         sched_phase();
         load_frags(1, pa, pw, 1);
-        if constexpr (ISSUE) issue2(gb, 2, sw, pwn);
+        if constexpr (ISSUE) issue2(gb, 2, sw, pwn, wl);
         mma4(0);
         sched_phase();
         load_frags(0, pa, pw, 2);
-        if constexpr (ISSUE) issue2(ga, 0, sa, pan);
+        if constexpr (ISSUE) issue2(ga, 0, sa, pan, al);
         mma4(1);
         sched_phase();
         load_frags(1, pa, pw, 3);
-        if constexpr (ISSUE) issue2(ga, 2, sa, pan);
+        if constexpr (ISSUE) issue2(ga, 2, sa, pan, al);
         mma4(0);
         sched_phase();
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -968,13 +975,14 @@ static bool vec_ok(const m324_gemm_args* a) {
 // Tile-order mode of tile_of(): M324_XCD bit 0 = contiguous range per XCD, bit 1 = the 4 x 2 group order for weights that
 // do not fit an XCD's L2 beside the streaming A panels AND are wider than deep (q|k|v, fc1: measured HBM fetch -28 % / -13 %
 // at equal time; fc2's K = 3072 A panels dominate its traffic and the group order re-fetches them: +35 %), bit 2 = force
-// it (tests, lab).  Default 3.
+// it (tests, lab), bit 3 = the ring kernels' look-ahead past the end of K fetches the last stage again instead of nothing (A/B).  Default 3.
 static int xcd_mode(const m324_gemm_args* a) {
     const int t = m324::tunable(m324::TUN_XCD);
-    if (!(t & 1)) return 0;
+    const int old_refetch = t & 8;               // bit 3 (A/B): look-ahead pieces past the end of K fetch the last stage again (rounds 1-4)
+    if (!(t & 1)) return old_refetch;
     const long wbytes = (long)a->N * a->K * (a->in_dtype == M324_BF16 ? 2 : 4);
-    if ((t & 4) || ((t & 2) && wbytes > (5l << 19) && a->N >= 2 * a->K)) return 3;
-    return 1;
+    if ((t & 4) || ((t & 2) && wbytes > (5l << 19) && a->N >= 2 * a->K)) return 3 | old_refetch;
+    return 1 | old_refetch;
 }
 
 // Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13|v14 forces a variant (A/B measurements, tests).  (v7, the half-tile ring

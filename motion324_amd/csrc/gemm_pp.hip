@@ -66,12 +66,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const bf16_t* __restric
         rb = dma_rsrc(W + (long)n0 * ldw);
     };
     // pieces i0, i0 + 1 of a chunk (which: 0 Aa, 1 W, 2 Ab) of K-stage st into ring position pos
-    auto issue2 = [&](int which, int i0, int st, int pos) {
+    const __amdgpu_buffer_rsrc_t rnone = dma_rsrc_none(A);    // look-ahead pieces past the end of K: gemm_tile.h dma_rsrc_none
+    auto issue2 = [&](int which, int i0, int st, int pos, bool live = true) {
         unsigned char* d = smem + pos * CH14 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned g = which == 0 ? gaa[i0 + i] : (which == 1 ? gw[i0 + i] : gab[i0 + i]);
-            dma_piece(which == 1 ? rb : ra, d + i * 1024, g, (unsigned)(st * 128));
+            dma_piece(live ? (which == 1 ? rb : ra) : rnone, d + i * 1024, g, (unsigned)(st * 128));
         }
     };
 
@@ -155,23 +156,24 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const bf16_t* __restric
             pb = pb >= 5 ? pb - 5 : pb;
             pan = pan >= 5 ? pan - 5 : pan;
             pwn = pwn >= 5 ? pwn - 5 : pwn;
-            const int sn = s + 1 < NS ? s + 1 : NS - 1;       // past the end the last stage is fetched again (never read)
+            const int sn = s + 1 < NS ? s + 1 : NS - 1;       // past the end: counted and written, not fetched
+            const bool live = s + 1 < NS;
             load_frags(0, pa, pw);
-            issue2(0, 0, sn, pan); issue2(1, 0, sn, pwn);
+            issue2(0, 0, sn, pan, live); issue2(1, 0, sn, pwn, live);
             mma8(3);                                          // (s-1, second half, k-steps 2, 3); zeros in a tile's first stage
             sched_a();
             load_frags(1, pa, pw);
-            issue2(0, 2, sn, pan); issue2(1, 2, sn, pwn);
+            issue2(0, 2, sn, pan, live); issue2(1, 2, sn, pwn, live);
             mma8(0);
             sched_a();
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");    // Y_s: Ab_s landed, Aa_s is in registers
             M324_BARRIER();
             load_frags(2, pb, pw);
-            issue2(2, 0, sn, pa);
+            issue2(2, 0, sn, pa, live);
             mma8(1);
             sched_b();
             load_frags(3, pb, pw);
-            issue2(2, 2, sn, pa);
+            issue2(2, 2, sn, pa, live);
             mma8(2);
             sched_b();
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");    // X_{s+1}: Aa_{s+1}, W_{s+1} landed; stage s is in registers

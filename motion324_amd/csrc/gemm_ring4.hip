@@ -51,11 +51,13 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
         ra = dma_rsrc(A + (long)m0 * lda);
         rb = dma_rsrc(W + (long)n0 * ldw);
     };
-    auto issue4 = [&](const unsigned (&g)[8], int i0, int st, int pos) {
+    const __amdgpu_buffer_rsrc_t rnone = dma_rsrc_none(A);    // look-ahead pieces past the end of K: gemm_tile.h dma_rsrc_none
+    const bool refetch = (xcd_remap & 8) != 0;
+    auto issue4 = [&](const unsigned (&g)[8], int i0, int st, int pos, bool live = true) {
         unsigned char* d = smem + pos * CHUNK10 + wave * 8192 + i0 * 1024;
         const bool isa = &g[0] == &ga[0];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma_piece(isa ? ra : rb, d + i * 1024, g[i0 + i], (unsigned)(st * 128));
+        for (int i = 0; i < 4; ++i) dma_piece(live ? (isa ? ra : rb) : rnone, d + i * 1024, g[i0 + i], (unsigned)(st * 128));
     };
     auto issue_prologue = [&]() {                           // A_0, W_0, A_1 -> chunks 0, 1, 2
         issue4(ga, 0, 0, 0); issue4(ga, 4, 0, 0);
@@ -108,20 +110,21 @@ __global__ __launch_bounds__(256) void gemm_ring4_kernel(const bf16_t* __restric
         pwn = pwn >= 5 ? pwn - 5 : pwn;
         pan = pan >= 5 ? pan - 5 : pan;
         const int sw = s + 1 < NS ? s + 1 : NS - 1, sa = s + 2 < NS ? s + 2 : NS - 1;
+        const bool wl = s + 1 < NS || refetch, al = s + 2 < NS || refetch;
         load_frags(0, pa, pw, 0);
-        if constexpr (ISSUE) issue4(gb, 0, sw, pwn);
+        if constexpr (ISSUE) issue4(gb, 0, sw, pwn, wl);
         mma16(1);                                           // (s-1, k-step 3); zeros in the first iteration
         sched_phase();
         load_frags(1, pa, pw, 1);
-        if constexpr (ISSUE) issue4(gb, 4, sw, pwn);
+        if constexpr (ISSUE) issue4(gb, 4, sw, pwn, wl);
         mma16(0);
         sched_phase();
         load_frags(0, pa, pw, 2);
-        if constexpr (ISSUE) issue4(ga, 0, sa, pan);
+        if constexpr (ISSUE) issue4(ga, 0, sa, pan, al);
         mma16(1);
         sched_phase();
         load_frags(1, pa, pw, 3);
-        if constexpr (ISSUE) issue4(ga, 4, sa, pan);
+        if constexpr (ISSUE) issue4(ga, 4, sa, pan, al);
         mma16(0);
         sched_phase();
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -211,12 +214,14 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
         g[8 + i] = (unsigned)(((long)min(r, N - 1 - n0) * ldw + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
     }
     const __amdgpu_buffer_rsrc_t ra = dma_rsrc(A + (long)m0 * lda), rb = dma_rsrc(W + (long)n0 * ldw);
-    auto issue3 = [&](int i0, int st, int slot) {           // pieces i0 .. i0+2 of stage st
+    const __amdgpu_buffer_rsrc_t rnone = dma_rsrc_none(A);    // look-ahead pieces past the end of K: gemm_tile.h dma_rsrc_none
+    const bool refetch = (xcd_remap & 8) != 0;
+    auto issue3 = [&](int i0, int st, int slot, bool live = true) {           // pieces i0 .. i0+2 of stage st
         unsigned char* base = smem + slot * STAGE12;
 #pragma unroll
         for (int i = i0; i < i0 + 3; ++i) {
             unsigned char* d = i < 8 ? base + wave * 8192 + i * 1024 : base + 32768 + wave * 4096 + (i - 8) * 1024;
-            dma_piece(i < 8 ? ra : rb, d, g[i], (unsigned)(st * 128));
+            dma_piece(live ? (i < 8 ? ra : rb) : rnone, d, g[i], (unsigned)(st * 128));
         }
     };
 
@@ -272,20 +277,21 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
         constexpr bool ISSUE = decltype(issue_tag)::value;
         const int fslot = slot == 0 ? 2 : slot - 1;         // (s + 2) % 3 == (s - 1) % 3
         const int sn = s + 2 < NS ? s + 2 : NS - 1;
+        const bool live = s + 2 < NS || refetch;
         load_frags(0, slot, 0);
-        if constexpr (ISSUE) issue3(0, sn, fslot);
+        if constexpr (ISSUE) issue3(0, sn, fslot, live);
         mma8(1);                                            // (s-1, k-step 3); zeros in the first iteration
         sched_phase();
         load_frags(1, slot, 1);
-        if constexpr (ISSUE) issue3(3, sn, fslot);
+        if constexpr (ISSUE) issue3(3, sn, fslot, live);
         mma8(0);
         sched_phase();
         load_frags(0, slot, 2);
-        if constexpr (ISSUE) issue3(6, sn, fslot);
+        if constexpr (ISSUE) issue3(6, sn, fslot, live);
         mma8(1);
         sched_phase();
         load_frags(1, slot, 3);
-        if constexpr (ISSUE) issue3(9, sn, fslot);
+        if constexpr (ISSUE) issue3(9, sn, fslot, live);
         mma8(0);
         sched_phase();
         asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");

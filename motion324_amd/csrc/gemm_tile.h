@@ -1043,6 +1043,13 @@ typedef __attribute__((address_space(1))) const void glb_ptr_t;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
 }
+// A resource without records: every lane of a piece issued through it is out of range -- the piece still counts in vmcnt and
+// writes its KiB of LDS (zeros), but fetches nothing.  The ring kernels issue a fixed number of pieces per K-stage (counted vmcnt
+// waits, branch-free loop); the look-ahead pieces past the end of K -- 1.5 of a tile's 12 + 1.5 stages at K = 768, 11 % of its
+// operand traffic -- go through this resource instead of fetching the last stage again (round 5).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc_none(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0, 0x00020000);
+}
 __device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)lds, 16, voff, soff, 0, 0);
 }
