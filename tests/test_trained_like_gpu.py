@@ -186,7 +186,14 @@ def test_trained_like_weights_at_c1_size(monkeypatch):
     assert e32 < FP32_TOL
     assert torch.isfinite(out16.pcd_moved).all()
     assert e16 < TRAINED_LIKE_BF16_TOL
+    # the reference's OWN autocast(bf16) forward against its own fp32 one on these weights and inputs (measured by
+    # tests/golden/make_trained_like_band.py on the imported reference): the HIP path's bf16 mode must not be wider
+    import json, os
+    band = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_like_band.json")))
+    print(f"    reference autocast(bf16) vs its fp32: synthetic weights {band['synthetic']:.2e}, trained-like {band['trained_like']:.2e}")
+    assert e16 < band["trained_like"]
 
 
-# measured on MI355X (round 5): see the test's printout in profiles/r05_parity_trained_like.md; gate = measured band + 25 %
-TRAINED_LIKE_BF16_TOL = 2e-2
+# measured on MI355X (round 5): 1.84e-2 - 1.92e-2 (profiles/r05_parity_trained_like.md; none of the bf16-mode shortcuts contributes:
+# each switched off leaves 1.7e-2 - 1.8e-2); gate = measured band + 25 %
+TRAINED_LIKE_BF16_TOL = 2.4e-2
