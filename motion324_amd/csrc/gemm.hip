@@ -846,12 +846,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 // least one 256 x 256 tile): half the LDS-DMA pieces per FLOP of the 128 x 128 kernel above, which is texture-path-bound.
 // Ring slot = X[32 m][256 n] + Y[32 m][256 j] (512-byte rows, 16 KiB each); an LDS-DMA piece = 2 rows x 512 B; slot of
 // (row r, 16-byte chunk c) = c ^ 4 (r & 3).  Per k-step a wave reads 6 fragments = 12 transposing reads for 8 MFMAs.
-__global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ Y,
-                                                              long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc,
-                                                              int ks, long strideC, int ntj) {
-    constexpr int TROW = 512, TOP = 32 * TROW;   // bytes per LDS row; one operand of a slot (16 KiB)
-    constexpr int RING = 4, PPW = 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING * 2 * TOP];
+// The body sees the ring through THREE __restrict__ pointers (LDS-DMA destinations, fragment reads, epilogue scratch): the
+// transposing read is an intrinsic with a memory operand, and hipcc's wait-count pass puts `s_waitcnt vmcnt(0)` in front of every LDS
+// access that may touch the bytes of an LDS-DMA in flight -- twice per half-tile here, which drained the ring every iteration
+// (rounds 1-4: 2320 cycles per half-tile for 1024 of MFMA, waves parked 74 % of their cycles, and a deeper ring changed nothing).
+// With alias scopes it trusts the kernel's own counted waits and barriers, which order every slot's fill against its reads.
+constexpr int TN_TROW = 512, TN_TOP = 32 * TN_TROW, TN_RING = 4;      // bytes per LDS row; one operand of a slot (16 KiB); slots
+__device__ __forceinline__ void tn_pipe_body(unsigned char* __restrict__ ring_w, const unsigned char* __restrict__ ring_r,
+                                             float* __restrict__ scratch, const bf16_t* __restrict__ X, long ldx,
+                                             const bf16_t* __restrict__ Y, long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc,
+                                             int ks, long strideC, int ntj) {
+    constexpr int TROW = TN_TROW, TOP = TN_TOP;
+    constexpr int RING = TN_RING, PPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -872,12 +878,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __re
     }
     const __amdgpu_buffer_rsrc_t rx = dma_rsrc(X + (long)mbeg * ldx), ry = dma_rsrc(Y + (long)mbeg * ldy);
     auto issue_x = [&](int h, int slot) {
-        unsigned char* st = smem + slot * 2 * TOP + wave * 2048;
+        unsigned char* st = ring_w + slot * 2 * TOP + wave * 2048;
 #pragma unroll
         for (int p = 0; p < 2; ++p) dma_piece(rx, st + p * 1024, gx[p], (unsigned)((long)h * 32 * ldx * 2));
     };
     auto issue_y = [&](int h, int slot) {
-        unsigned char* st = smem + slot * 2 * TOP + TOP + wave * 2048;
+        unsigned char* st = ring_w + slot * 2 * TOP + TOP + wave * 2048;
 #pragma unroll
         for (int p = 0; p < 2; ++p) dma_piece(ry, st + p * 1024, gy[p], (unsigned)((long)h * 32 * ldy * 2));
     };
@@ -909,7 +915,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __re
         return __builtin_bit_cast(bf16x8, v);
     };
     auto load_frags = [&](int set, int slot, int k16) {
-        const unsigned char* base = smem + slot * 2 * TOP + k16 * (16 * TROW);
+        const unsigned char* base = ring_r + slot * 2 * TOP + k16 * (16 * TROW);
 #pragma unroll
         for (int b = 0; b < 2; ++b) fy[set][b] = frag(base + yo[b]);
 #pragma unroll
@@ -935,14 +941,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __re
         issue_x(h < NH ? h : NH - 1, h);
         issue_y(h < NH ? h : NH - 1, h);
     }
-    M324_WAIT_PIECES(2 * PPW);
+    M324_WAIT_PIECES((RING - 2) * PPW);                 // half-tile 0 landed
     M324_BARRIER();
     load_frags(0, 0, 0);
     int slot = 0;
     for (int h = 0; h < NH; ++h) {
-        const int nslot = (slot + 1) & 3, fslot = (slot + 3) & 3;
-        const int hn = h + 3 < NH ? h + 3 : NH - 1;
-        M324_WAIT_PIECES(PPW);
+        const int nslot = slot + 1 == RING ? 0 : slot + 1, fslot = slot == 0 ? RING - 1 : slot - 1;     // fslot: half-tile h - 1's
+        const int hn = h + RING - 1 < NH ? h + RING - 1 : NH - 1;
+        M324_WAIT_PIECES((RING - 3) * PPW);             // half-tile h + 1 landed; RING - 3 later ones may fly
         M324_BARRIER();
         load_frags(1, slot, 1);
         issue_x(hn, fslot);
@@ -959,8 +965,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __re
 #undef M324_SG
     M324_BARRIER();
     Epilogue ep{};
-    store_tile_lds<float, 0, 0, 4>(acc, reinterpret_cast<float*>(smem) + wave * EP_WAVE_FLOATS, C, ldc, N, Kc, n0 + wm * 128,
+    store_tile_lds<float, 0, 0, 4>(acc, scratch + wave * EP_WAVE_FLOATS, C, ldc, N, Kc, n0 + wm * 128,
                                    j0 + wn * 64, lane, ep);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ Y,
+                                                              long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc,
+                                                              int ks, long strideC, int ntj) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[TN_RING * 2 * TN_TOP];
+    tn_pipe_body(smem, smem, reinterpret_cast<float*>(smem), X, ldx, Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
 }
 
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
