@@ -296,11 +296,17 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
 // Past the end of K the last stage is fetched again into free chunks (never read), so the loop is branch-free.
 
 
+// Every ring kernel's body sees its LDS through THREE __restrict__ pointers -- LDS-DMA destinations, fragment reads, epilogue scratch
+// (round 5).  hipcc's wait-count pass assumes that an LDS access may touch the bytes of any LDS-DMA it knows to be in flight and puts
+// `s_waitcnt vmcnt(0)` in front of it: in the first K-stage of every tile (the ring prologue / the next tile's prefetched chunks had just
+// been issued) and in front of the epilogue's first scratch access (the chunks prefetched under the epilogue had to LAND before the
+// epilogue could start) -- a full drain of the pipeline at each.  The kernels' own counted waits and barriers order every chunk's fill
+// against its reads; the alias scopes tell the pass so.  (The TN weight-gradient kernel lost 17-21 % of its time to the same drains.)
 template <typename TOUT, int ACT, int RES>
-__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
-                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
-                                                           int xcd_remap) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * CHUNK10];
+__device__ __forceinline__ void gemm_ring_body(unsigned char* __restrict__ ring_w, const unsigned char* __restrict__ smem,
+                                               float* __restrict__ scratch, const bf16_t* __restrict__ A, long lda,
+                                               const bf16_t* __restrict__ W, long ldw, TOUT* C, long ldc, int M, int N, int K,
+                                               const Epilogue& ep, int ntn, int xcd_remap) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -337,13 +343,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     const __amdgpu_buffer_rsrc_t rnone = dma_rsrc_none(A);
     const bool refetch = (xcd_remap & 8) != 0;              // M324_XCD bit 3 (A/B): fetch the last stage again instead, as rounds 1-4 did
     auto issue2a = [&](int i0, int st, int pos, bool live = true) {
-        unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
+        unsigned char* d = ring_w + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             dma_piece(live ? ra : rnone, d + i * 1024, va[i0 + i], (unsigned)(st * 128));
     };
     auto issue2b = [&](int i0, int st, int pos, bool live = true) {
-        unsigned char* d = smem + pos * CHUNK10 + wave * 4096 + i0 * 1024;
+        unsigned char* d = ring_w + pos * CHUNK10 + wave * 4096 + i0 * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             dma_piece(live ? rb : rnone, d + i * 1024, vb[i0 + i], (unsigned)(st * 128));
@@ -391,18 +397,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
     {
         LnPreT<4> first;
         ln_prefetch<ACT, 4, false>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, first, wn, ln_table);
-        // prologue of the FIRST tile: the whole ring -- A_0, W_0, A_1, W_1, A_2 (chunks 0..4) -- so the first K-stages of a tile
-        // (12 in all at K = 768) do not start with a look-ahead of one chunk; stage 0 then has nothing to issue
-        const int s1 = NS > 1 ? 1 : 0, s2 = NS > 2 ? 2 : NS - 1;
+        // prologue of the FIRST tile: A_0, W_0 (chunks 0, 1); A_1 goes out in front of stage 0 like every later tile's, W_1 and A_2
+        // inside stage 0.  (Rounds 1-4 issued the whole ring here and ran a peeled stage 0 without issues; hipcc's wait-count pass
+        // answered every fragment read of such straight-line code behind an LDS-DMA issue with `s_waitcnt vmcnt(0)` -- a full drain at
+        // the start of EVERY tile.  Inside the K loop it trusts the kernel's counted waits, so all K-stages now run there.)
         issue2a(0, 0, 0); issue2a(2, 0, 0);
         issue2b(0, 0, 1); issue2b(2, 0, 1);
-        issue2a(0, s1, 2); issue2a(2, s1, 2);
-        issue2b(0, s1, 3); issue2b(2, s1, 3);
-        issue2a(0, s2, 4); issue2a(2, s2, 4);
         ln_finish<ACT, 4>(ep, lane, first);
         ln_rs = first.rs, ln_cs = first.cs;
     }
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage 0 landed (A_1, W_1, A_2 may fly)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage 0 landed
     M324_BARRIER();
     int pa = 0, pw = 1;                                     // ring positions of A_s, W_s
     auto stage = [&](int s, auto issue_tag) {
@@ -449,15 +453,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[1][j] = (bf16x8)(0);
         pa = 0, pw = 1;
-        if (t == (int)blockIdx.x) {
-            stage(0, std::false_type{});                    // the first tile found the whole ring issued
-        } else {
-            // later tiles: A_0, W_0 arrived under the previous epilogue; A_1 goes out first, W_1 and A_2 with the stage
+        {
+            // A_0, W_0 are in place (first tile: the prologue; later tiles: they arrived under the previous epilogue); A_1 goes out
+            // first, W_1 and A_2 with stage 0
             const int s1 = NS > 1 ? 1 : 0;
             issue2a(0, s1, 2); issue2a(2, s1, 2);
-            stage(0, std::true_type{});
         }
-        for (int s = 1; s < NS; ++s) stage(s, std::true_type{});
+        for (int s = 0; s < NS; ++s) stage(s, std::true_type{});
         mma8(1);                                            // (NS-1, k-step 3)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the main loop: the ring becomes scratch
         M324_BARRIER();
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
             issue2a(0, 0, 0); issue2a(2, 0, 0);
             issue2b(0, 0, 1); issue2b(2, 0, 1);
         }
-        store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem + 2 * CHUNK10) + wave * ep_wave_floats(ACT), C, ldc, M, N,
+        store_tile_lds<TOUT, ACT, RES, 4>(acc, scratch + wave * ep_wave_floats(ACT), C, ldc, M, N,
                                           mt + wm * 128, nt + wn * 64, lane, ep, &ln_pre);
         if (more) {
             LnPreT<4> next;                                 // m0 / n0 are the next tile's already
@@ -481,6 +483,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restr
         }
     }
 #undef M324_SG
+}
+
+template <typename TOUT, int ACT, int RES>
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W,
+                                                           long ldw, TOUT* C, long ldc, int M, int N, int K, Epilogue ep, int ntn,
+                                                           int xcd_remap) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * CHUNK10];
+    gemm_ring_body<TOUT, ACT, RES>(smem, smem, reinterpret_cast<float*>(smem + 2 * CHUNK10), A, lda, W, ldw, C, ldc, M, N, K, ep, ntn, xcd_remap);
 }
 
 // ------------------------------------------------------------------------------------------------
