@@ -14,10 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libm324.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "gemm_pp.hip", "attention.hip", "attention_pwg.hip", "elementwise.hip", "backward.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "gemm_pp.hip", "gemm_hp.hip", "attention.hip", "attention_pwg.hip", "elementwise.hip", "backward.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(HERE, "..", "include", "m324.h"),
            os.path.join(CSRC, "attn_pwg_asm.inc"), os.path.join(CSRC, "attn_pwg_bounded_asm.inc"), os.path.join(CSRC, "attn_pwg_clobbers.inc"),
-           os.path.join(CSRC, "attn_pwg_kernel.inl")]
+           os.path.join(CSRC, "attn_pwg_kernel.inl"), os.path.join(CSRC, "gemm_hp_kernel.inl"), os.path.join(CSRC, "gemm_hp_clobbers.inc")] + [
+           os.path.join(CSRC, f"gemm_hp_{k}.inc") for k in ("gelu", "fold_gelu", "plain", "fold")]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950 has one unified 512-entry file), which removes the
 # v_accvgpr_read/write shuffling around every softmax / epilogue access of an accumulator
 # -fno-slp-vectorize: hipcc packs adjacent scalar fp32 adds / multiplies into v_pk_*_f32.  Next to a DPP reduction that turns

@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void rowstats_finish_kernel(const float2* __re
                                                               float2* __restrict__ rowstat) {
     const long m = (long)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
+    if ((ncb & 1) == 0) {
+        // even block counts: the arithmetic of the consumer GEMMs that merge the table themselves (gemm_tile.h ln_chan_step /
+        // ln_combine_halves: each half of the blocks by Chan's update, block after block, then the pairwise form for equal counts) --
+        // a folded product does not depend on WHO merged its rows' statistics (round 5: schedule v15 takes the merged table)
+        const int h = ncb >> 1;
+        float mean[2], m2[2];
+        for (int half = 0; half < 2; ++half) {
+            const float2 p0 = part[(long)(half * h) * M + m];
+            mean[half] = p0.x * (1.0f / 64.0f), m2[half] = p0.y;
+            for (int i = 1; i < h; ++i) {
+                const float2 pb = part[(long)(half * h + i) * M + m];
+                const float d = pb.x * (1.0f / 64.0f) - mean[half];
+                mean[half] = fmaf(d, 1.0f / (float)(i + 1), mean[half]);
+                m2[half] = m2[half] + fmaf(d * d, 64.0f * (float)i / (float)(i + 1), pb.y);
+            }
+        }
+        const float d = mean[1] - mean[0];
+        const float mm2 = (m2[0] + m2[1]) + (d * d) * (32.0f * (float)h);
+        const float mean_ = fmaf(0.5f, d, mean[0]);
+        const float rstd = rsqrtf(mm2 / (64.0f * (float)ncb) + eps);
+        rowstat[m] = make_float2(rstd, -rstd * mean_);
+        return;
+    }
     float s = 0.f;
     for (int b = 0; b < ncb; ++b) s += part[(long)b * M + m].x;
     const float n = 64.0f * (float)ncb, mean = s / n;

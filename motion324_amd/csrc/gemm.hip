@@ -1008,7 +1008,7 @@ static int xcd_mode(const m324_gemm_args* a) {
     return 1 | old_refetch;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13|v14 forces a variant (A/B measurements, tests).  (v7, the half-tile ring
+// Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13|v14|v15 forces a variant (A/B measurements, tests).  (v7, the half-tile ring
 // the chunk-ring kernels replaced, was retired in round 3: no shape reaches it -- K is a multiple of 64 for bf16 -- and its
 // A/B tables are kept in profiles/r01_ab_gemm_schedules.md.)
 static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_GEMM at load / m324_set_tunable
@@ -1024,6 +1024,15 @@ static int ring_grid(long ntiles) {
     if (m324::tunable(m324::TUN_GEMM_PERSIST) == 0 || n_cu <= 0) return (int)ntiles;
     return (int)(ntiles < n_cu ? ntiles : n_cu);
 }
+
+static Epilogue make_epilogue(const m324_gemm_args* a);
+// v15's epilogue code as gemm_hp.hip counts it: GELU bit 0, LayerNorm-fold consumer bit 3; -1: an epilogue it does not build
+static int hp_act(const m324_gemm_args* a) {
+    if (a->aux_mode != M324_AUX_NONE || (a->act != M324_ACT_NONE && a->act != M324_ACT_GELU)) return -1;
+    return (a->act == M324_ACT_GELU ? 1 : 0) | (a->ln_rowstat ? 8 : 0);
+}
+static int hp_res(const m324_gemm_args* a) { return (!a->residual && a->row_gin <= 0) ? 0 : 1; }
+static bool nbatch_one(const m324_gemm_args* a) { return a->batch <= 1; }
 
 static int pick_variant(const m324_gemm_args* a) {
     if (!vec_ok(a)) return 1;
@@ -1042,6 +1051,11 @@ static int pick_variant(const m324_gemm_args* a) {
         if (pp_ok) return 14;
         f = 0;
     }
+    // v15 (gemm_hp.hip): the hand-placed K = 768 stream with the deferred epilogue; hp_ok lists what it takes
+    if (f == 15) {
+        if (ring_ok && nbatch_one(a) && m324::hp_ok(a, make_epilogue(a), hp_act(a), hp_res(a))) return 15;
+        f = 0;
+    }
     if (a->M <= 64 && bf16 && !a->aux_mode && (f == 0 || f == 9)) return 9;
     // 256 x 256 tiles halve the LDS-DMA traffic per FLOP: fastest whenever the column count quantises (N % 256 == 0)
     // and the tiles fill most of the 256 CUs in whole rounds; otherwise the 128 x 128 tiles of v2 (two workgroups per
@@ -1053,6 +1067,16 @@ static int pick_variant(const m324_gemm_args* a) {
     // tiles quantise badly and the epilogue is light -- plain wide bf16 outputs (the training step's q|k|v projections: 42.8 us
     // against 47.8-49.0 at 10368 x 2304 x 768) -- and loses with GELU / head-major / LayerNorm-fold epilogues, which do not hide
     // beside the partner workgroup's MFMA stream.  M324_PP=0: never; bit 1: also where the 256 x 256 tiling fills its rounds (A/B); M324_GEMM=v14 forces it for every epilogue it builds.
+    // v15 (round 5, gemm_hp.hip): one wave per SIMD, hand-placed stream, the previous tile's epilogue between the MFMAs of the current
+    // tile.  Measured on random data, same box, interleaved (profiles/r05_gemm_hp.md): plain 10368 x 2304 x 768 41.4 us against v14's
+    // 44.2, v13's 48.8, v10's 50.2 -- the training step 93.3 -> 92.1-92.7 ms (M324_HP bit 1, default); fc1 + GELU 10368 x 3072
+    // 55.9 against v10's 57.8, 65536 x 3072 305.7 against 316.2: the chip is power-limited, a denser stream clocks lower, and with
+    // the m324_rowstats_finish launch the stream needs in front of a folded consumer the clip does not move (bit 0, off).  With one
+    // tile per workgroup nothing overlaps (the epilogue is the exposed tail): at least two tiles per CU.
+    if (f == 0 && ring_ok && nbatch_one(a) && m324::tunable(m324::TUN_HP) != 0 && a->K == 768 && a->N % 128 == 0 &&
+        (long)(a->N / 128) * ceil_div(a->M, BM5) >= 512 && hp_act(a) >= 0 &&
+        (m324::tunable(m324::TUN_HP) & ((hp_act(a) & 1) ? 1 : 2)) != 0 && m324::hp_ok(a, make_epilogue(a), hp_act(a), hp_res(a)))
+        return 15;
     const long t14 = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5);
     const long t5q = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const bool plain = a->act == M324_ACT_NONE && a->aux_mode == M324_AUX_NONE && !a->ln_rowstat && !a->gamma;
@@ -1142,7 +1166,10 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
         }
     }
     const int variant = nbatch > 1 ? 2 : pick_variant(a);
-    if (variant == 1) {
+    if (variant == 15) {
+        const int rc_ = m324::launch_hp(a, s, ep, hp_act(a), hp_res(a), xcd_mode(a));
+        if (rc_ != M324_OK) return rc_;
+    } else if (variant == 1) {
         hipLaunchKernelGGL((gemm_kernel<TIN, TOUT>), grid, dim3(256), 0, s, (const TIN*)a->A, a->lda, (const TIN*)a->W,
                            a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep);
     } else if (variant == 9) {
@@ -1267,6 +1294,7 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
         case 12: name = "gemm_ring3_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); break;
         case 13: name = "gemm_ring2_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
         case 14: name = "gemm_pp_kernel"; wg = m324::pp_grid(a); break;
+        case 15: name = "gemm_hp_kernel"; wg = m324::hp_grid(a); break;
         default: break;
     }
     // grid in threads, as rocprofv3's kernel trace prints it (x, y, z)

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import ops
 from .lib import ACT_GELU
 from .prepared import Prepared, pad_k
-from .transformer import LNFold, fuse_qkv
+from .transformer import LNFold, fuse_qkv, hp_consumer
 
 DINO_EPS = 1e-6
 TWO_STREAMS = True       # run(): under graph capture, two half-batches of frames as two branches (see the comment there)
@@ -186,7 +186,7 @@ class DinoEncoder(nn.Module):
                      **(fold.producer() if fold is not None else {}))
             if fold is not None:
                 w1, cs1, b1 = w["f_fc1"]
-                ops.gemm(fold.xb, w1, h1[r], bias=b1, act=ACT_GELU, ln=fold.ln(DINO_EPS, cs1))
+                ops.gemm(fold.xb, w1, h1[r], bias=b1, act=ACT_GELU, ln=fold.ln(DINO_EPS, cs1, merged=hp_consumer(fold.rows, w1.shape[0], w1.shape[1])))
             else:
                 ops.layernorm(x[r], *w["n2"], DINO_EPS, h[r])
                 ops.gemm(h[r], w["fc1"][0], h1[r], bias=w["fc1"][1], act=ACT_GELU)

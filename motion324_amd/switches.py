@@ -36,7 +36,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
 }
 # Library switches (C++; read by libm324 once, when it is loaded -- csrc/runtime.hip; m324_set_tunable overrides them)
 LIBRARY: Dict[str, Tuple[str, str]] = {
-    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13 | v14); 0 = chooser"),
+    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13 | v14 | v15); 0 = chooser"),
     "M324_GEMM_TN": ("0", "128: force the 128 x 128 weight-gradient kernel"),
     "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges, bit 1 4 x 2 group order for wide weights, bit 2 force it; bit 3: the ring GEMMs' look-ahead pieces past the end of K fetch the last stage again (rounds 1-4) instead of nothing (A/B)"),
     "M324_ATTN_NW": ("0", "attention forward: waves per workgroup (4 | 8); 0 = by sequence length"),
@@ -50,13 +50,15 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
     "M324_NT_MB": ("128", "GEMM: bf16 outputs (no residual) larger than this many MiB are stored nontemporal"),
     "M324_PP": ("1", "plain wide bf16 outputs whose 256 x 256 tiling fills < 85 % of its rounds (the training step's q|k|v projections) on v14: two persistent 256 x 128 workgroups per CU (0: the chunk rings of round 4)"),
+    "M324_HP": ("2", "schedule v15 (one wave per SIMD, hand-placed stream, the previous tile's epilogue between the MFMAs of the current one) for K = 768 GEMMs with bf16 output and at least two 256 x 128 tiles per CU: bit 1 the bias-only / plain epilogues (the training step's projections), bit 0 the GELU epilogues (fc1; folded consumers then get the merged statistics table from the host); 0: never"),
     "M324_PP_SKEW": ("0", "v14: start offset of a CU's second workgroup in units of 1024 cycles (0 = by epilogue: 7 with GELU / q|k|v heads, else 4; -1 = none)"),
     "M324_GEMM_PERSIST": ("1", "256 x 256 chunk-ring GEMM (v10): 1 = one persistent workgroup per CU, next tile's first chunks under the epilogue; 0 = one workgroup per tile"),
 }
 
 
 def get(name: str) -> str:
-    return os.environ.get(name, HOST[name][0])
+    """value of a switch: host switches, and library switches the host mirrors (M324_HP: transformer.hp_consumer)"""
+    return os.environ.get(name, (HOST.get(name) or LIBRARY[name])[0])
 
 
 def flag(name: str) -> bool:

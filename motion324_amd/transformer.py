@@ -132,6 +132,7 @@ FOLD_LN = int(switches.get("M324_FOLD_LN"))
 PAIR_PROJ = switches.flag("M324_PAIR_PROJ")         # the decoder's q and k|v LayerNorms / projections as two launches instead of four
 FOLD_MERGE = switches.flag("M324_FOLD_MERGE")      # folded consumers merge the producer's per-block statistics themselves
 ATTN_BOUNDED = switches.flag("M324_ATTN_BOUNDED")
+HP = int(switches.get("M324_HP"))                  # schedule v15 of m324_gemm (K = 768, GELU): takes the MERGED statistics table
 
 
 class LNFold:
@@ -165,10 +166,12 @@ class LNFold:
         self.pending = True
         return dict(stats_out=self.part, copy_out=self.xb if self.own_copy else None)
 
-    def ln(self, eps: float, colsum: torch.Tensor) -> tuple:
+    def ln(self, eps: float, colsum: torch.Tensor, merged: bool = False) -> tuple:
         """The `ln` argument of the ops.gemm call that consumes the stream: the merged table, or -- statistics still in the
-        producer's per-block form and M324_FOLD_MERGE on -- that table itself, merged by the consumer (no launch in between)."""
-        if self.pending and FOLD_MERGE and self.C <= 1024 and self.C % 128 == 0:      # m324_gemm: an even block count <= 16
+        producer's per-block form and M324_FOLD_MERGE on -- that table itself, merged by the consumer (no launch in between).
+        merged: the consumer is one that m324_gemm runs on schedule v15 (hp_consumer below), which reads the merged table: the
+        m324_rowstats_finish launch (2.5-4 us, the same arithmetic as the consumers' own merge) buys a GEMM 7-45 us shorter."""
+        if self.pending and FOLD_MERGE and not merged and self.C <= 1024 and self.C % 128 == 0:      # m324_gemm: an even block count <= 16
             return (self.part, colsum, eps)
         return (self.ready(eps), colsum)
 
@@ -177,6 +180,12 @@ class LNFold:
             ops.rowstats_finish(self.part, eps, self.stat)
             self.pending = False
         return self.stat
+
+
+def hp_consumer(rows: int, n_out: int, k: int) -> bool:
+    """m324_gemm's rule for schedule v15 (csrc/gemm.hip pick_variant): K = 768, GELU epilogue, N % 128 == 0, at least two 256 x 128
+    tiles per CU.  The host mirrors it only to hand such a consumer the merged statistics table."""
+    return (HP & 1) != 0 and k == 768 and n_out % 128 == 0 and (n_out // 128) * ((rows + 255) // 256) >= 512
 
 
 def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor, fold: Optional[LNFold] = None,
@@ -188,7 +197,7 @@ def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor, f
     h1 = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=x.device)
     if fold is not None:
         w1, cs1, b1 = P.folded(norm2.weight, norm2.bias, fc1.weight, fc1.bias)
-        ops.gemm(fold.xb, w1, h1, bias=b1, act=ACT_GELU, ln=fold.ln(norm2.eps, cs1))
+        ops.gemm(fold.xb, w1, h1, bias=b1, act=ACT_GELU, ln=fold.ln(norm2.eps, cs1, merged=hp_consumer(rows, fc1.out_features, C)))
         ops.gemm(h1, P.mat(fc2.weight), x, bias=P.vec(fc2.bias), residual=x, **(fold.producer() if feed_next else {}))
         return x
     h = torch.empty((rows, C), dtype=P.dtype, device=x.device)

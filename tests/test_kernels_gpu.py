@@ -306,6 +306,109 @@ def test_gemm_ring_kernels_are_race_free(tune, variant, M, N, K):
                 assert torch.equal(o, ref), f"launch {it}: result differs"
 
 
+def _plan(ops_mod, a, w, out, **kw):
+    """the kernel m324_gemm would launch for this call (m324_gemm_plan through the timing label of ops.gemm)"""
+    from motion324_amd import timing
+    with timing.Recorder() as rec:
+        ops_mod.gemm(a, w, out, **kw)
+    torch.cuda.synchronize()
+    return " ".join(item[5] for item in rec.items)
+
+
+@pytest.mark.parametrize("M,N", [(256, 128), (200, 128), (512, 384), (1000, 256), (2304, 1536), (8224, 3072)])
+@pytest.mark.parametrize("mode", ["gelu", "bias", "fold_gelu", "fold", "nobias", "nobias_gelu"])
+def test_gemm_v15_hand_placed_stream_equals_the_tile_kernels(tune, M, N, mode):
+    """Schedule v15 (csrc/gemm_hp.hip: one wave per SIMD, the previous tile's epilogue between the MFMAs of the current tile, stores
+    through the wave's LDS scratch) at K = 768: one tile, a ragged single tile, more workgroups than tiles, a ragged last row of
+    tiles, several tiles per workgroup (first tile without an epilogue, A / B accumulator sets, exposed tail) -- bias, bias + GELU and
+    the LayerNorm-fold consumer forms of both with a merged statistics table.  Same k order, same epilogue arithmetic as the
+    128 x 128 kernel: bit-identical; and within bf16 rounding of the fp64 result."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU, ACT_NONE
+    K, dtype = 768, torch.bfloat16
+    a, w = _q(_rand((M, K), 71), dtype).to(dtype).to(DEV), _q(_rand((N, K), 72, 0.03), dtype).to(dtype).to(DEV)
+    bias = _rand((N,), 73).to(DEV)
+    rowstat = torch.stack([torch.rand(M) + 0.5, 0.1 * torch.randn(M)], dim=1).contiguous().to(DEV)
+    colsum = _rand((N,), 74).to(DEV)
+    if "nobias" in mode:
+        bias = None
+    kw = dict(bias=bias, act=ACT_GELU if "gelu" in mode else ACT_NONE, ln=(rowstat, colsum) if "fold" in mode else None)
+    tune("M324_GEMM", "v2")
+    ref = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a, w, ref, **kw)
+    tune("M324_GEMM", "v15")
+    out = torch.full((M + 3, N), 7.0, dtype=dtype, device=DEV)          # three guard rows behind the ragged tile
+    ops.gemm(a, w, out[:M], **kw)
+    assert torch.equal(out[:M], ref)
+    assert float((out[M:].float() - 7.0).abs().max()) == 0.0              # rows past M are clipped by the store resource
+    v = a.double().cpu() @ w.double().cpu().T
+    if "fold" in mode:
+        v = rowstat[:, :1].double().cpu() * v + rowstat[:, 1:2].double().cpu() * colsum.double().cpu()
+    if bias is not None:
+        v = v + bias.double().cpu()
+    if "gelu" in mode:
+        v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+    assert rel_err(out[:M].float(), v) < TOL[dtype]
+
+
+def test_gemm_v15_is_chosen_where_it_was_measured_faster_and_only_there(tune):
+    """The chooser sends K = 768 GEMMs with a plain / bias-only bf16 epilogue and at least two 256 x 128 tiles per CU to v15 (M324_HP bit 1,
+    default; profiles/r05_gemm_hp.md), the GELU epilogues only with bit 0; what the stream does not build (residual, fp32 output, an
+    unmerged statistics table, one tile per workgroup) stays on the round-4 schedules, and a forced v15 falls back to the chooser
+    for those instead of failing."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    dtype = torch.bfloat16
+    M, N, K = 10368, 3072, 768
+    a, w = _q(_rand((M, K), 75), dtype).to(dtype).to(DEV), _q(_rand((N, K), 76, 0.03), dtype).to(dtype).to(DEV)
+    bias = _rand((N,), 77).to(DEV)
+    out = torch.empty((M, N), dtype=dtype, device=DEV)
+    assert "gemm_hp_kernel" in _plan(ops, a, w, out, bias=bias)                        # default M324_HP=2: bias-only / plain epilogues
+    assert "gemm_hp_kernel" in _plan(ops, a, w, out)                                   # no bias: a bias resource without records
+    assert "gemm_hp_kernel" not in _plan(ops, a, w, out, bias=bias, act=ACT_GELU)      # GELU: bit 0
+    assert "gemm_hp_kernel" not in _plan(ops, a[:2048], w, out[:2048], bias=bias)      # 192 tiles: one per workgroup
+    outf = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    assert "gemm_hp_kernel" not in _plan(ops, a, w, outf, bias=bias)
+    tune("M324_HP", 3)
+    assert "gemm_hp_kernel" in _plan(ops, a, w, out, bias=bias, act=ACT_GELU)
+    part = torch.rand((K // 64, M, 2), device=DEV)
+    colsum = _rand((N,), 78).to(DEV)
+    assert "gemm_hp_kernel" not in _plan(ops, a, w, out, bias=bias, act=ACT_GELU, ln=(part, colsum, 1e-5))      # unmerged table
+    rowstat = torch.rand((M, 2), device=DEV)
+    assert "gemm_hp_kernel" in _plan(ops, a, w, out, bias=bias, act=ACT_GELU, ln=(rowstat, colsum))
+    tune("M324_HP", 0)
+    assert "gemm_hp_kernel" not in _plan(ops, a, w, out, bias=bias)
+    tune("M324_HP", 2)
+    tune("M324_GEMM", "v15")
+    x = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm(a, w, x, residual=x)                                                        # forced, not built: the chooser's kernel runs
+    assert rel_err(x, a.double().cpu() @ w.double().cpu().T) < 1e-5
+
+
+@pytest.mark.parametrize("M", [10368, 65536])
+def test_gemm_v15_is_race_free_and_streams_large_outputs(tune, M):
+    """Forty launches at the model's fc1 shapes must give forty bit-identical results equal to the 128 x 128 kernel's: the stream states
+    its own vmcnt / lgkmcnt waits (gen_gemm_hp.py resolves them from the instruction order) and a missing one shows up as a tile read
+    before it landed -- rarely, and only when the chip is full.  M = 65536: the 402-MB output leaves through nontemporal stores."""
+    ops = _ops()
+    from motion324_amd.lib import ACT_GELU
+    dtype = torch.bfloat16
+    N, K = 3072, 768
+    a = _q(_rand((M, K), 81), dtype).to(dtype).to(DEV)
+    w = _q(_rand((N, K), 82, 0.05), dtype).to(dtype).to(DEV)
+    bias = _rand((N,), 83).to(DEV)
+    tune("M324_GEMM", "v2")
+    ref = torch.empty((M, N), dtype=dtype, device=DEV)
+    ops.gemm(a, w, ref, bias=bias, act=ACT_GELU)
+    tune("M324_GEMM", "v15")
+    outs = [torch.empty((M, N), dtype=dtype, device=DEV) for _ in range(2)]
+    for it in range(40 if M < 20000 else 12):
+        ops.gemm(a, w, outs[it % 2], bias=bias, act=ACT_GELU)
+        if it % 2 == 1:
+            for o in outs:
+                assert torch.equal(o, ref), f"launch {it}: result differs"
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 768, 3072), (64, 2304, 768), (37, 200, 64), (5, 36, 448)])
 def test_gemm_skinny_rows(M, N, K):
     """M <= 64 in bf16 takes the split-K-over-waves kernel (the shape encoder's 64 latent tokens): ragged M and N,
