@@ -389,9 +389,10 @@ def decoder_block_replay(model, sample, steps: int, q_mode: str = "pair"):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             keep = block()
-        for _ in range(3):
-            g.replay()
-        rounds = sorted(_event_time_ms(g.replay, max(steps, 20)) for _ in range(5))
+        for _ in range(100):                                 # ~80 ms: the clock has settled before the first timed round (three replays
+            g.replay()                                       # did not: the first of five rounds used to be the slow one, by up to 10 %)
+        in_order = [_event_time_ms(g.replay, max(steps, 20)) for _ in range(5)]
+        rounds = sorted(in_order)
         ms = rounds[2]                                       # median of five rounds of >= 20 replays
     del keep
     flops = model.decoder_block_flops(1, T, N)
@@ -399,7 +400,7 @@ def decoder_block_replay(model, sample, steps: int, q_mode: str = "pair"):
     return {"ms_per_step": round(ms, 4), "algorithmic_gflop": round(flops / 1e9, 1), "tflops": round(flops / ms / 1e9, 1),
             "frac_of_bf16_peak": round(flops / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
             "executed_gflop": round(fexe / 1e9, 1), "frac_executed_flops": round(fexe / ms / 1e9 / PEAK_BF16_TFLOPS, 4),
-            "rounds_ms": [round(r, 4) for r in rounds],
+            "rounds_ms": [round(r, 4) for r in rounds], "rounds_in_order_ms": [round(r, 4) for r in in_order],
             "q_mode": q_mode,
             "timing": "hipGraph of the block alone (norm_q + norm_kv, q + k|v projections -- one launch each, as in the product's forward "
                       "when the q projection is not hoisted --, attention, out-projection, MLP), replayed back to back between two HIP events (median of five rounds); input = this "
