@@ -1073,9 +1073,13 @@ static int pick_variant(const m324_gemm_args* a) {
     // 55.9 against v10's 57.8, 65536 x 3072 305.7 against 316.2: the chip is power-limited, a denser stream clocks lower, and with
     // the m324_rowstats_finish launch the stream needs in front of a folded consumer the clip does not move (bit 0, off).  With one
     // tile per workgroup nothing overlaps (the epilogue is the exposed tail): at least two tiles per CU.
-    if (f == 0 && ring_ok && nbatch_one(a) && m324::tunable(m324::TUN_HP) != 0 && a->K == 768 && a->N % 128 == 0 &&
-        (long)(a->N / 128) * ceil_div(a->M, BM5) >= 512 && hp_act(a) >= 0 &&
-        (m324::tunable(m324::TUN_HP) & ((hp_act(a) & 1) ? 1 : 2)) != 0 && m324::hp_ok(a, make_epilogue(a), hp_act(a), hp_res(a)))
+    // M324_HP bit 2 (default): the GELU epilogues from 4096 tiles on -- the decoder's fc1 (65536 rows, nontemporal stores): its block
+    // 0.770 -> 0.752 ms with the m324_rowstats_finish launch in front included (tools/block_lab.py, alternated processes)
+    const long thp = (long)(a->N / 128) * ceil_div(a->M, BM5);
+    const int hpm = m324::tunable(m324::TUN_HP);
+    if (f == 0 && ring_ok && nbatch_one(a) && hpm != 0 && a->K == 768 && a->N % 128 == 0 && thp >= 512 && hp_act(a) >= 0 &&
+        ((hp_act(a) & 1) ? ((hpm & 1) != 0 || ((hpm & 4) != 0 && thp >= 4096)) : (hpm & 2) != 0) &&
+        m324::hp_ok(a, make_epilogue(a), hp_act(a), hp_res(a)))
         return 15;
     const long t14 = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5);
     const long t5q = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);

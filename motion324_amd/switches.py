@@ -50,7 +50,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
     "M324_NT_MB": ("128", "GEMM: bf16 outputs (no residual) larger than this many MiB are stored nontemporal"),
     "M324_PP": ("1", "plain wide bf16 outputs whose 256 x 256 tiling fills < 85 % of its rounds (the training step's q|k|v projections) on v14: two persistent 256 x 128 workgroups per CU (0: the chunk rings of round 4)"),
-    "M324_HP": ("2", "schedule v15 (one wave per SIMD, hand-placed stream, the previous tile's epilogue between the MFMAs of the current one) for K = 768 GEMMs with bf16 output and at least two 256 x 128 tiles per CU: bit 1 the bias-only / plain epilogues (the training step's projections), bit 0 the GELU epilogues (fc1; folded consumers then get the merged statistics table from the host); 0: never"),
+    "M324_HP": ("6", "schedule v15 (one wave per SIMD, hand-placed stream, the previous tile's epilogue between the MFMAs of the current one) for K = 768 GEMMs with bf16 output and at least two 256 x 128 tiles per CU: bit 1 the bias-only / plain epilogues (the training step's projections), bit 2 the GELU epilogues from 4096 tiles on (the decoder's fc1, the 256-frame clip's), bit 0 every GELU epilogue; folded consumers it takes get the merged statistics table from the host (transformer.hp_consumer); 0: never"),
     "M324_PP_SKEW": ("0", "v14: start offset of a CU's second workgroup in units of 1024 cycles (0 = by epilogue: 7 with GELU / q|k|v heads, else 4; -1 = none)"),
     "M324_GEMM_PERSIST": ("1", "256 x 256 chunk-ring GEMM (v10): 1 = one persistent workgroup per CU, next tile's first chunks under the epilogue; 0 = one workgroup per tile"),
 }

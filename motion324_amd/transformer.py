@@ -183,9 +183,13 @@ class LNFold:
 
 
 def hp_consumer(rows: int, n_out: int, k: int) -> bool:
-    """m324_gemm's rule for schedule v15 (csrc/gemm.hip pick_variant): K = 768, GELU epilogue, N % 128 == 0, at least two 256 x 128
-    tiles per CU.  The host mirrors it only to hand such a consumer the merged statistics table."""
-    return (HP & 1) != 0 and k == 768 and n_out % 128 == 0 and (n_out // 128) * ((rows + 255) // 256) >= 512
+    """m324_gemm's rule for a GELU epilogue on schedule v15 (csrc/gemm.hip pick_variant): K = 768, N % 128 == 0, at least 512 tiles of
+    256 x 128 with M324_HP bit 0, 4096 with bit 2 (the default).  The host mirrors it only to hand such a consumer the merged
+    statistics table."""
+    if k != 768 or n_out % 128 != 0:
+        return False
+    tiles = (n_out // 128) * ((rows + 255) // 256)
+    return ((HP & 1) != 0 and tiles >= 512) or ((HP & 4) != 0 and tiles >= 4096)
 
 
 def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor, fold: Optional[LNFold] = None,

@@ -363,9 +363,9 @@ def test_gemm_v15_is_chosen_where_it_was_measured_faster_and_only_there(tune):
     a, w = _q(_rand((M, K), 75), dtype).to(dtype).to(DEV), _q(_rand((N, K), 76, 0.03), dtype).to(dtype).to(DEV)
     bias = _rand((N,), 77).to(DEV)
     out = torch.empty((M, N), dtype=dtype, device=DEV)
-    assert "gemm_hp_kernel" in _plan(ops, a, w, out, bias=bias)                        # default M324_HP=2: bias-only / plain epilogues
+    assert "gemm_hp_kernel" in _plan(ops, a, w, out, bias=bias)                        # default M324_HP=6: bias-only / plain epilogues ...
     assert "gemm_hp_kernel" in _plan(ops, a, w, out)                                   # no bias: a bias resource without records
-    assert "gemm_hp_kernel" not in _plan(ops, a, w, out, bias=bias, act=ACT_GELU)      # GELU: bit 0
+    assert "gemm_hp_kernel" not in _plan(ops, a, w, out, bias=bias, act=ACT_GELU)      # ... GELU from 4096 tiles on (984 here); bit 0: always
     assert "gemm_hp_kernel" not in _plan(ops, a[:2048], w, out[:2048], bias=bias)      # 192 tiles: one per workgroup
     outf = torch.empty((M, N), dtype=torch.float32, device=DEV)
     assert "gemm_hp_kernel" not in _plan(ops, a, w, outf, bias=bias)
@@ -378,7 +378,11 @@ def test_gemm_v15_is_chosen_where_it_was_measured_faster_and_only_there(tune):
     assert "gemm_hp_kernel" in _plan(ops, a, w, out, bias=bias, act=ACT_GELU, ln=(rowstat, colsum))
     tune("M324_HP", 0)
     assert "gemm_hp_kernel" not in _plan(ops, a, w, out, bias=bias)
-    tune("M324_HP", 2)
+    tune("M324_HP", 6)
+    big = torch.empty((45056, K), dtype=dtype, device=DEV)                             # 176 x 24 = 4224 tiles
+    outb = torch.empty((45056, N), dtype=dtype, device=DEV)
+    assert "gemm_hp_kernel" in _plan(ops, big, w, outb, bias=bias, act=ACT_GELU)
+    del big, outb
     tune("M324_GEMM", "v15")
     x = torch.zeros((M, N), dtype=torch.float32, device=DEV)
     ops.gemm(a, w, x, residual=x)                                                        # forced, not built: the chooser's kernel runs

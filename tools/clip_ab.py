@@ -32,7 +32,14 @@ HOST = {"M324_ATTN_BOUNDED": ("motion324_amd.transformer", "ATTN_BOUNDED"), "M32
         "M324_OVERLAP": ("motion324_amd.Pcd_motion", "OVERLAP_SHAPE_ENCODER"), "M324_HOIST_Q": ("motion324_amd.Pcd_motion", "HOIST_DECODER_Q")}
 
 
+BOTH = {"M324_HP": ("motion324_amd.transformer", "HP")}          # library switches the host mirrors
+
+
 def set_switch(k, v):
+    if k in BOTH and v is not None:
+        import importlib
+        mod, attr = BOTH[k]
+        setattr(importlib.import_module(mod), attr, v)
     if k in HOST:                      # host switches are module constants read at capture time
         import importlib
         mod, attr = HOST[k]
