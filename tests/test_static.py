@@ -60,3 +60,45 @@ def test_hand_placed_attention_stream_owns_its_registers():
     assert r.returncode == 0, r.stdout + r.stderr                        # includes the generator's own hazard checks
     for f, old in before.items():
         assert open(os.path.join(csrc, f)).read() == old, f"{f} is stale: run csrc/gen_attn_pwg.py"
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_hand_placed_gemm_stream_owns_its_registers():
+    """gemm_hp.hip (schedule v15) names its registers (v16-255, a0-255, s40-87) inside one asm statement per kernel: no spill, no
+    scratch, 512 registers, no compiler v_accvgpr_* / v_mfma outside the statement; every stream is built twice (plain and
+    nontemporal stores through the HP_ST_FLAG macro); and the committed .inc files are what the generator writes today -- the
+    generator's own checks run with it (hazard distances, wait counts resolved from the instruction order and equal on every
+    entry path of a tile body, packed registers consumed before they are rewritten, epilogue operands reloaded behind their last use)."""
+    import re
+    import subprocess as sp
+    sys.path.insert(0, ROOT)
+    from motion324_amd import build as B
+    asm = B.assembly(["gemm_hp.hip"])["gemm_hp.hip"]
+    text = open(asm).read()
+    kernels = re.findall(r"\.amdhsa_kernel (\S*gemm_hp\S*)", text)
+    assert len(kernels) == 8, kernels
+    meta = text[text.index("amdhsa.kernels"):]
+    for field, want in ((".vgpr_spill_count", "0"), (".sgpr_spill_count", "0"), (".private_segment_fixed_size", "0")):
+        vals = re.findall(re.escape(field) + r":\s*(\d+)", meta)
+        assert vals and all(v == want for v in vals), (field, vals)
+    assert all(int(v) == 512 for v in re.findall(r"\.vgpr_count:\s*(\d+)", meta))
+    assert all(int(v) == 163840 for v in re.findall(r"\.group_segment_fixed_size:\s*(\d+)", meta))      # ring + table + store scratch
+    outside, inside, nt = [], False, 0
+    for line in text.splitlines():
+        if ";;#ASMSTART" in line:
+            inside = True
+        elif ";;#ASMEND" in line:
+            inside = False
+        elif not inside and ("v_accvgpr" in line or "v_mfma" in line):
+            outside.append(line.strip())
+        elif inside and "buffer_store_dwordx4" in line and " nt" in line:
+            nt += 1
+    assert not outside, outside[:5]
+    assert nt == 4 * 64, nt                                               # 16 stores x (2 bodies + 2 tails) in each of the four nt kernels
+    csrc = os.path.join(ROOT, "motion324_amd", "csrc")
+    names = ["gemm_hp_gelu.inc", "gemm_hp_fold_gelu.inc", "gemm_hp_plain.inc", "gemm_hp_fold.inc", "gemm_hp_clobbers.inc"]
+    before = {f: open(os.path.join(csrc, f)).read() for f in names}
+    r = sp.run([sys.executable, os.path.join(csrc, "gen_gemm_hp.py")], capture_output=True, text=True, cwd=csrc)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for f, old in before.items():
+        assert open(os.path.join(csrc, f)).read() == old, f"{f} is stale: run csrc/gen_gemm_hp.py"
