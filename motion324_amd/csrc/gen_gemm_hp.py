@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Writes motion324_amd/csrc/gemm_hp_*.inc: the hand-placed instruction streams of schedule v15 (gemm_hp.hip), the K = 768 GEMM
 with the PREVIOUS tile's epilogue issued between the MFMAs of the current tile's main loop.  Run it after editing; the .inc files
-are committed, the build does not need this script.
+are committed, the build does not need this script (tests/test_static.py checks that they are what this script writes).
 
-Why (profiles/r05_gemm_labs.md): the K = 768 GEMMs are bound by what a CU can issue -- 12.3 k cycles of MFMA per 256 x 128 tile,
-1200-2000 VALU instructions of epilogue per wave and tile, and neither a partner workgroup (v14) nor compiler-scheduled fillers
-(tools/lab_src/de_lab.hip) hide the epilogue; a wave's OWN plain VALU instructions do issue in the shadow of its MFMAs when they sit
-between them in program order (tools/issue_lab, round 4; the attention stream of gen_attn_pwg.py rests on the same fact).
+Why (profiles/r05_gemm_labs.md, profiles/r05_gemm_hp.md): the K = 768 GEMMs are bound by what a CU can issue -- 12.3 k cycles of MFMA
+per 256 x 128 tile, 1200-2000 VALU instructions of epilogue per wave and tile, and neither a partner workgroup (v14) nor
+compiler-scheduled fillers (tools/lab_src/de_lab.hip) hide the epilogue; a wave's OWN plain VALU instructions do issue in the shadow of
+its MFMAs when they sit between them in program order (tools/issue_lab, round 4; the attention stream of gen_attn_pwg.py rests on the
+same fact).
 
 Structure: ONE persistent 4-wave workgroup per CU (one wave per SIMD, 512 registers), 256 x 128 output tiles, wave (wm, wn) owns
 128 rows x 64 columns = 4 x 2 accumulator blocks of 32 x 32 (swapped operands: a lane holds ONE output row and 4-column runs).
@@ -14,14 +15,25 @@ Structure: ONE persistent 4-wave workgroup per CU (one wave per SIMD, 512 regist
     ONE barrier per stage; fragments are read two k-steps (16 MFMAs) ahead of their MFMAs into three register sets, so the first
     16 MFMAs behind a barrier are the previous stage's last two k-steps.
   * two accumulator sets in AGPRs (a0-127 / a128-255) that swap roles every tile (the tile body is emitted twice): while set X
-    accumulates tile t, the epilogue of tile t - 1 reads set Y: v_accvgpr_read, LayerNorm fold / bias (packed FMAs), the 9-term
-    erf polynomial of gemm_tile.h (packed), bf16 pack, v_permlane32_swap (16 contiguous bytes of one row per lane), buffer stores
-    clipped by the resource's record count (ragged last row tile: no predicates).  Stores are issued right behind a stage's top
-    barrier: they count in vmcnt, and a whole stage passes before the next counted wait needs them retired.
+    accumulates tile t, the epilogue of tile t - 1 reads set Y: v_accvgpr_read, LayerNorm fold / bias, the 9-term erf polynomial of
+    gemm_tile.h, bf16 pack, v_permlane32_swap (16 contiguous bytes of one row per lane).  The arithmetic is PLAIN fp32 VALU: packed
+    fp32 (v_pk_fma_f32 ...) does not issue in the MFMAs' shadow (measured: 832 packed instructions per tile cost 4.2 cycles each,
+    1856 plain ones in their place 2.6); only the exposed tail behind a workgroup's last tile uses the packed forms.
+  * stores: a row block (32 rows x 64 columns of the wave) leaves through the wave's 16-row x 128-byte LDS scratch in two halves
+    (exec-masked ds_write_b128 of the packed rows, read back as whole rows) and out as 8 rows x 128 contiguous bytes per instruction,
+    clipped by the store resource's record count (ragged last row tile: no predicates).  The cache flag of the stores is the
+    includer's macro HP_ST_FLAG ("" or " nt": outputs above M324_NT_MB leave nontemporal -- 402 MB of plain stores push the
+    operands out of the L2s).  A bounce's wait never directly follows its read-back: the parts are woven into the next row block's
+    first instructions.
   * tiles are seamless: stages 10, 11 of a tile fetch stages 0, 1 of the workgroup's next tile (resource words from the tile table
-    the C++ side leaves in LDS); a workgroup's first tile runs the epilogue of a null tile (record count 0: every store dropped),
-    its last tile is followed by an exposed epilogue.
-Register map: see `alloc` below (v16-255, a0-255, s40-99 belong to the asm statement).
+    the C++ side leaves in LDS); a workgroup's first tile runs a body WITHOUT epilogue fillers, its last tile is followed by the
+    exposed epilogue.
+  * the generator resolves every s_waitcnt from the instruction order (loads return in order among themselves, LDS operations too:
+    a wait for operation T may leave as many in flight as were issued behind T; stores count in vmcnt in hardware but not here --
+    the bound stays valid), checks that the counts do not depend on the path by which a body is entered (prologue, first tile, the
+    other set's body), and checks the hazards the assembler does not handle inside an asm statement.
+Register map: see `alloc` below (v16-255, a0-255, s40-87 belong to the asm statement).  `--lab`: timing-only ablation streams for
+tools/hp_lab (no epilogue, no stores, no LDS-DMA, no fragment reads, no barriers, packed arithmetic, nt / sc1 stores, stamps).
 """
 from __future__ import annotations
 
