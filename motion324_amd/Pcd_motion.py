@@ -513,7 +513,9 @@ class Motion_Latent_Model(nn.Module):
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             pts = self._point_features(P, self._f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
                                        self._f32c(sample["ref_shape_normals"]), self._f32c(sample["ref_shape_rgbs"]))
-            query = P.f32(self.learnable_tokens).reshape(K, C).repeat(B, 1)          # fp32 [B*K, C]
+            # fp32 [B*K, C], expanded once per weight version (the block reads it as the residual and writes a new stream)
+            query = P.derived(f"latent_tokens_x{B}", (self.learnable_tokens,),
+                              lambda: self.learnable_tokens.detach().to(device=P.device, dtype=torch.float32).reshape(K, C).repeat(B, 1))
             mesh = self.encoder_cross_attn.run(P, query, pts, B, K, S)
             if cap is not None:
                 cap["shape_point_feat"], cap["encoder_out"] = pts.clone(), mesh.clone()

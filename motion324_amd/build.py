@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libm324.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "gemm_pp.hip", "gemm_hp.hip", "attention.hip", "attention_pwg.hip", "elementwise.hip", "backward.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_ring4.hip", "gemm_hp.hip", "attention.hip", "attention_pwg.hip", "elementwise.hip", "backward.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(HERE, "..", "include", "m324.h"),
            os.path.join(CSRC, "attn_pwg_asm.inc"), os.path.join(CSRC, "attn_pwg_bounded_asm.inc"), os.path.join(CSRC, "attn_pwg_clobbers.inc"),
            os.path.join(CSRC, "attn_pwg_kernel.inl"), os.path.join(CSRC, "gemm_hp_kernel.inl"), os.path.join(CSRC, "gemm_hp_clobbers.inc")] + [
@@ -72,6 +72,62 @@ def build(verbose: bool = False, force: bool = False) -> str:
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
+
+
+SAN_LIB = os.path.join(OBJ, "san", "libm324_san.so")
+
+
+def build_sanitized() -> str:
+    """Host side of every translation unit (``--cuda-host-only``: launchers, argument validation, the m324_*_plan queries, the
+    kernel chooser, the tunable table; no device code) with AddressSanitizer + UndefinedBehaviorSanitizer, linked against the
+    shared sanitizer runtime.  GPU ASan is not available on this pool, and the host side is where the C ABI takes raw pointers
+    and sizes from a caller; tests/test_sanitizer.py loads the result in a child process (LD_PRELOAD of the runtime) and drives
+    every entry point that returns before its first HIP call.  A few seconds: there is no device compilation."""
+    sdir = os.path.dirname(SAN_LIB)
+    os.makedirs(sdir, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ["--offload-arch=gfx950", "--cuda-host-only", "-O1", "-g", "-std=c++17", "-fPIC", "-Wno-unused-function",
+             "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libsan"]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(sdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if _stale(o, [s, os.path.abspath(__file__)] + HEADERS):
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (sanitizer build) failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or _stale(SAN_LIB, objs):
+        # a host-only object still refers to its translation unit's device-code bundle (__hip_fatbin_<hash>; the module
+        # constructor hands it to the HIP runtime, which parses it lazily, at the first launch): an EMPTY bundle each
+        r = subprocess.run(["nm", "-u"] + objs, capture_output=True, text=True)
+        syms = sorted({ln.split()[-1] for ln in r.stdout.splitlines() if "__hip_fatbin_" in ln})
+        stub = os.path.join(sdir, "fatbin_stub.c")
+        with open(stub, "w") as f:
+            f.write("/* GENERATED by motion324_amd.build.build_sanitized: empty offload bundles for a host-only build */\n")
+            for sym in syms:
+                f.write(f'__attribute__((aligned(4096))) const char {sym}[4096] = "__CLANG_OFFLOAD_BUNDLE__";\n')
+        so = os.path.join(sdir, "fatbin_stub.o")
+        run(["gcc", "-fPIC", "-c", stub, "-o", so])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-o", SAN_LIB] + objs + [so, "-ldl"])
+    return SAN_LIB
+
+
+def sanitizer_runtime() -> str:
+    """path of the shared ASan runtime the sanitized library needs preloaded into a Python child"""
+    r = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = r.stdout.strip()
+    if not os.path.isabs(path):
+        import glob
+        hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+        path = hits[0] if hits else ""
+    return path
 
 
 def assembly(sources=None) -> dict:

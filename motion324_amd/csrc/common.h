@@ -34,7 +34,7 @@ void m324_set_error(const char* fmt, ...);
 // path calls getenv().
 namespace m324 {
 enum Tunable { TUN_GEMM = 0, TUN_GEMM_TN, TUN_XCD, TUN_ATTN_NW, TUN_ATTN_FLAT, TUN_ATTN_OCC, TUN_ATTN_NQ2, TUN_ATTN_BWD_NW,
-               TUN_ATTN_EXP, TUN_LN_ROWS, TUN_GEMM_PERSIST, TUN_ATTN_PWG, TUN_QKV_RING, TUN_NT_MB, TUN_PP, TUN_PP_SKEW, TUN_HP, TUN_COUNT };
+               TUN_ATTN_EXP, TUN_LN_ROWS, TUN_GEMM_PERSIST, TUN_ATTN_PWG, TUN_QKV_RING, TUN_NT_MB, TUN_HP, TUN_COUNT };
 int tunable(int which);          // 0 = "not set" for every switch except TUN_XCD (default 3) / TUN_ATTN_FLAT (default 1)
 }  // namespace m324
 

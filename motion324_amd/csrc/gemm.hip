@@ -302,6 +302,14 @@ __global__ __launch_bounds__(512, 2) void gemm_glds5_kernel(const TIN* __restric
 // been issued) and in front of the epilogue's first scratch access (the chunks prefetched under the epilogue had to LAND before the
 // epilogue could start) -- a full drain of the pipeline at each.  The kernels' own counted waits and barriers order every chunk's fill
 // against its reads; the alias scopes tell the pass so.  (The TN weight-gradient kernel lost 17-21 % of its time to the same drains.)
+// INVARIANT the three views rest on (they DO name the same bytes, so by the letter of `restrict` this is outside the language):
+// every pair of conflicting accesses -- a chunk's LDS-DMA fill and its fragment reads, a chunk's last read and its refill, a scratch
+// write and the ring bytes under it -- is separated by a counted `s_waitcnt vmcnt` AND a workgroup barrier that are written as
+// `asm volatile(... ::: "memory")`, which no LLVM pass moves memory operations across; hipcc only turns `restrict` into scoped-noalias
+// metadata after inlining, i.e. it may reorder between two such fences, where no conflicting pair lives.  Guards: tools/audit_barriers.py
+// (every barrier of an LDS-DMA kernel has its vmcnt wait in the ISA; tests/test_static.py), the compiler version the ISA was read on is
+// pinned there too (a new hipcc must be re-validated: grep the loops for `vmcnt(0)`), and the race tests stay in the default GPU
+// suite (tools/ln_stress.py form: test_kernels_gpu.py `*_beside_chunk_ring_*`, the v15 race test).
 template <typename TOUT, int ACT, int RES>
 __device__ __forceinline__ void gemm_ring_body(unsigned char* __restrict__ ring_w, const unsigned char* __restrict__ smem,
                                                float* __restrict__ scratch, const bf16_t* __restrict__ A, long lda,
@@ -1008,9 +1016,10 @@ static int xcd_mode(const m324_gemm_args* a) {
     return 1 | old_refetch;
 }
 
-// Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13|v14|v15 forces a variant (A/B measurements, tests).  (v7, the half-tile ring
+// Kernel choice.  M324_GEMM=v1|v2|v5|v9|v10|v11|v12|v13|v15 forces a variant (A/B measurements, tests).  (v7, the half-tile ring
 // the chunk-ring kernels replaced, was retired in round 3: no shape reaches it -- K is a multiple of 64 for bf16 -- and its
-// A/B tables are kept in profiles/r01_ab_gemm_schedules.md.)
+// A/B tables are kept in profiles/r01_ab_gemm_schedules.md.  v14, round 5's two persistent 256 x 128 workgroups per CU, was retired in
+// round 6: v15 took every shape it was chosen for (41.4 against 44.2 us at 10368 x 2304 x 768); tables: profiles/r05_gemm_labs.md section 2.)
 static int forced_variant() { return m324::tunable(m324::TUN_GEMM); }   // M324_GEMM at load / m324_set_tunable
 
 // v10 is persistent: one 8-wave workgroup per CU (160 KiB of LDS each); M324_GEMM_PERSIST=0: one workgroup per tile (A/B)
@@ -1044,13 +1053,7 @@ static int pick_variant(const m324_gemm_args* a) {
     const bool ring_ok = bf16 && a->K % 64 == 0 && a->K >= 128;      // v10 / v11: K-stages of 64, at least two
     if (f == 1 || f == 2 || f == 5) return f;
     if (f >= 10 && f <= 13) return ring_ok ? f : (f == 13 ? 2 : 5);
-    // v14 builds the residual-free bf16 epilogues only (gemm_pp.hip launch_pp); a forced v14 leaves the rest to the chooser
-    const bool pp_ok = ring_ok && a->out_dtype == M324_BF16 && !a->residual && a->row_gin <= 0 && !a->ln_stats_out && !a->ln_copy_out &&
-                       a->aux_mode != M324_AUX_N3 && a->M > 64;
-    if (f == 14) {
-        if (pp_ok) return 14;
-        f = 0;
-    }
+    if (f == 14) f = 0;                          // retired schedule: the chooser decides
     // v15 (gemm_hp.hip): the hand-placed K = 768 stream with the deferred epilogue; hp_ok lists what it takes
     if (f == 15) {
         if (ring_ok && nbatch_one(a) && m324::hp_ok(a, make_epilogue(a), hp_act(a), hp_res(a))) return 15;
@@ -1063,13 +1066,9 @@ static int pick_variant(const m324_gemm_args* a) {
     // below; of the two, the 4-wave persistent v11 wins when the output is fp32 (residual epilogues: little VALU work,
     // 1.5x the LDS fragment traffic saved), the 8-wave v10 when it is bf16 (GELU / q|k|v epilogues want two waves per
     // SIMD).  K = 64 (a single K-stage) runs on the two-stage 256 x 256 kernel v5.
-    // v14 (round 5): two persistent 256 x 128 workgroups per CU.  Measured (profiles/r05_gemm_labs.md): it wins where 256 x 256
-    // tiles quantise badly and the epilogue is light -- plain wide bf16 outputs (the training step's q|k|v projections: 42.8 us
-    // against 47.8-49.0 at 10368 x 2304 x 768) -- and loses with GELU / head-major / LayerNorm-fold epilogues, which do not hide
-    // beside the partner workgroup's MFMA stream.  M324_PP=0: never; bit 1: also where the 256 x 256 tiling fills its rounds (A/B); M324_GEMM=v14 forces it for every epilogue it builds.
     // v15 (round 5, gemm_hp.hip): one wave per SIMD, hand-placed stream, the previous tile's epilogue between the MFMAs of the current
-    // tile.  Measured on random data, same box, interleaved (profiles/r05_gemm_hp.md): plain 10368 x 2304 x 768 41.4 us against v14's
-    // 44.2, v13's 48.8, v10's 50.2 -- the training step 93.3 -> 92.1-92.7 ms (M324_HP bit 1, default); fc1 + GELU 10368 x 3072
+    // tile.  Measured on random data, same box, interleaved (profiles/r05_gemm_hp.md): plain 10368 x 2304 x 768 41.4 us against v13's
+    // 48.8, v10's 50.2 (and 44.2 for round 5's retired two-workgroups-per-CU schedule) -- the training step 93.3 -> 92.1-92.7 ms (M324_HP bit 1, default); fc1 + GELU 10368 x 3072
     // 55.9 against v10's 57.8, 65536 x 3072 305.7 against 316.2: the chip is power-limited, a denser stream clocks lower, and with
     // the m324_rowstats_finish launch the stream needs in front of a folded consumer the clip does not move (bit 0, off).  With one
     // tile per workgroup nothing overlaps (the epilogue is the exposed tail): at least two tiles per CU.
@@ -1081,12 +1080,6 @@ static int pick_variant(const m324_gemm_args* a) {
         ((hp_act(a) & 1) ? ((hpm & 1) != 0 || ((hpm & 4) != 0 && thp >= 4096)) : (hpm & 2) != 0) &&
         m324::hp_ok(a, make_epilogue(a), hp_act(a), hp_res(a)))
         return 15;
-    const long t14 = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5);
-    const long t5q = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
-    const bool plain = a->act == M324_ACT_NONE && a->aux_mode == M324_AUX_NONE && !a->ln_rowstat && !a->gamma;
-    if (pp_ok && f == 0 && plain && m324::tunable(m324::TUN_PP) != 0 && a->N % 128 == 0 && a->N >= 1536 && t14 >= 448 &&
-        ((m324::tunable(m324::TUN_PP) & 2) != 0 || (double)t5q / (double)(((t5q + 255) / 256) * 256) < 0.85))
-        return 14;
     const long t5 = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5);
     const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
     if (a->N % BN5 == 0 && t5 >= 200 && e5 >= 0.75) {
@@ -1120,7 +1113,6 @@ static int pick_variant(const m324_gemm_args* a) {
 template <typename TOUT, int ACT, int RES>
 static int launch_pipe(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int variant) {
     if (variant == 11 || variant == 12) return m324::launch_ring4(a, s, ep, ACT, RES, xcd_mode(a), variant);
-    if (variant == 14) return m324::launch_pp(a, s, ep, ACT, RES, xcd_mode(a));
     if (variant == 13) {
         hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(ceil_div(a->N, BN) * ceil_div(a->M, BM)), dim3(256), 0, s,
                            (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M, a->N, a->K, ep,
@@ -1208,9 +1200,6 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
         if (variant == 11 || variant == 12) {                                                                            \
             const int rc_ = m324::launch_ring4(a, s, ep, ACT, RES, xcd_mode(a), variant);                                \
             if (rc_ != M324_OK) return rc_;                                                                              \
-        } else if (variant == 14) {                                                                                      \
-            const int rc_ = m324::launch_pp(a, s, ep, ACT, RES, xcd_mode(a));                                            \
-            if (rc_ != M324_OK) return rc_;                                                                              \
         } else if (variant == 13)                                                                                        \
             hipLaunchKernelGGL((gemm_ring2_kernel<TOUT, ACT, RES>), dim3(grid.x * grid.y), dim3(256), 0, s,              \
                                (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (TOUT*)a->C, a->ldc, a->M,      \
@@ -1297,7 +1286,6 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
         case 11: name = "gemm_ring4_kernel"; wg = (long)ceil_div(a->N, BN5) * ceil_div(a->M, BM5); if (wg > 256) wg = 256; break;
         case 12: name = "gemm_ring3_kernel"; wg = (long)ceil_div(a->N, 128) * ceil_div(a->M, BM5); break;
         case 13: name = "gemm_ring2_kernel"; wg = (long)ceil_div(a->N, BN) * ceil_div(a->M, BM); break;
-        case 14: name = "gemm_pp_kernel"; wg = m324::pp_grid(a); break;
         case 15: name = "gemm_hp_kernel"; wg = m324::hp_grid(a); break;
         default: break;
     }

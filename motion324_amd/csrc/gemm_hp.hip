@@ -32,7 +32,6 @@ constexpr int HP_TABLE_BYTES = 8192;              // tile table: 48 bytes per en
 constexpr int HP_SCRATCH = 2048;                  // store scratch per wave: 16 rows x 128 bytes
 constexpr int HP_MAX_TILES = HP_TABLE_BYTES / 48 - 2;
 
-#define HP_TRACE 0
 #define HP_ST_FLAG ""
 #define HP_KERNEL gemm_hp_gelu_kernel
 #define HP_ASM_INC "gemm_hp_gelu.inc"
@@ -113,7 +112,7 @@ int launch_hp(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int ac
     const dim3 grid(ntiles < hp_cus() ? ntiles : hp_cus());
 #define M324_HP(KERNEL)                                                                                                              \
     hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, s, (const bf16_t*)a->A, a->lda, (const bf16_t*)a->W, a->ldw, (bf16_t*)a->C, a->ldc, a->M, a->N, \
-                       ep.bias, ep.colsum, ep.rowstat, ntn, ntiles, xcd_remap, (unsigned*)nullptr)
+                       ep.bias, ep.colsum, ep.rowstat, ntn, ntiles, xcd_remap)
     switch (act_code + (ep.stream ? 16 : 0)) {
         case 0: M324_HP(gemm_hp_plain_kernel); break;
         case 1: M324_HP(gemm_hp_gelu_kernel); break;

@@ -42,9 +42,6 @@ struct Epilogue {
 // gemm_ring4.hip (own translation unit: built WITHOUT -amdgpu-mfma-vgpr-form, its 256 accumulators live in AGPRs).
 // act_code: the ACT template value (0 none, 1 GELU, 2 GELU + pre-activation, 3 x gelu', 4 q|k|v heads); res_code: RES.
 int launch_ring4(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap, int variant);
-// gemm_pp.hip (v14: two persistent 4-wave 256 x 128 workgroups per CU, out of phase); pp_grid: its grid in workgroups
-int launch_pp(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap);
-int pp_grid(const m324_gemm_args* a);
 // gemm_hp.hip (v15: the hand-placed K = 768 stream, previous tile's epilogue inside the main loop); hp_ok: does it take this GEMM
 bool hp_ok(const m324_gemm_args* a, const Epilogue& ep, int act_code, int res_code);
 int launch_hp(const m324_gemm_args* a, hipStream_t s, const Epilogue& ep, int act_code, int res_code, int xcd_remap);

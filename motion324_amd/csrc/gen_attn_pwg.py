@@ -611,8 +611,11 @@ def program():
     return P
 
 
-def write(name, P):
-    out = os.path.join(HERE, name)
+LAB_DIR = os.path.join(HERE, "..", "..", "tools", "lab_src")      # --lab: the timing-only ablation streams are lab material
+
+
+def write(name, P, where=HERE):
+    out = os.path.normpath(os.path.join(where, name))
     n_ins = sum(1 for i in P if i.kind != "label")
     with open(out, "w") as f:
         f.write("// GENERATED by gen_attn_pwg.py -- do not edit; the instruction stream of attn_pwg_kernel's asm statement.\n")
@@ -632,27 +635,27 @@ def main():
         f.write("// GENERATED by gen_attn_pwg.py: registers the asm statement of attn_pwg_kernel owns.\n")
         names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 196)] + [f"s{i}" for i in range(50, 64)]
         f.write(", ".join(f'"{n}"' for n in names) + "\n")
-    with open(os.path.join(HERE, "attn_pwg_clobbers_lab.inc"), "w") as f:
-        names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 196)] + [f"s{i}" for i in range(50, 86)]
-        f.write(", ".join(f'"{n}"' for n in names) + "\n")
     if "--lab" in sys.argv:
+        with open(os.path.join(LAB_DIR, "attn_pwg_clobbers_lab.inc"), "w") as f:
+            names = [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(0, 196)] + [f"s{i}" for i in range(50, 86)]
+            f.write(", ".join(f'"{n}"' for n in names) + "\n")
         # timing-only ablations (wrong results) for tools/pwg_check.py --ablate: which stream costs what
         for i, key in enumerate(("noexp", "nomax", "nobarrier", "nodma", "nofill")):
             OPT[key] = True
-            write(f"attn_pwg_lab{i + 1}.inc", program())
+            write(f"attn_pwg_lab{i + 1}.inc", program(), LAB_DIR)
             OPT[key] = False
         OPT["pk_sum"] = not OPT["pk_sum"]            # the other form of the row sums (A/B)
-        write("attn_pwg_lab6.inc", program())
+        write("attn_pwg_lab6.inc", program(), LAB_DIR)
         OPT["pk_sum"] = not OPT["pk_sum"]
         OPT["trunc_pack"] = True
-        write("attn_pwg_lab7.inc", program())
+        write("attn_pwg_lab7.inc", program(), LAB_DIR)
         OPT["trunc_pack"] = False
         OPT["lookahead"] = 1
         OPT["trace"] = True
-        write("attn_pwg_lab8.inc", program())
+        write("attn_pwg_lab8.inc", program(), LAB_DIR)
         OPT["trace"] = False
         OPT["lsum_mfma"] = True
-        write("attn_pwg_lab9.inc", program())
+        write("attn_pwg_lab9.inc", program(), LAB_DIR)
         OPT["lsum_mfma"] = False
 
 

@@ -714,8 +714,11 @@ def program():
     return out
 
 
-def write(name, Pg):
-    out = os.path.join(HERE, name)
+LAB_DIR = os.path.join(HERE, "..", "..", "tools", "lab_src")      # --lab: the ablation streams are lab material, not product
+
+
+def write(name, Pg, where=HERE):
+    out = os.path.normpath(os.path.join(where, name))
     n_ins = sum(1 for i in Pg if i.kind != "label")
     with open(out, "w") as f:
         f.write("// GENERATED by gen_gemm_hp.py -- do not edit; an instruction stream of gemm_hp.hip's asm statement.\n")
@@ -757,7 +760,7 @@ def main():
                     OPT["stflag"] = " " + key
                 else:
                     OPT[key] = True
-            write(f"gemm_hp_lab{k + 1}.inc", program())
+            write(f"gemm_hp_lab{k + 1}.inc", program(), LAB_DIR)
             for key in keys:
                 if key == "packed":
                     OPT["scalar"] = True

@@ -23,7 +23,7 @@ namespace {
 struct TunDef { const char* env; int dflt; };
 const TunDef kTun[m324::TUN_COUNT] = {
     {"M324_GEMM", 0}, {"M324_GEMM_TN", 0}, {"M324_XCD", 3}, {"M324_ATTN_NW", 0}, {"M324_ATTN_FLAT", 1},
-    {"M324_ATTN_OCC", 0}, {"M324_ATTN_NQ2", 0}, {"M324_ATTN_BWD_NW", 0}, {"M324_ATTN_EXP", 0}, {"M324_LN_ROWS", 2}, {"M324_GEMM_PERSIST", 1}, {"M324_ATTN_PWG", 1}, {"M324_QKV_RING", 1}, {"M324_NT_MB", 128}, {"M324_PP", 1}, {"M324_PP_SKEW", 0}, {"M324_HP", 6}};
+    {"M324_ATTN_OCC", 0}, {"M324_ATTN_NQ2", 0}, {"M324_ATTN_BWD_NW", 0}, {"M324_ATTN_EXP", 0}, {"M324_LN_ROWS", 2}, {"M324_GEMM_PERSIST", 1}, {"M324_ATTN_PWG", 1}, {"M324_QKV_RING", 1}, {"M324_NT_MB", 128}, {"M324_HP", 6}};
 std::atomic<int> g_tun[m324::TUN_COUNT];
 int parse_tun(const char* e) { return (e[0] == 'v' || e[0] == 'V') ? atoi(e + 1) : atoi(e); }
 struct TunInit {

@@ -89,7 +89,8 @@ class GraphedForward:
         # max_graphs > 0: keep at most that many captured shape sets, dropping the least recently used (each graph owns a
         # private memory pool with a clip's activations and its static inputs).  capture_error_mode: torch.cuda.graph's
         # -- "thread_local" lets other threads (a DataLoader's pin-memory thread, another stream's allocation) keep
-        # calling into HIP while this thread captures.
+        # calling into HIP while this thread captures.  One override: a segmented capture with M324_KV_OVERLAP=1 (an
+        # exchange in flight across a cut) turns "global" into "thread_local" (see __call__).
         # weak: the model itself owns this object (Motion_Latent_Model's automatic graph replay) -- a strong reference back
         # would make model <-> graphs cyclic garbage, which Python's collector may free at any time, e.g. in the middle
         # of a LATER stream capture, where destroying a hipGraph aborts the process
@@ -148,10 +149,15 @@ class GraphedForward:
                 try:
                     if self.segmented:
                         global _SEGMENTER
-                        # "thread_local": with M324_KV_OVERLAP an exchange is IN FLIGHT while the next link of the chain is being
-                        # captured, and the transport's own threads (gloo's copies through host memory; RCCL's watchdog) keep
-                        # calling into HIP -- in "global" mode any such call invalidates the capture on this thread
-                        g = _Segmenter("thread_local" if self.capture_error_mode == "global" else self.capture_error_mode)
+                        # With M324_KV_OVERLAP=1 an exchange is IN FLIGHT while the next link of the chain is being captured, and the
+                        # transport's own threads (gloo's copies through host memory; RCCL's watchdog) keep calling into HIP -- in
+                        # "global" mode any such call invalidates the capture on this thread, so THAT form (and only that form)
+                        # captures "thread_local" whatever the caller asked for.  Without the overlap the caller's mode stands.
+                        from . import Pcd_motion
+                        mode = self.capture_error_mode
+                        if Pcd_motion.KV_OVERLAP and mode == "global":
+                            mode = "thread_local"
+                        g = _Segmenter(mode)
                         cap_stream = torch.cuda.Stream()
                         cap_stream.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(cap_stream):

@@ -19,7 +19,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_HOIST_Q": ("1", "Pcd_motion.HOIST_DECODER_Q", "graph capture: decoder point features + q projection on the shape-encoder branch"),
     "M324_DECODE_ROWS": (str(1 << 17), "Pcd_motion.DECODE_ROWS", "max (frames x points) rows per decoder pass"),
     "M324_OVERLAP": ("1", "Pcd_motion.OVERLAP_SHAPE_ENCODER", "inference: shape encoder on a second HIP stream under the image encoder"),
-    "M324_KV_OVERLAP": ("1", "Pcd_motion.KV_OVERLAP", "frame-parallel (one sample): every global block attends to the rank's own keys while the k|v all-gather is in flight, then to the gathered remote keys, and merges the partial softmaxes by their log-sum-exps (0: one attention after the gather)"),
+    "M324_KV_OVERLAP": ("0", "Pcd_motion.KV_OVERLAP", "frame-parallel (one sample), opt-in until it has run on a multi-GPU RCCL node: 1 = every global block attends to the rank's own keys while the k|v all-gather is in flight, then to the gathered remote keys, and merges the partial softmaxes by their log-sum-exps (0: one attention after the gather)"),
     "M324_KV_REHEARSE": ("0", "Pcd_motion.KV_REHEARSE", "one rank with forced collectives (bench.py M324_BENCH_COLLECT=1): W > 1 runs every global block's overlapped form as rank 0 of W would (own keys = the first 1 / W of the frames), to price the split attention + merge on one GPU"),
     "M324_FOLD_LN": ("2", "transformer.FOLD_LN", "LayerNorm fold: 0 off, 1 bf16 streams only (the decoder), 2 every stream (trunk, DINO too)"),
     "M324_FOLD_MERGE": ("1", "transformer.FOLD_MERGE", "LayerNorm fold: the consumer GEMM merges the producer's per-block row statistics itself (0: m324_rowstats_finish launch between them)"),
@@ -36,7 +36,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
 }
 # Library switches (C++; read by libm324 once, when it is loaded -- csrc/runtime.hip; m324_set_tunable overrides them)
 LIBRARY: Dict[str, Tuple[str, str]] = {
-    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13 | v14 | v15); 0 = chooser"),
+    "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13 | v15); 0 = chooser"),
     "M324_GEMM_TN": ("0", "128: force the 128 x 128 weight-gradient kernel"),
     "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges, bit 1 4 x 2 group order for wide weights, bit 2 force it; bit 3: the ring GEMMs' look-ahead pieces past the end of K fetch the last stage again (rounds 1-4) instead of nothing (A/B)"),
     "M324_ATTN_NW": ("0", "attention forward: waves per workgroup (4 | 8); 0 = by sequence length"),
@@ -49,9 +49,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_QKV_RING": ("1", "128 x 128 chunk ring (v13) instead of the two-stage v2: bit 0 for the fused q|k|v projection (head-major epilogue), bit 1 for plain bf16 outputs (A/B)"),
     "M324_LN_ROWS": ("2", "LayerNorm: rows per wave (2 = two interleaved rows, 1 = one row: A/B)"),
     "M324_NT_MB": ("128", "GEMM: bf16 outputs (no residual) larger than this many MiB are stored nontemporal"),
-    "M324_PP": ("1", "plain wide bf16 outputs whose 256 x 256 tiling fills < 85 % of its rounds (the training step's q|k|v projections) on v14: two persistent 256 x 128 workgroups per CU (0: the chunk rings of round 4)"),
     "M324_HP": ("6", "schedule v15 (one wave per SIMD, hand-placed stream, the previous tile's epilogue between the MFMAs of the current one) for K = 768 GEMMs with bf16 output and at least two 256 x 128 tiles per CU: bit 1 the bias-only / plain epilogues (the training step's projections), bit 2 the GELU epilogues from 4096 tiles on (the decoder's fc1, the 256-frame clip's), bit 0 every GELU epilogue; folded consumers it takes get the merged statistics table from the host (transformer.hp_consumer); 0: never"),
-    "M324_PP_SKEW": ("0", "v14: start offset of a CU's second workgroup in units of 1024 cycles (0 = by epilogue: 7 with GELU / q|k|v heads, else 4; -1 = none)"),
     "M324_GEMM_PERSIST": ("1", "256 x 256 chunk-ring GEMM (v10): 1 = one persistent workgroup per CU, next tile's first chunks under the epilogue; 0 = one workgroup per tile"),
 }
 

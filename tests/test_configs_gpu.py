@@ -213,7 +213,7 @@ def test_frame_parallel_at_c2_size(world, precision, tol, overlap, monkeypatch):
     """Frame-parallel forward at the real trunk sizes: 32 frames over 2 ranks (16 + 16: the all_gather_into_tensor fast
     path, 5184 local / 10 368 global tokens) and over 3 ranks (11 + 11 + 10: uneven shards, padded gather) == the
     single-process forward (fp32: summation order only; bf16: the single-process run takes the fused transposed-V
-    projection epilogue, the sharded one m324_qkv_split -- bf16 rounding apart).  overlap "1" (M324_KV_OVERLAP, default): every
+    projection epilogue, the sharded one m324_qkv_split -- bf16 rounding apart).  overlap "1" (M324_KV_OVERLAP=1, opt-in): every
     global block attends to the rank's own 5184 / 3564 keys while the gather is in flight, then to the remote ranges (one or two),
     and merges by log-sum-exp -- eagerly and as the chain of hipGraphs with TWO cuts per global block; "0": one attention."""
     import torch.multiprocessing as mp

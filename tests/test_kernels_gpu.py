@@ -167,7 +167,7 @@ def test_layernorm_bf16_input(rows, C, with_bias):
         ops.layernorm(x.to(torch.bfloat16).to(DEV), w.to(DEV), None, 1e-5, torch.empty((rows, C), dtype=torch.float32, device=DEV))
 
 
-@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v10", "v11", "v12", "v13", "v14"])
+@pytest.mark.parametrize("variant", ["v1", "v2", "v5", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("K", [64, 192, 832])
 def test_gemm_every_schedule_forced(tune, variant, dtype, K):
@@ -205,7 +205,7 @@ def test_gemm_every_schedule_forced(tune, variant, dtype, K):
     assert rel_err(x, x0.double() + a.double() @ w.double().T) < 1e-5
 
 
-@pytest.mark.parametrize("variant", ["v5", "v10", "v11", "v12", "v13", "v14"])
+@pytest.mark.parametrize("variant", ["v5", "v10", "v11", "v12", "v13"])
 def test_gemm_chunk_ring_many_tiles(tune, variant):
     """The 256-wide kernels on a grid with more tiles than CUs (20 x 16 = 320 tiles of 256 x 256, ragged last row of
     tiles): the persistent v10 / v11 walk 1-2 tiles per workgroup with the next tile's first chunks prefetched under the
@@ -236,7 +236,7 @@ def test_gemm_chunk_ring_many_tiles(tune, variant):
     assert torch.equal(x, x2)
 
 
-@pytest.mark.parametrize("variant", ["v2", "v5", "v10", "v11", "v12", "v13", "v14"])
+@pytest.mark.parametrize("variant", ["v2", "v5", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("M,N", [(20 * 256 - 37, 1300), (129, 128), (3 * 256, 7 * 256), (1100, 260)])
 def test_gemm_grouped_tile_order_covers_every_tile_once(tune, variant, M, N):
     """M324_XCD=7 forces the 4 x 2 group tile order (gemm_tile.h tile_of; chosen by default only for weights larger than
@@ -263,7 +263,7 @@ def test_gemm_grouped_tile_order_covers_every_tile_once(tune, variant, M, N):
     assert torch.equal(x, xr)
 
 
-@pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13", "v14"])
+@pytest.mark.parametrize("variant", ["v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("M,N,K", [(65, 8, 128), (37, 200, 128), (300, 136, 192), (513, 260, 128), (256, 256, 128), (257, 132, 320)])
 def test_gemm_ring_edge_shapes(tune, variant, M, N, K):
     """The chunk-ring kernels at their smallest legal depth (K = 128: two K-stages, the peeled stage 0 plus one loop
@@ -285,7 +285,7 @@ def test_gemm_ring_edge_shapes(tune, variant, M, N, K):
 
 
 @pytest.mark.parametrize("variant,M,N,K", [("v10", 8192, 3072, 768), ("v11", 8192, 3072, 768), ("v12", 10368, 768, 3072),
-                                            ("v13", 10368, 768, 768), ("v14", 10368, 3072, 768), ("v14", 8224, 2304, 768)])
+                                            ("v13", 10368, 768, 768)])
 def test_gemm_ring_kernels_are_race_free(tune, variant, M, N, K):
     """The LDS-DMA rings state their own vmcnt waits (tests/test_static.py audits them); a missing one shows up as a tile
     read before it landed -- rarely, and only when the chip is full.  Forty launches at the model's shapes must give
@@ -531,7 +531,7 @@ def test_gemm_qkv_heads_epilogue(B, L, H, norm, bias):
     assert rel_err(out_f.float(), ref_o) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [None, "v2", "v10", "v11", "v13", "v14"])
+@pytest.mark.parametrize("variant", [None, "v2", "v10", "v11", "v13"])
 def test_gemm_qkv_heads_transposed_v_epilogue(tune, variant):
     """M324_AUX_QKV_HEADS_VT: as the head-major epilogue, but V leaves as the transposed, key-permuted Vt the default
     attention kernel reads.  Vt must equal m324_gemm + m324_qkv_split bit for bit (both round acc + bias to bf16 once);
@@ -1066,7 +1066,7 @@ def _ln_ref(x, w, b, eps):
     return y + b.double() if b is not None else y
 
 
-@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13", "v14"])
+@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,groups", [(3 * 256, 768, 192, 1), (2 * 230, 192, 256, 2), (513, 576, 128, 1)])
 def test_gemm_ln_fold_producer(tune, variant, out_dtype, M, N, K, groups):
@@ -1196,7 +1196,7 @@ def _block_table(xb: torch.Tensor) -> torch.Tensor:
     return torch.stack([s, m2], dim=2).permute(1, 0, 2).contiguous().float()
 
 
-@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13", "v14"])
+@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("M,N,K", [(470, 192, 256), (513, 3072, 768), (1100, 768, 1024)])
 def test_gemm_ln_fold_consumer_merges_block_table(tune, variant, M, N, K):
     """ln = (part, colsum, eps): the consumer merges the producer's per-block statistics of its rows itself (no m324_rowstats_finish
@@ -1245,7 +1245,7 @@ def test_gemm_ln_fold_consumer_result_does_not_depend_on_the_schedule(tune, M, N
     wf, colsum, bias = _folded(lnw, lnb, w, b)
     part = _block_table(xb).to(DEV)
     outs = {}
-    for variant in ("v2", "v10", "v11", "v12", "v13", "v14"):
+    for variant in ("v2", "v10", "v11", "v12", "v13"):
         tune("M324_GEMM", variant)
         out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
         ops.gemm(xb.to(DEV), wf.to(DEV), out, bias=bias.to(DEV), act=ACT_GELU, ln=(part, colsum.to(DEV), 1e-5))
@@ -1265,7 +1265,7 @@ def test_gemm_ln_fold_block_table_rejects_odd_block_counts():
         ops.gemm(a, w, out, ln=(torch.zeros((3, M, 2), device=DEV), torch.zeros((N,), device=DEV), 1e-5))
 
 
-@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13", "v14"])
+@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v11", "v12", "v13"])
 @pytest.mark.parametrize("mode", ["plain", "gelu", "f32out"])
 @pytest.mark.parametrize("M,N,K", [(3 * 256, 768, 192), (470, 192, 256), (513, 3072, 768)])
 def test_gemm_ln_fold_consumer(tune, variant, mode, M, N, K):

@@ -393,7 +393,7 @@ def _fp_worker(rank, world, port, case, precision, ret):
 def test_frame_parallel_equals_single_gpu(case, world, overlap, monkeypatch):
     """Frames sharded over ranks (uneven for world = 3: T = 3 -> 1+1+1; tiny_resize T = 2 is too short) with the
     K/V all-gather in every global block == the single-process forward, bit for bit in fp32 up to summation order.
-    overlap "1" (M324_KV_OVERLAP, the default): the rank's own keys are attended while the gather is in flight, the remote
+    overlap "1" (M324_KV_OVERLAP=1, opt-in): the rank's own keys are attended while the gather is in flight, the remote
     ranges afterwards, and the partial softmaxes merged by their log-sum-exps -- case tiny_resize (B = 1, two frames over two
     ranks); B = 2 (tiny) takes the one-attention form: the own rows are not one range of the batch-major clip order; "0": one
     attention over the gathered keys."""

@@ -16,6 +16,16 @@ def test_lds_dma_kernels_wait_for_their_tiles_before_every_barrier():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_compiler_is_the_one_the_lds_alias_views_were_validated_on():
+    """The ring GEMMs hand ONE LDS buffer to their body through three __restrict__ views (csrc/gemm.hip gemm_ring_body, tn_pipe_body:
+    the invariant is written there).  That is validated by reading the ISA, per compiler: a new hipcc must be re-read (no compiler
+    `s_waitcnt vmcnt(0)` inside the K loops, every barrier behind its counted wait -- tools/audit_barriers.py) before this pin moves."""
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True)
+    assert "roc-7.2.0" in r.stdout and "HIP version: 7.2." in r.stdout, \
+        "hipcc changed: re-validate the __restrict__ LDS views of the ring GEMMs (DESIGN.md section 6), then update this pin\n" + r.stdout
+
+
 def test_no_packed_fp32_instruction_consumes_a_fresh_dpp_move():
     """v_mov_b32_dpp + v_pk_add_f32 (what the SLP vectoriser makes of two interleaved `v += dpp(v)` butterflies) returned wrong
     sums on MI355X beside a chunk-ring GEMM on the same CUs (round 3); the build's -fno-slp-vectorize keeps

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of GEMM schedules on the IN-CLIP forms of the wide projections (bf16 inference): fused head-major q|k|v epilogue
 and fc1 + GELU, both as LayerNorm-fold consumers that merge the producer's unmerged statistics table themselves.
-usage: tools/fold_ab.py [v13,v14,...] [--rounds 6] [--iters 20]"""
+usage: tools/fold_ab.py [v13,v15,...] [--rounds 6] [--iters 20]"""
 import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ from motion324_amd import lib, ops
 from motion324_amd.lib import ACT_GELU
 
 ap = argparse.ArgumentParser()
-ap.add_argument("variants", nargs="?", default="v10,v13,v14")
+ap.add_argument("variants", nargs="?", default="v10,v13,v15")
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--iters", type=int, default=20)
 args = ap.parse_args()

@@ -105,13 +105,13 @@ __global__ __launch_bounds__(256, 1) void attn_pwg_lab8_kernel(const bf16_t* __r
     float lse0, lse1;
     unsigned dbg0, dbg1, dbg2, dbg3, dbg4;
     asm volatile(
-#include "../../motion324_amd/csrc/attn_pwg_lab8.inc"
+#include "attn_pwg_lab8.inc"
         : [lse0] "=&v"(lse0), [lse1] "=&v"(lse1)
           , [dbg0] "=&v"(dbg0), [dbg1] "=&v"(dbg1), [dbg2] "=&v"(dbg2), [dbg3] "=&v"(dbg3), [dbg4] "=&v"(dbg4)
         : [rq] "s"(rq), [rk] "s"(rk), [rv] "s"(rv), [nt] "s"(nt), [rem] "s"(rem), [hi4] "v"(hi4), [wlds] "s"(wlds), [ko0] "v"(ko0), [vk0] "v"(vk[0]), [vk1] "v"(vk[1]),
           [vv0] "v"(vv[0]), [vv1] "v"(vv[1]), [qoff0] "v"(qoff0), [qoff1] "v"(qoff1), [escr] "v"(escr)
         : "memory", "vcc", "scc",
-#include "../../motion324_amd/csrc/attn_pwg_clobbers_lab.inc"
+#include "attn_pwg_clobbers_lab.inc"
     );
     if (lse && blockIdx.x == (gridDim.x >> 1) + 3 && lane == 0) {
         unsigned* d = reinterpret_cast<unsigned*>(lse + (long)gridDim.x / nqt * Lq) + wave * 8;

@@ -1,8 +1,8 @@
-// The kernel body of gemm_hp.hip; included once per instruction stream (HP_KERNEL = kernel name, HP_ASM_INC = the generated stream,
-// HP_ST_FLAG = the stores' cache flag).  The lab's stamped / ablation streams use their own twin of this file (tools/lab_src/).
+// Lab twin of motion324_amd/csrc/gemm_hp_kernel.inl (tools/lab_src/hp_lab.hip): the product wrapper plus HP_TRACE = 1 (the stamped stream's
+// debug outputs) and HP_TRACE = 2 (every tile of a workgroup lands on the same 64 KiB: no output traffic; wrong results).
 __global__ __launch_bounds__(256, 1) void HP_KERNEL(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw, bf16_t* C, long ldc,
                                                     int M, int N, const float* __restrict__ bias, const float* __restrict__ colsum,
-                                                    const float2* __restrict__ rowstat, int ntn, int ntiles, int xcd_remap) {
+                                                    const float2* __restrict__ rowstat, int ntn, int ntiles, int xcd_remap, unsigned* trace) {
     // three ring buffers [X 256 rows x 128 B | W 128 rows x 128 B] + the workgroup's tile table + 2 KiB of store scratch per wave; the only
     // LDS object of the kernel
     __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * HP_STAGE + HP_TABLE_BYTES + 4 * HP_SCRATCH];
@@ -25,7 +25,11 @@ __global__ __launch_bounds__(256, 1) void HP_KERNEL(const bf16_t* __restrict__ A
         tile_of(t, ntiles, ntm, ntn, xcd_remap, tm, tn);
         const long mrem = min(256, M - tm * 256);
         const unsigned long xa = (unsigned long)(A + (long)tm * 256 * lda), wa = (unsigned long)(W + (long)tn * 128 * ldw);
+#if HP_TRACE == 2          // lab: every tile of a workgroup lands on the same 64 KiB (no output traffic to HBM; wrong results)
+        const unsigned long ca = (unsigned long)(C + (long)(blockIdx.x % ntm) * 256 * ldc + (blockIdx.x / ntm % ntn) * 128);
+#else
         const unsigned long ca = (unsigned long)(C + (long)tm * 256 * ldc + tn * 128);
+#endif
         const unsigned long ra = (unsigned long)(rowstat + (long)tm * 256);
         unsigned* o = tab + e * 12;
         o[0] = (unsigned)xa;
@@ -72,13 +76,26 @@ __global__ __launch_bounds__(256, 1) void HP_KERNEL(const bf16_t* __restrict__ A
     const i32x4 rb = rsrc_words(bias ? (const void*)bias : (const void*)A, bias ? (long)N * 4 : 0l);
     const i32x4 rcs = rsrc_words(colsum ? (const void*)colsum : (const void*)A, colsum ? (long)N * 4 : 0l);
     __syncthreads();
+#if HP_TRACE == 1
+    unsigned dbg0, dbg1, dbg2, dbg3;
+#endif
     asm volatile(
 #include HP_ASM_INC
+#if HP_TRACE == 1
+        : [dbg0] "=&v"(dbg0), [dbg1] "=&v"(dbg1), [dbg2] "=&v"(dbg2), [dbg3] "=&v"(dbg3)
+#else
         :
+#endif
         : [rb] "s"(rb), [rcs] "s"(rcs), [wldsx] "s"(wldsx), [wldsw] "s"(wldsw), [wmo] "s"(wmo), [wno] "s"(wno), [xs16] "s"(xs16), [ws16] "s"(ws16),
           [cs8] "s"(cs8), [ntl] "s"(ntl), [xo0] "v"(xo[0]), [xo1] "v"(xo[1]), [wo0] "v"(wo[0]), [wo1] "v"(wo[1]), [fb] "v"(fb), [wa0] "v"(wa0),
           [rda] "v"(rda), [svo] "v"(svo), [bo] "v"(bo), [ro] "v"(ro), [tab] "v"(tabv)
         : "memory", "vcc", "scc",
 #include "gemm_hp_clobbers.inc"
     );
+#if HP_TRACE == 1
+    if (trace && tid == 0) {
+        unsigned* o = trace + (long)blockIdx.x * 4;
+        o[0] = dbg0, o[1] = dbg1, o[2] = dbg2, o[3] = dbg3;
+    }
+#endif
 }

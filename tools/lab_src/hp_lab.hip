@@ -23,76 +23,76 @@ constexpr int HP_SCRATCH = 2048;
 #define HP_ONE(NAME, INC) 
 #define HP_KERNEL k_full
 #define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_gelu.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_plain
 #define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_plain.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab1
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab1.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab1.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab2
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab2.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab2.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab4
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab4.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab4.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab5
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab5.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab5.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab6
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab6.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab6.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab7
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab7.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab7.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab8
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab8.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab8.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab9
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab9.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab9.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab10
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab10.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab10.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #define HP_KERNEL k_lab11
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab11.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab11.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #undef HP_TRACE
 #define HP_TRACE 2
 #define HP_KERNEL k_small
 #define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_gelu.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 #undef HP_TRACE
 #define HP_TRACE 1
 #define HP_KERNEL k_trace
-#define HP_ASM_INC "../../motion324_amd/csrc/gemm_hp_lab3.inc"
-#include "../../motion324_amd/csrc/gemm_hp_kernel.inl"
+#define HP_ASM_INC "gemm_hp_lab3.inc"
+#include "gemm_hp_lab_kernel.inl"
 #undef HP_KERNEL
 #undef HP_ASM_INC
 }  // namespace
