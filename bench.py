@@ -407,7 +407,7 @@ def decoder_block_replay(model, sample, steps: int, q_mode: str = "pair"):
                       "clip's trunk output"}
 
 
-def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
+def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out, headline_ms=None):
     """BASELINE's other configurations and the headline's precision variants, driver-visible in the default command
     (each a few steps; a failure is reported in place, never raised): the headline without its two narrower-than-reference
     shortcuts, fp32 parity mode on c2, the c3 training step, the 256-frame clip on one GPU, and the PCIe hand-over."""
@@ -562,7 +562,58 @@ def secondary_measurements(args, D, model, sd, sample, sample_np, ref_out):
         return {"value": round(w["B"] * w["T"] / ms * 1e3, 2), "unit": "frames/s", "ms_per_step": round(ms, 3), "finite": fin,
                 "note": "training.frames = 12, clip of 32 frames (parity of the resize: goldens tiny_resize and c1)"}
 
+    def long_video():
+        """SURVEY 8(f) row 1, the caller north_star names: motion324_amd.inference.run_model_inference (the reference's
+        scripts/inference_with_video_mesh.py:132-256) on a 256-frame HOST-resident video cut into 32-frame windows -- wall clock
+        around the whole call (window plan, uploads, forwards, merge), i.e. what a user of the script sees.  Nine windows of 32
+        frames produce the 256 output frames (every window re-runs the anchor frame, the last one overlaps its neighbour)."""
+        from motion324_amd.inference import plan_windows, run_model_inference
+        T, C = 256, w["T"]
+        g = torch.Generator().manual_seed(11)
+        vid8 = torch.randint(0, 256, (T, w["HW"], w["HW"], 3), generator=g, dtype=torch.uint8).pin_memory()
+        vidf = (vid8.float() / 255.0).pin_memory()
+        inp = {k: v for k, v in sample.items() if k != "rgb_video"}
+        cfg = {"training": {"frames": C, "use_amp": args.precision == "bf16"}}
+        n_win = len(plan_windows(T, C)[0])
+
+        def wall(video, reps=3, **kw):
+            model._drop_auto_graph()                    # every row starts from a model without captured graphs
+            for _ in range(3):                          # both window shapes reach their hipGraph (third call of a shape on)
+                o = run_model_inference(model, inp, video, cfg, dev, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                o = run_model_inference(model, inp, video, cfg, dev, **kw)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3, o
+        rows = {}
+        was = model.auto_graph
+        model.auto_graph = True                         # the scripts' plain `model(sample)` loop: graph replay from the third call on
+        try:
+            ms_u8, o_u8 = wall(vid8)
+            ms_f, o_f = wall(vidf)
+            ms_plain, o_p = wall(vidf, pipelined=False)
+            ms_pageable, _ = wall(vidf.clone(), reps=2)     # a caller that did not pin its frames: through the driver's bounce buffers
+        finally:
+            model.auto_graph = was
+            model._drop_auto_graph()
+        for name, ms in (("pipelined_uint8_frames", ms_u8), ("pipelined_fp32_frames", ms_f), ("plain_loop_fp32_frames", ms_plain),
+                         ("pipelined_fp32_frames_pageable_host", ms_pageable)):
+            rows[name] = {"ms_per_video": round(ms, 2), "video_frames_per_s": round(T / ms * 1e3, 1),
+                          "forwarded_frames_per_s": round(n_win * C / ms * 1e3, 1), "ms_per_window": round(ms / n_win, 3)}
+        res = {"value": rows["pipelined_uint8_frames"]["forwarded_frames_per_s"], "unit": "frames/s (forwarded; H2D, host work and merge included)",
+               "frames": T, "window": C, "windows": n_win, "rows": rows,
+               "identical_results": bool(torch.equal(o_u8, o_f) and torch.equal(o_f, o_p)), "finite": bool(torch.isfinite(o_u8).all()),
+               "note": "wall clock around run_model_inference on a pinned host video; plain_loop = the reference's literal loop (one "
+                       "synchronous upload per window, shape encoder and anchor frame recomputed per window); the forwards of all rows "
+                       "are hipGraph replays (the model's automatic graph, third call of a shape on)"}
+        if headline_ms:
+            res["headline_ms_per_clip"] = round(headline_ms, 3)
+            res["forwarded_rate_vs_headline"] = round(rows["pipelined_uint8_frames"]["forwarded_frames_per_s"] / (w["B"] * w["T"] / headline_ms * 1e3), 4)
+        return res
+
     guarded("headline_without_precision_shortcuts", strict)
+    guarded("long_video_driver", long_video)
     guarded("c2_with_training_frames_12_pos_embed_resized", resized)
     guarded("fp32_parity_mode_c2", fp32)
     guarded("h2d", h2d)
@@ -761,7 +812,7 @@ def run_infer(args, D: Dist):
         else:
             line["cpu_baseline"] = None
         if world == 1 and fast is not None and not args.no_secondary:
-            line["secondary"] = secondary_measurements(args, D, model, sd, sample, sample_np, ref)
+            line["secondary"] = secondary_measurements(args, D, model, sd, sample, sample_np, ref, headline_ms=ms)
     return line
 
 

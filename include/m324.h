@@ -232,6 +232,12 @@ int m324_attention_merge(const void* O0, const float* lse0, const void* O1, cons
  * ------------------------------------------------------------------------------------------ */
 int m324_patchify(const float* video, int F, int Hin, int Win, int size, int patch,
                   void* out, int Kp, int dtype, void* stream);
+/* The same on BYTE frames (ABI 19): video [F, Hin, Win, 3] uint8 in 0..255 -- what a video decoder delivers; every tap is
+ * converted as (float)v / 255.0f (IEEE division), i.e. exactly the caller's `frames.float() / 255.0`
+ * (scripts/inference_with_video_mesh.py:364), so the rows equal m324_patchify's on the converted frames bit for bit.
+ * The long-video driver uploads a quarter of the bytes (motion324_amd/inference.py). */
+int m324_patchify_u8(const unsigned char* video, int F, int Hin, int Win, int size, int patch,
+                     void* out, int Kp, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * m324_point_encode: Fourier features of points, PointEmbed.embed (model/Pcd_motion.py:178-182).

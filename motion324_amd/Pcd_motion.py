@@ -399,8 +399,8 @@ class Motion_Latent_Model(nn.Module):
         if timing.active() or any(isinstance(v, torch.Tensor) and v.device.type != "cuda" for v in sample.values()) \
                 or torch.cuda.is_current_stream_capturing():
             return None
-        from .graph import GraphedForward, _KEYS
-        key = (compute_dtype(),) + tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
+        from .graph import GraphedForward, shape_key
+        key = (compute_dtype(),) + shape_key(sample)
         seen = self.__dict__.setdefault("_ag_seen", {})
         if key not in seen and len(seen) >= 8:               # a caller that keeps changing shapes: forget the oldest
             del seen[next(iter(seen))]
@@ -409,9 +409,9 @@ class Motion_Latent_Model(nn.Module):
             return None
         ag = self.__dict__.get("_ag")
         if ag is None:
-            # at most two shape sets stay captured (each holds a clip's activations and its static inputs in a private
-            # pool); "thread_local": a DataLoader thread or another stream may keep calling into HIP during the capture
-            ag = GraphedForward(self, warmup=1, weak=True, max_graphs=2, capture_error_mode="thread_local")
+            # at most three shape sets stay captured (each holds a clip's activations and its static inputs in a private
+            # pool; the long-video driver alone uses two: the first window and the windows behind it); "thread_local": a DataLoader thread or another stream may keep calling into HIP during the capture
+            ag = GraphedForward(self, warmup=1, weak=True, max_graphs=3, capture_error_mode="thread_local")
             self.__dict__["_ag"] = ag                       # not a submodule: plain attribute
         fresh = ag._key(sample) not in ag._graphs
         if fresh:
@@ -440,6 +440,8 @@ class Motion_Latent_Model(nn.Module):
         finally:
             self.__dict__["_ag_busy"] = False
         out = edict(input_data=sample, pcd_moved=res.pcd_moved.clone())
+        if "reuse" in res:
+            out.reuse = edict({k: v.clone() for k, v in res.reuse.items()})
         if "loss_metrics" in res:
             lm = edict()
             for k, v in res.loss_metrics.items():
@@ -510,24 +512,35 @@ class Motion_Latent_Model(nn.Module):
         side = _side_stream(dev) if OVERLAP_SHAPE_ENCODER and cap is None else None
         if side is not None:
             side.wait_stream(main_stream)
+        # The long-video driver (inference.run_model_inference) runs many windows of ONE video over ONE mesh: stage A's result and
+        # the anchor frame's image tokens are the same in every window (bit for bit: every kernel works row by row), so a window may
+        # hand them in instead of recomputing them -- `m324_mesh_tokens` [B*K, C] and `m324_anchor_tokens` [1 + g*g, C] (B = 1;
+        # `rgb_video` then holds the frames BEHIND the anchor) -- and a window asked to (`m324_keep_reuse`) returns them as `reuse`.
+        mesh_in, anchor_in = sample.get("m324_mesh_tokens"), sample.get("m324_anchor_tokens")
+        keep_reuse = bool(sample.get("m324_keep_reuse", False))
+        if (mesh_in is not None or anchor_in is not None) and (shard is not None or cap is not None):
+            raise M324Error("m324_mesh_tokens / m324_anchor_tokens: single-GPU inference windows only")
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            pts = self._point_features(P, self._f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
-                                       self._f32c(sample["ref_shape_normals"]), self._f32c(sample["ref_shape_rgbs"]))
-            # fp32 [B*K, C], expanded once per weight version (the block reads it as the residual and writes a new stream)
-            query = P.derived(f"latent_tokens_x{B}", (self.learnable_tokens,),
-                              lambda: self.learnable_tokens.detach().to(device=P.device, dtype=torch.float32).reshape(K, C).repeat(B, 1))
-            mesh = self.encoder_cross_attn.run(P, query, pts, B, K, S)
-            if cap is not None:
-                cap["shape_point_feat"], cap["encoder_out"] = pts.clone(), mesh.clone()
-            for blk in self.points_transformer_blocks:
-                blk.run(P, mesh, B, K)
-            if cap is not None:
-                cap["mesh_feat"] = mesh.clone()
+            if mesh_in is not None:
+                mesh = self._f32c(mesh_in).reshape(B * K, C)
+            else:
+                pts = self._point_features(P, self._f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
+                                           self._f32c(sample["ref_shape_normals"]), self._f32c(sample["ref_shape_rgbs"]))
+                # fp32 [B*K, C], expanded once per weight version (the block reads it as the residual and writes a new stream)
+                query = P.derived(f"latent_tokens_x{B}", (self.learnable_tokens,),
+                                  lambda: self.learnable_tokens.detach().to(device=P.device, dtype=torch.float32).reshape(K, C).repeat(B, 1))
+                mesh = self.encoder_cross_attn.run(P, query, pts, B, K, S)
+                if cap is not None:
+                    cap["shape_point_feat"], cap["encoder_out"] = pts.clone(), mesh.clone()
+                for blk in self.points_transformer_blocks:
+                    blk.run(P, mesh, B, K)
+                if cap is not None:
+                    cap["mesh_feat"] = mesh.clone()
             # the decoder's point features and q projection depend on the mesh points only: under graph capture they
             # ride on this branch too (seven small launches, ~40 us, off the critical path between trunk and decoder)
             hoisted = None
             if (HOIST_DECODER_Q and side is not None and torch.cuda.is_current_stream_capturing()
-                    and DECODE_ROWS // sample["rgb_video"].shape[1] >= N):
+                    and DECODE_ROWS // (sample["rgb_video"].shape[1] + (anchor_in is not None)) >= N):
                 pcd_h, nrm_h, rgb_h = (self._f32c(sample[k]) for k in ("ref_pcd", "ref_normal", "ref_rgb"))
                 hoisted = []
                 for b in range(B):
@@ -551,10 +564,20 @@ class Motion_Latent_Model(nn.Module):
                 video = video[:, mine.start:mine.stop]
             elif video.shape[1] != len(mine):
                 raise M324Error(f"frame-parallel forward: rank {rank} of {world} owns {len(mine)} of {T_full} frames, rgb_video has {video.shape[1]}")
-        video = self._f32c(video)
+        # byte frames (what a decoder delivers) stay bytes: m324_patchify_u8 converts every tap as v / 255
+        video = video.detach().contiguous() if video.dtype == torch.uint8 else self._f32c(video)
         _, T, Hin, Win, _ = video.shape
-        dino_x = self.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))
         Pn = self.num_patches_h * self.num_patches_w
+        if anchor_in is not None:
+            if B != 1 or tuple(anchor_in.shape) != (1 + Pn, C):
+                raise M324Error(f"m324_anchor_tokens: expected [{1 + Pn}, {C}] with one sample per call, got {tuple(anchor_in.shape)} (B = {B})")
+            dino_x = torch.empty(((T + 1) * (1 + Pn), C), dtype=torch.float32, device=dev)
+            ops.cast(self._f32c(anchor_in), torch.float32, out=dino_x[:1 + Pn])      # m324_cast fp32 -> fp32: a row copy
+            self.image_encoder.run(P, video.reshape(T, Hin, Win, 3), out=dino_x[1 + Pn:])
+            T += 1
+            T_full = T
+        else:
+            dino_x = self.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))
 
         if side is not None:                      # join: the assembly reads the latent tokens
             main_stream.wait_stream(side)
@@ -672,6 +695,10 @@ class Motion_Latent_Model(nn.Module):
             else:
                 out = torch.cat([parts[r, :f] for r, f in enumerate(frames)], dim=0).transpose(0, 1).contiguous()
         result = edict(input_data=sample, pcd_moved=out)
+        if keep_reuse:
+            Ld = 1 + Pn
+            anchor = dino_x[:Ld] if B == 1 else dino_x.view(B, T, Ld, C)[:, 0].reshape(B * Ld, C).contiguous()
+            result.reuse = edict(mesh_tokens=mesh, anchor_tokens=anchor)
         if "point_clouds" in sample:                                           # reference :582-592
             m = self.loss_computer(out, sample["point_clouds"].to(dev))
             lm = edict()

@@ -275,8 +275,14 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qs
 // One thread per output pixel (frame, oy, ox): 4 bilinear taps x 3 interleaved channels.
 // PyTorch upsample_bilinear2d, align_corners=False: src = scale * (dst + 0.5) - 0.5 clamped at 0,
 // scale = in / out; i1 = min(i0 + 1, in - 1).
-template <typename T>
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ video, int F, int Hin, int Win, int size,
+// TIN = unsigned char: byte frames, every tap converted as (float)v / 255.0f -- the caller's `frames.float() / 255.0`, IEEE division.
+template <typename TIN>
+__device__ __forceinline__ float patch_tap(const TIN* p, int c) {
+    if constexpr (sizeof(TIN) == 1) return (float)p[c] / 255.0f;
+    else return p[c];
+}
+template <typename T, typename TIN>
+__global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ video, int F, int Hin, int Win, int size,
                                                        int patch, T* __restrict__ out, int Kp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)F * size * size;
@@ -288,18 +294,18 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
     const float ly = fy - (float)y0, lx = fx - (float)x0;
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const float* base = video + (long)f * Hin * Win * 3;
-    const float* p00 = base + ((long)y0 * Win + x0) * 3;
-    const float* p01 = base + ((long)y0 * Win + x1) * 3;
-    const float* p10 = base + ((long)y1 * Win + x0) * 3;
-    const float* p11 = base + ((long)y1 * Win + x1) * 3;
+    const TIN* base = video + (long)f * Hin * Win * 3;
+    const TIN* p00 = base + ((long)y0 * Win + x0) * 3;
+    const TIN* p01 = base + ((long)y0 * Win + x1) * 3;
+    const TIN* p10 = base + ((long)y1 * Win + x0) * 3;
+    const TIN* p11 = base + ((long)y1 * Win + x1) * 3;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};   // dinov2.py:7-8
     const int g = size / patch;
     const int py = oy / patch, ky = oy % patch, px = ox / patch, kx = ox % patch;
     T* orow = out + ((long)f * g * g + (long)py * g + px) * Kp;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v = hy * (hx * p00[c] + lx * p01[c]) + ly * (hx * p10[c] + lx * p11[c]);
+        const float v = hy * (hx * patch_tap(p00, c) + lx * patch_tap(p01, c)) + ly * (hx * patch_tap(p10, c) + lx * patch_tap(p11, c));
         Elem<T>::store(orow + c * patch * patch + ky * patch + kx, (v - mean[c]) / stdv[c]);
     }
     // zero the K padding once per patch row (the thread of the patch's first pixel)
@@ -922,18 +928,31 @@ extern "C" int m324_qkv_split(const void* q_src, long ldq, const void* k_src, lo
     return M324_OK;
 }
 
-extern "C" int m324_patchify(const float* video, int F, int Hin, int Win, int size, int patch, void* out, int Kp, int dtype,
-                             void* stream) {
-    M324_REQUIRE(video && out, "m324_patchify: null pointer");
-    M324_REQUIRE(F > 0 && Hin > 0 && Win > 0 && size > 0 && patch > 0 && size % patch == 0, "m324_patchify: bad geometry");
-    M324_REQUIRE(Kp >= 3 * patch * patch, "m324_patchify: Kp=%d too small", Kp);
+template <typename TIN>
+static int patchify_launch(const TIN* video, int F, int Hin, int Win, int size, int patch, void* out, int Kp, int dtype, void* stream, const char* what) {
+    M324_REQUIRE(video && out, "%s: null pointer", what);
+    M324_REQUIRE(F > 0 && Hin > 0 && Win > 0 && size > 0 && patch > 0 && size % patch == 0, "%s: bad geometry", what);
+    M324_REQUIRE(Kp >= 3 * patch * patch, "%s: Kp=%d too small", what, Kp);
     const long total = (long)F * size * size;
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_DTYPE(dtype, "m324_patchify",
-                   hipLaunchKernelGGL(patchify_kernel<T>, dim3(ceil_div(total, 256)), dim3(256), 0, s, video, F, Hin, Win,
-                                      size, patch, (T*)out, Kp));
-    M324_CHECK_LAUNCH("m324_patchify");
+    if (dtype == M324_BF16)
+        hipLaunchKernelGGL((patchify_kernel<bf16_t, TIN>), dim3(ceil_div(total, 256)), dim3(256), 0, s, video, F, Hin, Win, size, patch, (bf16_t*)out, Kp);
+    else if (dtype == M324_F32)
+        hipLaunchKernelGGL((patchify_kernel<float, TIN>), dim3(ceil_div(total, 256)), dim3(256), 0, s, video, F, Hin, Win, size, patch, (float*)out, Kp);
+    else
+        M324_FAIL(M324_ERR_UNSUPPORTED, "%s: dtype %d", what, dtype);
+    M324_CHECK_LAUNCH(what);
     return M324_OK;
+}
+
+extern "C" int m324_patchify(const float* video, int F, int Hin, int Win, int size, int patch, void* out, int Kp, int dtype,
+                             void* stream) {
+    return patchify_launch<float>(video, F, Hin, Win, size, patch, out, Kp, dtype, stream, "m324_patchify");
+}
+
+extern "C" int m324_patchify_u8(const unsigned char* video, int F, int Hin, int Win, int size, int patch, void* out, int Kp, int dtype,
+                                void* stream) {
+    return patchify_launch<unsigned char>(video, F, Hin, Win, size, patch, out, Kp, dtype, stream, "m324_patchify_u8");
 }
 
 extern "C" int m324_point_encode(const float* xyz, int P, void* out, long ld, int dtype, void* stream) {

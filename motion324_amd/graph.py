@@ -28,7 +28,21 @@ from . import prepared
 from .prepared import compute_dtype
 
 _KEYS = ("ref_shape_pcd", "ref_shape_normals", "ref_shape_rgbs", "ref_pcd", "ref_normal", "ref_rgb", "rgb_video",
-         "point_clouds")
+         "point_clouds", "m324_mesh_tokens", "m324_anchor_tokens")
+_FLAGS = ("m324_keep_reuse",)          # non-tensor entries of a sample that change what the forward returns
+
+
+def shape_key(sample) -> Tuple:
+    """what a captured graph is specialised on besides weights and precision: every input's shape, whether the frames are
+    bytes (m324_patchify_u8) or fp32, and the flags"""
+    return tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample) + \
+        (("u8", sample["rgb_video"].dtype == torch.uint8),) + tuple((f, bool(sample.get(f, False))) for f in _FLAGS)
+
+
+def _static_copy(k: str, t: torch.Tensor) -> torch.Tensor:
+    if k == "rgb_video" and t.dtype == torch.uint8:
+        return t.detach().contiguous().clone()
+    return t.detach().to(torch.float32).contiguous().clone()
 
 
 class _Segmenter:
@@ -110,8 +124,7 @@ class GraphedForward:
         self._graphs.clear()
 
     def _key(self, sample) -> Tuple:
-        return (prepared.generation(), prepared.weight_stamp(self.model), compute_dtype()) + \
-            tuple((k, tuple(sample[k].shape)) for k in _KEYS if k in sample)
+        return (prepared.generation(), prepared.weight_stamp(self.model), compute_dtype()) + shape_key(sample)
 
     def static_inputs(self, sample: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """The graph's own input buffers for this sample's shapes (captured on first use), holding a copy of `sample`.
@@ -135,7 +148,8 @@ class GraphedForward:
             # tensors created under torch.inference_mode() could not be updated in place by a later call that runs
             # under plain no_grad ("Inplace update to inference tensor outside InferenceMode").
             with torch.inference_mode(False), torch.no_grad():
-                static_in = {k: sample[k].detach().to(torch.float32).contiguous().clone() for k in _KEYS if k in sample}
+                static_in = {k: _static_copy(k, sample[k]) for k in _KEYS if k in sample}
+                static_in.update({f: True for f in _FLAGS if sample.get(f, False)})
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
@@ -189,6 +203,8 @@ class GraphedForward:
         g, static_in, static_out = entry
         with torch.inference_mode(False), torch.no_grad():
             for k, buf in static_in.items():
+                if not isinstance(buf, torch.Tensor):
+                    continue
                 src = sample[k]
                 if src.data_ptr() != buf.data_ptr():
                     buf.copy_(src, non_blocking=True)
@@ -196,4 +212,6 @@ class GraphedForward:
         out = edict(input_data=sample, pcd_moved=static_out["pcd_moved"])
         if "loss_metrics" in static_out:
             out.loss_metrics = static_out["loss_metrics"]
+        if "reuse" in static_out:                    # static buffers like pcd_moved: overwritten by this graph's next replay
+            out.reuse = static_out["reuse"]
         return out

@@ -131,10 +131,11 @@ class DinoEncoder(nn.Module):
         self.model.eval()
         return self
 
-    def run(self, P: Prepared, video: torch.Tensor, two_streams: bool = True) -> torch.Tensor:
-        """video [F, Hin, Win, 3] fp32 in [0,1] (channel-last, any size) -> pre-final-norm tokens
-        [F * (1 + g*g), C] fp32.  Resize to 224^2 + ImageNet normalisation + im2col happen in one kernel
-        (Pcd_motion.py:470-472, dinov2.py:78-80)."""
+    def run(self, P: Prepared, video: torch.Tensor, two_streams: bool = True, out: torch.Tensor = None) -> torch.Tensor:
+        """video [F, Hin, Win, 3] fp32 in [0,1] or uint8 in 0..255 (channel-last, any size) -> pre-final-norm tokens
+        [F * (1 + g*g), C] fp32 (written into `out` when given: a caller that already holds some frames' tokens -- the long-video
+        driver's anchor frame -- passes the rows behind them).  Resize to 224^2 + ImageNet normalisation + im2col happen in one
+        kernel (Pcd_motion.py:470-472, dinov2.py:78-80)."""
         m = self.model
         Fr = video.shape[0]
         g, C, H = self.num_patches_per_dim, m.embed_dim, m.num_heads
@@ -142,7 +143,9 @@ class DinoEncoder(nn.Module):
         kp = pad_k(3 * self.patch_size ** 2)
         patches = ops.patchify(video, self.image_size, self.patch_size, kp, P.dtype)
         pos = P.derived(f"dino_pos{g}", (m.pos_embed,), lambda: m.interpolated_pos(g).to(P.device))
-        x = torch.empty((Fr * Lt, C), dtype=torch.float32, device=video.device)
+        if out is not None and (out.shape != (Fr * Lt, C) or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise ValueError(f"DinoEncoder.run: out must be contiguous fp32 [{Fr * Lt}, {C}], got {out.dtype}{tuple(out.shape)}")
+        x = out if out is not None else torch.empty((Fr * Lt, C), dtype=torch.float32, device=video.device)
         ops.gemm(patches, P.mat(m.patch_embed.proj.weight), x, bias=P.vec(m.patch_embed.proj.bias),
                  residual=pos[1:], res_rows=g * g, row_map=(g * g, Lt, 1))
         ops.dino_cls_rows(P.f32(m.cls_token).reshape(-1), pos[0], x, Fr, Lt)

@@ -67,11 +67,99 @@ def _cfg_get(cfg, key, default=None):
     return cfg.get(key, default) if isinstance(cfg, dict) else getattr(cfg, key, default)
 
 
+class _WindowFeeder:
+    """Frames of the windows on their way to the GPU: window w + 1 uploads on a copy stream while window w computes.
+
+    Source: the caller's video [T,H,W,3] -- fp32 in [0,1] or uint8 in 0..255 (a quarter of the bytes; m324_patchify_u8 converts
+    every tap as v / 255, bit-identical to `video.float() / 255`), on the host (pinned: DMA straight from the caller's pages;
+    pageable: through two pinned bounce buffers) or already on the device.  Two device staging buffers; an event per buffer says
+    "uploaded" (the compute stream waits on it) and "consumed" (the next upload into that buffer waits on it).  The anchor frame
+    0 opens every window of the reference's plan (scripts/inference_with_video_mesh.py:187-194): it is uploaded once and kept."""
+
+    def __init__(self, video: torch.Tensor, device, max_frames: int, overlap: bool = True):
+        self.video, self.dev, self.overlap = video, torch.device(device), overlap
+        if video.dtype != torch.uint8 and video.dtype != torch.float32:
+            self.video = video = video.float()                 # the reference's `.float()` (fp16 / fp64 frames)
+        frame = tuple(video.shape[1:])
+        self.stage = [torch.empty((max_frames,) + frame, dtype=video.dtype, device=self.dev) for _ in range(2)]
+        self.on_host = video.device.type == "cpu"
+        self.bounce = None
+        if self.on_host and not video.is_pinned():
+            self.bounce = [torch.empty((max_frames,) + frame, dtype=video.dtype).pin_memory() for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=self.dev) if overlap else None
+        self.uploaded = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [None, None]
+        self.host_done = [None, None]                          # bounce buffer k may be refilled once its DMA has left it
+        self.anchor = None
+        self.n = 0
+
+    def _copy(self, slot: int, dst_off: int, lo: int, hi: int) -> None:
+        dst = self.stage[slot][dst_off:dst_off + hi - lo]
+        if self.bounce is not None:
+            b = self.bounce[slot][dst_off:dst_off + hi - lo]
+            b.copy_(self.video[lo:hi])                         # host memcpy into pinned pages
+            dst.copy_(b, non_blocking=True)
+        else:
+            dst.copy_(self.video[lo:hi], non_blocking=True)
+
+    def upload(self, frames) -> int:
+        """Starts the upload of the given video frame indices (the anchor 0 may lead; the rest is one contiguous run) into the
+        next staging buffer; returns the slot."""
+        slot = self.n & 1
+        self.n += 1
+        main = torch.cuda.current_stream(self.dev)
+        st = self.copy_stream if self.copy_stream is not None else main
+        if self.bounce is not None and self.host_done[slot] is not None:
+            self.host_done[slot].synchronize()
+        with torch.cuda.stream(st):
+            if self.consumed[slot] is not None:
+                st.wait_event(self.consumed[slot])
+            off = 0
+            rest = list(frames)
+            if len(rest) > 1 and rest[0] == 0 and rest[1] != 1:           # anchor + a later run
+                if self.anchor is None:
+                    self.anchor = self.video[0:1].to(self.dev, non_blocking=True) if self.on_host else self.video[0:1].clone()
+                self.stage[slot][0:1].copy_(self.anchor, non_blocking=True)
+                off, rest = 1, rest[1:]
+            lo, hi = rest[0], rest[-1] + 1
+            assert rest == list(range(lo, hi)), "a window is the anchor frame plus one contiguous run of frames"
+            self._copy(slot, off, lo, hi)
+            self.uploaded[slot].record(st)
+            if self.bounce is not None:
+                self.host_done[slot] = torch.cuda.Event()
+                self.host_done[slot].record(st)
+        return slot
+
+    def frames(self, slot: int, n: int) -> torch.Tensor:
+        """The staged frames [n,H,W,3] of a slot, valid for work enqueued on the current stream from here on."""
+        torch.cuda.current_stream(self.dev).wait_event(self.uploaded[slot])
+        return self.stage[slot][:n]
+
+    def release(self, slot: int) -> None:
+        """Everything enqueued so far on the current stream has read the slot's frames."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self.consumed[slot] = ev
+
+
+def _native(model) -> bool:
+    from .Pcd_motion import Motion_Latent_Model
+    return isinstance(model, Motion_Latent_Model)
+
+
 def run_model_inference(model, input_data: Dict[str, torch.Tensor], video_tensor: torch.Tensor, config, device,
-                        group=None) -> Optional[torch.Tensor]:
+                        group=None, pipelined: Optional[bool] = None, reuse: Optional[bool] = None) -> Optional[torch.Tensor]:
     """Same contract as the reference driver: video_tensor [T,H,W,3] in [0,1] (any T) -> trajectories [1,T,N,3]
     fp32 on `device`.  With an initialised process group the windows are sharded over its ranks and the result is
-    available on every rank."""
+    available on every rank.
+
+    On a HIP device the windows are PIPELINED (pipelined=None: whenever the device is one; False: the plain loop, one
+    synchronous upload per window, kept for A/B and as the reference's literal form): window w + 1's frames travel on a copy
+    stream under window w's forward (_WindowFeeder: pinned staging, the anchor frame uploaded once, uint8 videos accepted --
+    a quarter of the host-to-device bytes).  reuse (None: with this package's model): the shape encoder's latent tokens and
+    the anchor frame's image tokens are computed by the first window and handed to the others (Motion_Latent_Model._forward:
+    `m324_mesh_tokens`, `m324_anchor_tokens`) -- they are the same in every window, bit for bit; the result equals the plain
+    loop's exactly (tests/test_configs_gpu.py)."""
     tr = _cfg_get(config, "training")
     chunk = _cfg_get(tr, "frames", 12)
     use_amp = _cfg_get(tr, "use_amp", False)
@@ -80,16 +168,59 @@ def run_model_inference(model, input_data: Dict[str, torch.Tensor], video_tensor
     ref_pcd = input_data["ref_pcd"]
     N = ref_pcd.shape[1]
     dev_type = torch.device(device).type
+    if pipelined is None:
+        pipelined = dev_type == "cuda"
+    if pipelined and dev_type != "cuda":
+        raise ValueError("run_model_inference(pipelined=True) needs a HIP device")
+    if video_tensor.dtype == torch.uint8 and not _native(model):
+        raise ValueError("uint8 frames are converted by this package's model only (m324_patchify_u8); pass `video.float() / 255`")
+    if reuse is None:
+        reuse = pipelined and _native(model) and not getattr(model, "training", False) and ref_pcd.shape[0] == 1
+    rank, world = parallel.world_info(group)
+    mine = list(parallel.partition(len(windows), world, rank))
 
-    def forward_window(w: int) -> torch.Tensor:
-        idx = torch.as_tensor(windows[w], device=video_tensor.device)
-        sample = dict(input_data)
-        sample["rgb_video"] = video_tensor.index_select(0, idx)[None].float().to(device)
-        with torch.no_grad(), torch.autocast(enabled=bool(use_amp), device_type=dev_type, dtype=torch.bfloat16):
-            out = model(sample)
+    def check(out) -> torch.Tensor:
         if not (isinstance(out, dict) and "pcd_moved" in out):
             raise RuntimeError("model returned no pcd_moved")
         return out["pcd_moved"].float()[0]
 
-    outs = parallel.map_items(forward_window, len(windows), (len(windows[0]), N, 3), device, group=group)
-    return merge_windows(outs, out_map, ref_pcd.to(device))
+    def call(sample):
+        with torch.no_grad(), torch.autocast(enabled=bool(use_amp), device_type=dev_type, dtype=torch.bfloat16):
+            return model(sample)
+
+    if not pipelined:
+        def forward_window(w: int) -> torch.Tensor:
+            idx = torch.as_tensor(windows[w], device=video_tensor.device)
+            sample = dict(input_data)
+            frames = video_tensor.index_select(0, idx)[None]
+            sample["rgb_video"] = (frames if frames.dtype == torch.uint8 else frames.float()).to(device)
+            return check(call(sample))
+        outs = [forward_window(w) for w in mine]
+    else:
+        feeder = _WindowFeeder(video_tensor, device, len(windows[0]))
+        kept = None                                    # (mesh tokens, anchor tokens) of this video, from the first window that ran
+        outs = []
+
+        def frames_of(w: int):
+            # a later window with the anchor's tokens at hand uploads only the frames behind the anchor
+            return windows[w][1:] if (kept is not None and w > 0 and len(windows) > 1) else windows[w]
+        slot = feeder.upload(frames_of(mine[0])) if mine else None
+        for i, w in enumerate(mine):
+            fr = frames_of(w)
+            sample = dict(input_data)
+            sample["rgb_video"] = feeder.frames(slot, len(fr))[None]
+            if kept is not None and len(fr) < len(windows[w]):
+                sample["m324_mesh_tokens"], sample["m324_anchor_tokens"] = kept
+            elif kept is not None:
+                sample["m324_mesh_tokens"] = kept[0]
+            elif reuse and len(mine) > 1:
+                sample["m324_keep_reuse"] = True
+            out = call(sample)
+            feeder.release(slot)
+            if kept is None and reuse and len(mine) > 1:
+                kept = (out["reuse"]["mesh_tokens"], out["reuse"]["anchor_tokens"]) if windows[w][0] == 0 else None
+            if i + 1 < len(mine):                      # the next window's frames travel under this window's forward
+                slot = feeder.upload(frames_of(mine[i + 1]))
+            outs.append(check(out))
+    local = torch.stack(outs, dim=0) if outs else torch.zeros((0, len(windows[0]), N, 3), dtype=torch.float32, device=device)
+    return merge_windows(parallel.all_gather_items(local, len(windows), group), out_map, ref_pcd.to(device))

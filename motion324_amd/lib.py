@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 ERR_UNSUPPORTED = -3          # m324_status M324_ERR_UNSUPPORTED
 
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "m324_attention": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _I, _P, _I, _P],
     "m324_attention_merge": [_P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "m324_patchify": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "m324_patchify_u8": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "m324_point_encode": [_P, _I, _P, _L, _I, _P],
     "m324_point_concat": [_P, _P, _I, _P, _I, _I, _I, _P],
     "m324_dino_cls_rows": [_P, _P, _P, _I, _I, _I, _P],

@@ -469,14 +469,16 @@ def attention_merge(parts, out: torch.Tensor, B: int, H: int, Lq: int) -> torch.
 
 
 def patchify(video: torch.Tensor, size: int, patch: int, Kp: int, dtype: torch.dtype) -> torch.Tensor:
-    """video [F,Hin,Win,3] fp32 -> [F*(size/patch)^2, Kp] normalised, bilinearly resized patch rows."""
-    if video.dtype != torch.float32 or not video.is_contiguous() or video.dim() != 4 or video.shape[3] != 3:
+    """video [F,Hin,Win,3] fp32 in [0,1] -- or uint8 in 0..255, converted per tap as v / 255 (m324_patchify_u8: the rows equal the
+    fp32 path's on `video.float() / 255` bit for bit) -> [F*(size/patch)^2, Kp] normalised, bilinearly resized patch rows."""
+    if video.dtype not in (torch.float32, torch.uint8) or not video.is_contiguous() or video.dim() != 4 or video.shape[3] != 3:
         raise L.M324Error(f"patchify: video {video.dtype}{tuple(video.shape)}")
     Fr, Hin, Win, _ = video.shape
     g = size // patch
     out = torch.empty((Fr * g * g, Kp), dtype=dtype, device=video.device)
-    L.check(L.load().m324_patchify(_p(video), Fr, Hin, Win, size, patch, _p(out), Kp, code_of(dtype), _stream()),
-            "m324_patchify")
+    fn, name = (L.load().m324_patchify_u8, "m324_patchify_u8") if video.dtype == torch.uint8 else (L.load().m324_patchify, "m324_patchify")
+    L.check(fn(_p(video), Fr, Hin, Win, size, patch, _p(out), Kp, code_of(dtype), _stream()), name)
+    _wrote(out)
     return out
 
 

@@ -529,6 +529,80 @@ def test_sliding_window_driver_with_the_real_model(T):
     assert rel_err(got, want) < FP32_TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pipelined_driver_equals_the_plain_loop_bit_for_bit(precision):
+    """The engineered driver -- window w + 1's frames on a copy stream under window w's forward, the shape encoder's tokens and
+    the anchor frame's image tokens computed once per video, hipGraph replay from the third window of a shape on -- against the
+    reference's literal loop (one synchronous upload per window, everything recomputed): the SAME trajectories, bit for bit, from
+    pinned, pageable and device-resident videos; and without the reuse."""
+    import motion324_amd as m
+    from motion324_amd.inference import run_model_inference
+    T = 30
+    model, sd, cfg, dm = _tiny4()
+    inp, video = _driver_inputs(T)
+    inp = {k: v.cuda() for k, v in inp.items()}
+    m.set_precision(precision)
+    try:
+        model.auto_graph = False
+        plain = run_model_inference(model, inp, video, cfg, "cuda", pipelined=False)
+        model.auto_graph = True
+        for src in (video, video.pin_memory(), video.cuda()):
+            got = run_model_inference(model, inp, src, cfg, "cuda")
+            assert torch.equal(got, plain), float((got - plain).abs().max())
+        assert model.__dict__.get("_ag") is not None and len(model._ag._graphs) >= 1      # the later windows were graph replays
+        got = run_model_inference(model, inp, video, cfg, "cuda", reuse=False)
+        assert torch.equal(got, plain)
+        # a second video through the same model (graphs and static inputs are reused; the kept tokens are per video)
+        inp2, video2 = _driver_inputs(T)
+        video2 = video2.flip(0).contiguous()
+        model.auto_graph = False
+        plain2 = run_model_inference(model, inp, video2, cfg, "cuda", pipelined=False)
+        model.auto_graph = True
+        assert torch.equal(run_model_inference(model, inp, video2.pin_memory(), cfg, "cuda"), plain2)
+        assert not torch.equal(plain2, plain)
+    finally:
+        m.set_precision(None)
+
+
+def test_byte_frames_equal_their_float_form_bit_for_bit():
+    """uint8 frames (a quarter of the upload) are converted by m324_patchify_u8 as v / 255 per tap: the trajectories equal those
+    of `video.float() / 255` exactly -- plain loop, pipelined driver, and the model called directly."""
+    from motion324_amd import ops
+    from motion324_amd.inference import run_model_inference
+    T = 9
+    model, sd, cfg, dm = _tiny4()
+    inp, _ = _driver_inputs(T)
+    inp = {k: v.cuda() for k, v in inp.items()}
+    g = torch.Generator().manual_seed(5)
+    vid8 = torch.randint(0, 256, (T, 50, 70, 3), generator=g, dtype=torch.uint8)
+    vidf = vid8.float() / 255.0
+    a = ops.patchify(vid8.cuda(), 224, 14, 640, torch.float32)
+    b = ops.patchify(vidf.cuda(), 224, 14, 640, torch.float32)
+    assert torch.equal(a, b)
+    want = run_model_inference(model, inp, vidf, cfg, "cuda", pipelined=False)
+    assert torch.equal(run_model_inference(model, inp, vid8, cfg, "cuda", pipelined=False), want)
+    assert torch.equal(run_model_inference(model, inp, vid8.pin_memory(), cfg, "cuda"), want)
+    assert torch.equal(run_model_inference(model, inp, vid8, cfg, "cuda"), want)
+    with torch.no_grad():
+        s8, sf = dict(inp, rgb_video=vid8[None, :4].cuda()), dict(inp, rgb_video=vidf[None, :4].cuda())
+        assert torch.equal(model(s8).pcd_moved, model(sf).pcd_moved)
+
+
+def test_window_reuse_keys_are_refused_where_they_do_not_apply():
+    from motion324_amd.lib import M324Error
+    model, sd, cfg, dm = _tiny4()
+    inp, video = _driver_inputs(4)
+    s = {k: v.cuda() for k, v in inp.items()}
+    s["rgb_video"] = video[None].cuda()
+    with torch.no_grad():
+        out = model(dict(s, m324_keep_reuse=True))
+        assert out.reuse.mesh_tokens.shape == (8, 192) and out.reuse.anchor_tokens.shape == (257, 192)
+        later = dict(s, rgb_video=s["rgb_video"][:, 1:], m324_mesh_tokens=out.reuse.mesh_tokens, m324_anchor_tokens=out.reuse.anchor_tokens)
+        assert torch.equal(model(later).pcd_moved, out.pcd_moved)               # the same window, anchor and mesh handed in
+        with pytest.raises(M324Error, match="m324_anchor_tokens"):
+            model(dict(later, m324_anchor_tokens=out.reuse.anchor_tokens[:100]))
+
+
 def _driver_worker(rank, world, port, T, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
