@@ -76,26 +76,33 @@ class _WindowFeeder:
     "uploaded" (the compute stream waits on it) and "consumed" (the next upload into that buffer waits on it).  The anchor frame
     0 opens every window of the reference's plan (scripts/inference_with_video_mesh.py:187-194): it is uploaded once and kept."""
 
-    def __init__(self, video: torch.Tensor, device, max_frames: int, overlap: bool = True):
-        self.video, self.dev, self.overlap = video, torch.device(device), overlap
-        if video.dtype != torch.uint8 and video.dtype != torch.float32:
-            self.video = video = video.float()                 # the reference's `.float()` (fp16 / fp64 frames)
-        frame = tuple(video.shape[1:])
-        self.stage = [torch.empty((max_frames,) + frame, dtype=video.dtype, device=self.dev) for _ in range(2)]
-        self.on_host = video.device.type == "cpu"
+    def __init__(self, dtype: torch.dtype, frame: tuple, device, max_frames: int):
+        self.dev, self.max_frames = torch.device(device), max_frames
+        self.stage = [torch.empty((max_frames,) + tuple(frame), dtype=dtype, device=self.dev) for _ in range(2)]
         self.bounce = None
-        if self.on_host and not video.is_pinned():
-            self.bounce = [torch.empty((max_frames,) + frame, dtype=video.dtype).pin_memory() for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=self.dev) if overlap else None
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        # the staging buffers were allocated on the caller's stream and are written on the copy stream: whatever that stream still
+        # has queued (a previous owner of the memory) comes first
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.dev))
         self.uploaded = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [None, None]
         self.host_done = [None, None]                          # bounce buffer k may be refilled once its DMA has left it
-        self.anchor = None
+        self.video, self.on_host, self.anchor = None, False, None
         self.n = 0
+
+    def begin(self, video: torch.Tensor) -> "_WindowFeeder":
+        """A new video through the same staging buffers.  The events of the previous video stay in force: a caller that runs
+        videos back to back without synchronising (the next video's first upload may be issued while the previous video's last
+        window is still reading its frames) is ordered by them."""
+        self.video, self.on_host, self.anchor = video, video.device.type == "cpu", None
+        if self.on_host and not video.is_pinned() and self.bounce is None:
+            self.bounce = [torch.empty(self.stage[0].shape, dtype=video.dtype).pin_memory() for _ in range(2)]
+        self.pageable = self.on_host and not video.is_pinned()
+        return self
 
     def _copy(self, slot: int, dst_off: int, lo: int, hi: int) -> None:
         dst = self.stage[slot][dst_off:dst_off + hi - lo]
-        if self.bounce is not None:
+        if self.pageable:
             b = self.bounce[slot][dst_off:dst_off + hi - lo]
             b.copy_(self.video[lo:hi])                         # host memcpy into pinned pages
             dst.copy_(b, non_blocking=True)
@@ -107,9 +114,8 @@ class _WindowFeeder:
         next staging buffer; returns the slot."""
         slot = self.n & 1
         self.n += 1
-        main = torch.cuda.current_stream(self.dev)
-        st = self.copy_stream if self.copy_stream is not None else main
-        if self.bounce is not None and self.host_done[slot] is not None:
+        st = self.copy_stream
+        if self.pageable and self.host_done[slot] is not None:
             self.host_done[slot].synchronize()
         with torch.cuda.stream(st):
             if self.consumed[slot] is not None:
@@ -125,7 +131,7 @@ class _WindowFeeder:
             assert rest == list(range(lo, hi)), "a window is the anchor frame plus one contiguous run of frames"
             self._copy(slot, off, lo, hi)
             self.uploaded[slot].record(st)
-            if self.bounce is not None:
+            if self.pageable:
                 self.host_done[slot] = torch.cuda.Event()
                 self.host_done[slot].record(st)
         return slot
@@ -140,6 +146,22 @@ class _WindowFeeder:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
         self.consumed[slot] = ev
+
+
+_FEEDERS: Dict[tuple, _WindowFeeder] = {}          # staging buffers (2 x one window of frames) kept per device and frame format
+
+
+def _feeder_for(video: torch.Tensor, device, max_frames: int) -> _WindowFeeder:
+    if video.dtype != torch.uint8 and video.dtype != torch.float32:
+        video = video.float()                          # the reference's `.float()` (fp16 / fp64 frames)
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), video.dtype, tuple(video.shape[1:]), max_frames)
+    f = _FEEDERS.get(key)
+    if f is None:
+        while len(_FEEDERS) >= 2:                      # a caller that keeps changing formats: drop the oldest
+            del _FEEDERS[next(iter(_FEEDERS))]
+        f = _FEEDERS[key] = _WindowFeeder(video.dtype, tuple(video.shape[1:]), dev, max_frames)
+    return f.begin(video)
 
 
 def _native(model) -> bool:
@@ -197,7 +219,7 @@ def run_model_inference(model, input_data: Dict[str, torch.Tensor], video_tensor
             return check(call(sample))
         outs = [forward_window(w) for w in mine]
     else:
-        feeder = _WindowFeeder(video_tensor, device, len(windows[0]))
+        feeder = _feeder_for(video_tensor, device, len(windows[0]))
         kept = None                                    # (mesh tokens, anchor tokens) of this video, from the first window that ran
         outs = []
 

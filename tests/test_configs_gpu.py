@@ -560,6 +560,11 @@ def test_pipelined_driver_equals_the_plain_loop_bit_for_bit(precision):
         model.auto_graph = True
         assert torch.equal(run_model_inference(model, inp, video2.pin_memory(), cfg, "cuda"), plain2)
         assert not torch.equal(plain2, plain)
+        # videos back to back WITHOUT a synchronisation in between: the second video's first upload is issued while the first video's
+        # last windows are still queued -- the staging buffers' events order them (bench.py's long_video_driver row is the full-size form)
+        pa, pb = video.pin_memory(), video2.pin_memory()
+        results = [run_model_inference(model, inp, v, cfg, "cuda") for v in (pa, pb, pa, pb)]
+        assert all(torch.equal(r, want) for r, want in zip(results, (plain, plain2, plain, plain2)))
     finally:
         m.set_precision(None)
 
