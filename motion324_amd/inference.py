@@ -11,9 +11,13 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 
 from . import parallel
+
+_HOST_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="m324-stage")     # pageable frames -> pinned bounce buffers
 
 Slot = Optional[Tuple[int, int]]      # (window index, frame slot inside that window) or None = ref_pcd
 
@@ -57,10 +61,26 @@ def plan_windows(total_T: int, chunk: int) -> Tuple[List[List[int]], List[Slot]]
     return windows, out
 
 
+_MERGE_INDEX: Dict[tuple, tuple] = {}              # (device, n_windows, C, out_map) -> (gather index on the device, frames replaced by ref_pcd)
+
+
 def merge_windows(outs: torch.Tensor, out_map: List[Slot], ref_pcd: torch.Tensor) -> torch.Tensor:
-    """outs [n_windows, C, N, 3] -> trajectories [1, len(out_map), N, 3]."""
-    frames = [ref_pcd.reshape(-1, 3).to(outs.dtype) if s is None else outs[s[0], s[1]] for s in out_map]
-    return torch.stack(frames, dim=0).unsqueeze(0)
+    """outs [n_windows, C, N, 3] -> trajectories [1, len(out_map), N, 3]: one gather over the (window, slot) pairs of the plan
+    (the index lives on the device, cached per plan: no host-to-device copy between the last forward and the result), then the
+    frames the reference overwrites with ref_pcd."""
+    nW, C = outs.shape[0], outs.shape[1]
+    key = (str(outs.device), nW, C, tuple(out_map))
+    hit = _MERGE_INDEX.get(key)
+    if hit is None:
+        if len(_MERGE_INDEX) >= 16:
+            _MERGE_INDEX.clear()
+        flat = [0 if s is None else s[0] * C + s[1] for s in out_map]
+        hit = _MERGE_INDEX[key] = (torch.tensor(flat, dtype=torch.long).to(outs.device), [t for t, s in enumerate(out_map) if s is None])
+    idx, from_ref = hit
+    merged = outs.reshape(nW * C, *outs.shape[2:]).index_select(0, idx)
+    for t in from_ref:
+        merged[t] = ref_pcd.reshape(-1, 3).to(outs.dtype)
+    return merged.unsqueeze(0)
 
 
 def _cfg_get(cfg, key, default=None):
@@ -103,8 +123,14 @@ class _WindowFeeder:
     def _copy(self, slot: int, dst_off: int, lo: int, hi: int) -> None:
         dst = self.stage[slot][dst_off:dst_off + hi - lo]
         if self.pageable:
+            # host memcpy into pinned pages, four ranges at a time (copy_ releases the GIL; one thread moves 3-10 GB/s, a window of
+            # fp32 frames is 100 MB), then one DMA
             b = self.bounce[slot][dst_off:dst_off + hi - lo]
-            b.copy_(self.video[lo:hi])                         # host memcpy into pinned pages
+            n = hi - lo
+            cuts = [lo + n * k // 4 for k in range(5)]
+            jobs = [_HOST_POOL.submit(b[a - lo:e - lo].copy_, self.video[a:e]) for a, e in zip(cuts[:-1], cuts[1:]) if e > a]
+            for j in jobs:
+                j.result()
             dst.copy_(b, non_blocking=True)
         else:
             dst.copy_(self.video[lo:hi], non_blocking=True)

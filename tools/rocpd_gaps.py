@@ -2,7 +2,8 @@
 """Idle time between kernels from a rocprofv3 rocpd sqlite database: for the LAST `n` back-to-back repetitions of the
 clip (a repetition starts at every patchify_kernel), after dropping the last `skip` ones (bench.py ends with `--steps`
 eager instrumented repetitions; the graph replays come before them), prints span, busy time (union of the kernel
-intervals), the idle remainder and the gap histogram.  Usage: tools/rocpd_gaps.py results.db [n] [skip]"""
+intervals), the idle remainder and the gap histogram.  Usage: tools/rocpd_gaps.py results.db [n] [skip] [marker]
+(marker: the kernel that opens a repetition; default patchify_kernel = a clip; adamw_flat_kernel = a training step)"""
 import sqlite3
 import sys
 
@@ -14,7 +15,8 @@ def main():
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     name = "name" if "name" in cols else "kernel_name"
     rows = con.execute(f"select start, end, {name} from kernels order by start").fetchall()
-    starts = [i for i, r in enumerate(rows) if "patchify_kernel" in r[2]]
+    marker = sys.argv[4] if len(sys.argv) > 4 else "patchify_kernel"
+    starts = [i for i, r in enumerate(rows) if marker in r[2]]
     if len(starts) < n + skip + 1:
         print("not enough repetitions")
         return
