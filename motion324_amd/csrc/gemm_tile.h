@@ -56,41 +56,93 @@ constexpr int TILE_BYTES = BM * ROWB;                   // 16 KiB per operand pe
 
 using m324::Epilogue;
 
-// GELU for bf16 outputs (round 6): Phi(x) as a logistic function, GELU(x) = x / (1 + 2^(x p(t))) with t = min(x x / 64, 1) and
-// p(t) = K0 + K1 t + K2 t^2 minimax-fitted to x Phi(x): |error| <= 2.6e-5 for EVERY x (relative 7.7e-5 for x > 0.02: 25 times
-// below the bf16 rounding of the result), exact limits (0 and x) at both ends, NaN in -> NaN out.  Beyond |x| = 8 the argument
-// continues linearly (p(1) = -log2(e) * 3.45: the logistic has long saturated).  7 plain VALU + 2 transcendental instructions
-// per value in place of the 12 plain ones of rounds 2-5's erf polynomial (|error| 6e-5): in schedule v15 the epilogue sits between
-// a wave's own MFMAs, where plain VALU instructions beyond ~5 per MFMA cost their issue time and transcendentals next to nothing
-// (tools/issue_lab, profiles/r04_issue_lab.md: MFMA + 2 v_exp_f32 = 32.8 cycles against 32.0).  The fp32 parity path keeps erff.
-// ONE arithmetic for every schedule (gen_gemm_hp.py emits the same nine instructions): the product does not depend on which
-// schedule the chooser -- or a graph branch with half the rows -- picks (tests/test_kernels_gpu.py test_gemm_v15_*).
-#define M324_GELU_S2 0.015625f
-#define M324_GELU_K0 -2.301121234893799f
-#define M324_GELU_K1 -6.833646297454834f
-#define M324_GELU_K2 4.154421329498291f
-__device__ __forceinline__ float gelu_sig(float x) {
-    float t = x * x;
-    t = fminf(fmaxf(t * M324_GELU_S2, 0.0f), 1.0f);               // v_mul_f32 ... clamp
-    float p = fmaf(t, M324_GELU_K2, M324_GELU_K1);
-    p = fmaf(p, t, M324_GELU_K0);
-    const float e = __builtin_amdgcn_exp2f(x * p);                 // v_exp_f32: 2^(-log2(e) x (k0 + k1 t + k2 t^2))
-    return x * __builtin_amdgcn_rcpf(e + 1.0f);                    // v_rcp_f32
+// GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
+// bf16 rounding of the result); the fp32 parity path keeps erff.  ~12 VALU + 2 transcendental ops
+// instead of ocml's branchy erff -- the fc1 epilogue (128x128 GELUs per workgroup) is otherwise as
+// long as its whole K = 768 main loop.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 1 - erf(z), z >= 0
+    const float phi = x >= 0.f ? 1.0f - 0.5f * erfc_z : 0.5f * erfc_z;                       // Phi(x)
+    return x * phi;
 }
-__device__ __forceinline__ float gelu_fast(float x) { return gelu_sig(x); }
+
+// Two GELUs per instruction stream for the bf16 epilogue: GELU(x) = x (1/2 + u Q(u^2)), u = clamp(x, +-3 sqrt 2), with
+// u Q(u^2) = erf(u / sqrt 2) / 2 as an odd minimax polynomial (9 coefficients, |erf error| <= 1.7e-5; beyond the clamp
+// erf(3) = 0.99998 stands in for 1), evaluated with packed fp32 FMAs (v_pk_fma_f32) and no transcendental: 13 VALU
+// instructions per pair.  |GELU error| <= 6e-5 absolute -- below the bf16 rounding step of every output larger than 0.02.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+#define M324_GELU_Q8 5.626603458e-11f
+#define M324_GELU_Q7 -5.371752709e-09f
+#define M324_GELU_Q6 2.268262506e-07f
+#define M324_GELU_Q5 -5.646163474e-06f
+#define M324_GELU_Q4 9.359017959e-05f
+#define M324_GELU_Q3 -1.109398132e-03f
+#define M324_GELU_Q2 9.818113584e-03f
+#define M324_GELU_Q1 -6.634691738e-02f
+#define M324_GELU_Q0 3.989031257e-01f
+#define M324_GELU_CLAMP 4.2426405f
+// N independent pairs, one Horner step of every pair before the next step of any: a dependent v_pk_fma_f32 needs a wait
+// state, and the compiler otherwise emits the pairs one after another with an s_nop between all 11 dependent steps.
+template <int N>
+__device__ __forceinline__ void gelu_poly2n(f32x2v (&x)[N]) {
+    f32x2v u[N], t[N], p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        u[i].x = __builtin_amdgcn_fmed3f(x[i].x, -M324_GELU_CLAMP, M324_GELU_CLAMP);
+        u[i].y = __builtin_amdgcn_fmed3f(x[i].y, -M324_GELU_CLAMP, M324_GELU_CLAMP);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = u[i] * u[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = __builtin_elementwise_fma((f32x2v)(M324_GELU_Q8), t[i], (f32x2v)(M324_GELU_Q7));
+#define M324_GELU_STEP(C)          \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], (f32x2v)(C));
+    M324_GELU_STEP(M324_GELU_Q6)
+    M324_GELU_STEP(M324_GELU_Q5)
+    M324_GELU_STEP(M324_GELU_Q4)
+    M324_GELU_STEP(M324_GELU_Q3)
+    M324_GELU_STEP(M324_GELU_Q2)
+    M324_GELU_STEP(M324_GELU_Q1)
+    M324_GELU_STEP(M324_GELU_Q0)
+#undef M324_GELU_STEP
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = __builtin_elementwise_fma(u[i], p[i], (f32x2v)(0.5f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] * p[i];
+}
+__device__ __forceinline__ f32x2v gelu_poly2(f32x2v x) {
+    f32x2v v[1] = {x};
+    gelu_poly2n<1>(v);
+    return v[0];
+}
 
 template <typename TOUT>
 __device__ __forceinline__ void apply_gelu4(float4& v) {
     if constexpr (sizeof(TOUT) == 2) {
-        v = make_float4(gelu_sig(v.x), gelu_sig(v.y), gelu_sig(v.z), gelu_sig(v.w));
+        f32x2v a[2] = {{v.x, v.y}, {v.z, v.w}};
+        gelu_poly2n<2>(a);
+        v = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
     } else {
         v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
     }
 }
 template <typename TOUT>
 __device__ __forceinline__ void apply_gelu8(float4& v, float4& w) {
-    apply_gelu4<TOUT>(v);
-    apply_gelu4<TOUT>(w);
+    if constexpr (sizeof(TOUT) == 2) {
+        f32x2v a[4] = {{v.x, v.y}, {v.z, v.w}, {w.x, w.y}, {w.z, w.w}};
+        gelu_poly2n<4>(a);
+        v = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+        w = make_float4(a[2].x, a[2].y, a[3].x, a[3].y);
+    } else {
+        apply_gelu4<TOUT>(v);
+        apply_gelu4<TOUT>(w);
+    }
 }
 
 // d gelu(z) / dz = Phi(z) + z phi(z).  fp32 outputs: erff / expf; bf16 outputs: the polynomial erf above and exp2.

@@ -15,8 +15,8 @@ Structure: ONE persistent 4-wave workgroup per CU (one wave per SIMD, 512 regist
     ONE barrier per stage; fragments are read two k-steps (16 MFMAs) ahead of their MFMAs into three register sets, so the first
     16 MFMAs behind a barrier are the previous stage's last two k-steps.
   * two accumulator sets in AGPRs (a0-127 / a128-255) that swap roles every tile (the tile body is emitted twice): while set X
-    accumulates tile t, the epilogue of tile t - 1 reads set Y: v_accvgpr_read, LayerNorm fold / bias, the logistic-form GELU of
-    gemm_tile.h (gelu_sig: 7 plain + 2 transcendental instructions per value), bf16 pack, v_permlane32_swap (16 contiguous bytes of one row per lane).  The arithmetic is PLAIN fp32 VALU: packed
+    accumulates tile t, the epilogue of tile t - 1 reads set Y: v_accvgpr_read, LayerNorm fold / bias, the 9-term erf polynomial of
+    gemm_tile.h, bf16 pack, v_permlane32_swap (16 contiguous bytes of one row per lane).  The arithmetic is PLAIN fp32 VALU: packed
     fp32 (v_pk_fma_f32 ...) does not issue in the MFMAs' shadow (measured: 832 packed instructions per tile cost 4.2 cycles each,
     1856 plain ones in their place 2.6); only the exposed tail behind a workgroup's last tile uses the packed forms.
   * stores: a row block (32 rows x 64 columns of the wave) leaves through the wave's 16-row x 128-byte LDS scratch in two halves
@@ -41,7 +41,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gen_attn_pwg import I, v, a, regs, salu, nop, trans  # noqa: E402  (instruction records, register names)
+from gen_attn_pwg import I, v, a, regs, salu, nop  # noqa: E402  (instruction records, register names)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -71,29 +71,27 @@ WF = [[alloc(4) for _ in range(2)] for _ in range(3)]        # weight-row fragme
 BIAS = alloc(32)             # bias[j * 16 + r]: column wn*64 + j*32 + 8 (r >> 2) + 4 hi + (r & 3)
 CS = alloc(32)               # colsum, same indexing
 RS = alloc(8)                # (rstd, -rstd mean) of the lane's row of row block i: RS + 2 i
-EX, ET, EQ = alloc(8), alloc(8), alloc(8)      # x (bias / fold applied), t = sat(x x / 64), the chain p -> z -> 2^z -> 1 + 2^z -> its reciprocal
+EX, EU, ET, EQ = alloc(8), alloc(8), alloc(8), alloc(8)
 P = [alloc(8), alloc(8)]     # packed bf16 of a block (two sets, alternating blocks)
 FA = [alloc(4), alloc(4)]    # X fragment address per k-step: [0] buffers 0 / 1 (immediate 0 / STAGE), [1] buffer 2
 FW = [alloc(4), alloc(4)]    # W fragment address
 DX, DW = alloc(8), alloc(4)  # LDS-DMA lane offsets of the wave's 8 X pieces / 4 W pieces
 TT = alloc(8)                # table words on their way to SGPRs; the same registers receive the bounced rows (RB) -- never at the same time
 RB = TT
-VTAB, K1V = alloc(1), alloc(1)                 # K1V: the GELU constant that rides in a VGPR (one scalar operand per VALU instruction)
+VTAB, CLAMPV, Q7V = alloc(1), alloc(1), alloc(1)
 WA = alloc(4)                # bounce: the lane's scratch write address for chunk pair k = 2 j + half
 CV = WA                      # (lab: direct stores, OPT bounce off) store offset of the lane's row in row block i (+ 16 hi)
 RDA, SVO = alloc(1), alloc(1)  # bounce: scratch read address (row L >> 3, chunk L & 7), store offset of that row / chunk
 V_END = _next_v
 
 RA, RW, RC, RR = 40, 44, 48, 52          # buffer resources: X / W of the tile being fetched, C / rowstat of the epilogue's tile
-GQ = 56                                  # s56-59: GELU constants S2, K0, K1, K2 (gemm_tile.h gelu_sig)
+GQ = 56                                  # s56-65: (Q8,Q7) (Q6,Q5) (Q4,Q3) (Q2,Q1) (Q0,-clamp)
 SK, ST, NOFF, SROW = 66, 67, 68, 69       # K offset of the stage to fetch, tiles left, byte offset of the tile's columns in bias / colsum, store row offset
 STMP = 70                                # s70-81 scratch / trace
 EXLO, EXHI = 84, 86                      # exec masks: rows 0-15 / 16-31 of a 32-row block (lanes 0-15 + 32-47 / 16-31 + 48-63)
-# GELU(x) = x / (1 + 2^(x p(t))), t = min(x x / 64, 1), p(t) = K0 + K1 t + K2 t^2: Phi(x) as a logistic function of an odd cubic-in-t
-# argument, minimax-fitted to x Phi(x) (|error| <= 2.6e-5 for every x; the clamp makes the argument linear beyond |x| = 8, where the
-# logistic has long saturated).  The constants carry the factor -log2(e).  The SAME arithmetic, instruction for instruction, as
-# gemm_tile.h gelu_sig (the compiled schedules): results are bit-identical across schedules.
-GELU_S2, GELU_K0, GELU_K1, GELU_K2 = 0.015625, -2.301121234893799, -6.833646297454834, 4.154421329498291
+GELU_Q = [3.989031257e-01, -6.634691738e-02, 9.818113584e-03, -1.109398132e-03, 9.359017959e-05, -5.646163474e-06, 2.268262506e-07,
+          -5.371752709e-09, 5.626603458e-11]
+GELU_CLAMP = 4.2426405
 
 
 def ACC(s, i, j, r=0):
@@ -262,26 +260,19 @@ def epi_block(s, i, j, pset, store=True):
             for p in range(4):
                 out += arith("add", EX + 2 * p, ("v", EX + 2 * p), ("v", b0 + 2 * p))
         if OPT["gelu"]:
-            # 7 plain + 2 transcendental instructions per value (the erf polynomial of rounds 2-5: 12 plain): transcendentals run
-            # beside the MFMAs almost for free (tools/issue_lab: MFMA + 2 v_exp_f32 = 32.8 cycles against 32.0), plain VALU does not
             for k in range(8):
-                out.append(valu(f"v_mul_f32_e32 {v(ET + k)}, {v(EX + k)}, {v(EX + k)}", rd=[f"v{EX + k}"], wr=[f"v{ET + k}"]))
-            for k in range(8):
-                out.append(valu(f"v_mul_f32_e64 {v(ET + k)}, {sreg(GQ)}, {v(ET + k)} clamp", rd=[f"v{ET + k}"], wr=[f"v{ET + k}"]))
-            for k in range(8):
-                out.append(valu(f"v_fma_f32 {v(EQ + k)}, {v(ET + k)}, {sreg(GQ + 3)}, {v(K1V)}", rd=[f"v{ET + k}", f"v{K1V}"], wr=[f"v{EQ + k}"]))
-            for k in range(8):
-                out.append(valu(f"v_fma_f32 {v(EQ + k)}, {v(EQ + k)}, {v(ET + k)}, {sreg(GQ + 1)}", rd=[f"v{EQ + k}", f"v{ET + k}"], wr=[f"v{EQ + k}"]))
-            for k in range(8):
-                out.append(valu(f"v_mul_f32_e32 {v(EQ + k)}, {v(EX + k)}, {v(EQ + k)}", rd=[f"v{EX + k}", f"v{EQ + k}"], wr=[f"v{EQ + k}"]))
-            for k in range(8):
-                out.append(trans(f"v_exp_f32_e32 {v(EQ + k)}, {v(EQ + k)}", [f"v{EQ + k}"], [f"v{EQ + k}"]))
-            for k in range(8):
-                out.append(valu(f"v_add_f32_e32 {v(EQ + k)}, 1.0, {v(EQ + k)}", rd=[f"v{EQ + k}"], wr=[f"v{EQ + k}"]))
-            for k in range(8):
-                out.append(trans(f"v_rcp_f32_e32 {v(EQ + k)}, {v(EQ + k)}", [f"v{EQ + k}"], [f"v{EQ + k}"]))
-            for k in range(8):
-                out.append(valu(f"v_mul_f32_e32 {v(EX + k)}, {v(EX + k)}, {v(EQ + k)}", rd=[f"v{EX + k}", f"v{EQ + k}"], wr=[f"v{EX + k}"]))
+                out.append(valu(f"v_med3_f32 {v(EU + k)}, {v(EX + k)}, {sreg(GQ + 9)}, {v(CLAMPV)}", rd=[f"v{EX + k}", f"v{CLAMPV}"], wr=[f"v{EU + k}"]))
+            for p in range(4):
+                out += arith("mul", ET + 2 * p, ("v", EU + 2 * p), ("v", EU + 2 * p))
+            for p in range(4):         # q = Q8 t + Q7 (one scalar operand per instruction: Q7 comes from a VGPR)
+                out += arith("fma", EQ + 2 * p, ("v", ET + 2 * p), ("s", GQ), ("vb", Q7V) if OPT["scalar"] else ("s", GQ + 1))
+            for step in range(6, -1, -1):      # q = q t + Q_step
+                for p in range(4):
+                    out += arith("fma", EQ + 2 * p, ("v", EQ + 2 * p), ("v", ET + 2 * p), ("s", GQ + 8 - step))
+            for p in range(4):         # q = u q + 1/2
+                out += arith("fma", EQ + 2 * p, ("v", EU + 2 * p), ("v", EQ + 2 * p), ("c", "0.5"))
+            for p in range(4):
+                out += arith("mul", EX + 2 * p, ("v", EX + 2 * p), ("v", EQ + 2 * p))
         for p in range(4):
             d = P[pset] + 4 * h + p
             out.append(valu(f"v_cvt_pk_bf16_f32 {v(d)}, {v(EX + 2 * p)}, {v(EX + 2 * p + 1)}", rd=[f"v{EX + 2 * p}", f"v{EX + 2 * p + 1}"], wr=[f"v{d}"]))
@@ -344,7 +335,7 @@ def weave(main, parts, first=8, gap=40):
 
 
 # ------------------------------------------------------------------------------------------------ placement
-COST = {"valu": 1.0, "perm": 1.0, "trans": 1.3, "ds": 1.0, "vmem": 1.0, "salu": 0.7, "nop": 0.3, "wait": 0.3, "barrier": 0.3}
+COST = {"valu": 1.0, "perm": 1.0, "trans": 2.0, "ds": 1.0, "vmem": 1.0, "salu": 0.7, "nop": 0.3, "wait": 0.3, "barrier": 0.3}
 
 
 def spread(items, lo, hi):
@@ -473,9 +464,11 @@ def tail(sx, label):
 def prologue():
     L = [nop(5)]
     # GELU constants
-    for k, c in enumerate((GELU_S2, GELU_K0, GELU_K1, GELU_K2)):
+    qs = [GELU_Q[8], GELU_Q[7], GELU_Q[6], GELU_Q[5], GELU_Q[4], GELU_Q[3], GELU_Q[2], GELU_Q[1], GELU_Q[0], -GELU_CLAMP]
+    for k, c in enumerate(qs):
         L.append(salu(f"s_mov_b32 {sreg(GQ + k)}, 0x{f32_bits(c):08x}"))
-    L.append(valu(f"v_mov_b32_e32 {v(K1V)}, 0x{f32_bits(GELU_K1):08x}", wr=[f"v{K1V}"]))
+    L.append(valu(f"v_mov_b32_e32 {v(CLAMPV)}, 0x{f32_bits(GELU_CLAMP):08x}", wr=[f"v{CLAMPV}"]))
+    L.append(valu(f"v_mov_b32_e32 {v(Q7V)}, 0x{f32_bits(GELU_Q[7]):08x}", wr=[f"v{Q7V}"]))
     L += [salu(f"s_mov_b32 {sreg(EXLO)}, 0x0000ffff"), salu(f"s_mov_b32 {sreg(EXLO + 1)}, 0x0000ffff"),
           salu(f"s_mov_b32 {sreg(EXHI)}, 0xffff0000"), salu(f"s_mov_b32 {sreg(EXHI + 1)}, 0xffff0000")]
     for k in range(4):
@@ -565,16 +558,13 @@ def resolve_waits(seq, what):
 
 def check(seq, what):
     """hazard distances the assembler does not insert inside an asm statement (wait states: every instruction 1, s_nop N = N + 1)"""
-    last_mfma_wr, last_valu_wr, last_sgpr_wr, last_perm_wr, last_trans_wr = {}, {}, {}, {}, {}
+    last_mfma_wr, last_valu_wr, last_sgpr_wr, last_perm_wr = {}, {}, {}, {}
     pos = 0
     for ins in seq:
-        if ins.kind in ("valu", "perm", "trans"):
+        if ins.kind in ("valu", "perm"):
             for r in ins.rd | ins.wr:
                 if r in last_mfma_wr and pos - last_mfma_wr[r] < 13:
                     raise SystemExit(f"{what}: MFMA result {r} touched by VALU after {pos - last_mfma_wr[r]} states: {ins.text}")
-            for r in ins.rd:
-                if r in last_trans_wr and pos - last_trans_wr[r] < 2:
-                    raise SystemExit(f"{what}: transcendental result {r} consumed after {pos - last_trans_wr[r]} state: {ins.text}")
         if ins.kind == "perm":
             for r in ins.rd:
                 if r in last_valu_wr and pos - last_valu_wr[r] < 2:
@@ -596,17 +586,13 @@ def check(seq, what):
         if ins.kind == "mfma":
             for r in ins.wr:
                 last_mfma_wr[r] = pos
-        if ins.kind in ("valu", "perm", "trans"):
+        if ins.kind in ("valu", "perm"):
             for r in ins.wr:
                 if r.startswith("s"):
                     last_sgpr_wr[r] = pos
                 else:
                     last_valu_wr[r] = pos
                     last_mfma_wr.pop(r, None)
-                    if ins.kind == "trans":
-                        last_trans_wr[r] = pos
-                    else:
-                        last_trans_wr.pop(r, None)
                     if ins.kind == "perm":
                         last_perm_wr[r] = pos
                     else:
@@ -666,7 +652,7 @@ def check_eloads(seq, what):
         if ins.kind == "vmem" and getattr(ins, "tag", None) == ("eload",):
             for r in ins.wr:
                 first_load.setdefault(r, pos)
-        elif ins.kind in ("valu", "perm", "trans"):
+        elif ins.kind in ("valu", "perm"):
             for r in ins.rd & watched:
                 last_read[r] = pos
     for r, p in first_load.items():

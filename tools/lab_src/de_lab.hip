@@ -324,19 +324,6 @@ __global__ __launch_bounds__(256) void gemm_de_kernel(const bf16_t* __restrict__
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-// rounds 2-5's erf polynomial (the product moved to the logistic form of gemm_tile.h gelu_sig in round 6); this lab keeps what it measured
-#ifndef M324_GELU_Q8
-#define M324_GELU_Q8 5.626603458e-11f
-#define M324_GELU_Q7 -5.371752709e-09f
-#define M324_GELU_Q6 2.268262506e-07f
-#define M324_GELU_Q5 -5.646163474e-06f
-#define M324_GELU_Q4 9.359017959e-05f
-#define M324_GELU_Q3 -1.109398132e-03f
-#define M324_GELU_Q2 9.818113584e-03f
-#define M324_GELU_Q1 -6.634691738e-02f
-#define M324_GELU_Q0 3.989031257e-01f
-#define M324_GELU_CLAMP 4.2426405f
-#endif
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
 void m324_set_error(const char*, ...) {}
 int m324::tunable(int) { return 0; }
