@@ -72,6 +72,23 @@ def _gemm_plan(args) -> str:
     return buf.value.decode()
 
 
+def gemm_schedule(M: int, N: int, K: int, *, act: int = L.ACT_NONE, out_dtype: torch.dtype = torch.bfloat16, bias: bool = True,
+                  fold_merged: bool = False) -> int:
+    """The schedule m324_gemm WOULD pick for a bf16 GEMM of this shape and epilogue with the library's live tunables (host-only
+    query, m324_gemm_plan: no launch, no device memory touched).  fold_merged: a LayerNorm-fold consumer handed the MERGED
+    statistics table.  The host never mirrors the chooser's rules: it asks."""
+    args = L.GemmArgs()
+    args.A = args.W = args.C = 4096                       # aligned stand-ins: the plan query reads sizes and flags only
+    args.M, args.N, args.K, args.lda, args.ldw, args.ldc = M, N, K, K, K, N
+    args.in_dtype, args.out_dtype, args.act, args.batch = BF16, code_of(out_dtype), act, 1
+    if bias:
+        args.bias = 4096
+    if fold_merged:
+        args.ln_rowstat, args.ln_colsum, args.ln_ncb, args.ln_eps = 4096, 4096, 0, 1e-5
+    buf = C.create_string_buffer(192)
+    return int(L.load().m324_gemm_plan(C.byref(args), buf, 192))
+
+
 def _attn_plan(B, H, Lq, Lk, flags, dtype_code) -> str:
     buf = C.create_string_buffer(192)
     L.load().m324_attention_plan(B, H, Lq, Lk, flags, dtype_code, buf, 192)

@@ -132,7 +132,6 @@ FOLD_LN = int(switches.get("M324_FOLD_LN"))
 PAIR_PROJ = switches.flag("M324_PAIR_PROJ")         # the decoder's q and k|v LayerNorms / projections as two launches instead of four
 FOLD_MERGE = switches.flag("M324_FOLD_MERGE")      # folded consumers merge the producer's per-block statistics themselves
 ATTN_BOUNDED = switches.flag("M324_ATTN_BOUNDED")
-HP = int(switches.get("M324_HP"))                  # schedule v15 of m324_gemm (K = 768, GELU): takes the MERGED statistics table
 
 
 class LNFold:
@@ -183,13 +182,13 @@ class LNFold:
 
 
 def hp_consumer(rows: int, n_out: int, k: int) -> bool:
-    """m324_gemm's rule for a GELU epilogue on schedule v15 (csrc/gemm.hip pick_variant): K = 768, N % 128 == 0, at least 512 tiles of
-    256 x 128 with M324_HP bit 0, 4096 with bit 2 (the default).  The host mirrors it only to hand such a consumer the merged
-    statistics table."""
-    if k != 768 or n_out % 128 != 0:
+    """Will m324_gemm run this fc1 + GELU LayerNorm-fold consumer on schedule v15 when it gets the MERGED statistics table?  (v15
+    reads the merged table only; the other schedules merge the producer's block table themselves, which saves the
+    m324_rowstats_finish launch.)  Asked of the library (ops.gemm_schedule -> m324_gemm_plan, live tunables included), so that
+    `lib.set_tunable("M324_HP", ...)` / a forced M324_GEMM and this decision cannot drift apart."""
+    if k != 768 or n_out % 128 != 0 or rows < 1:
         return False
-    tiles = (n_out // 128) * ((rows + 255) // 256)
-    return ((HP & 1) != 0 and tiles >= 512) or ((HP & 4) != 0 and tiles >= 4096)
+    return ops.gemm_schedule(rows, n_out, k, act=ACT_GELU, fold_merged=True) == 15
 
 
 def _mlp_residual(P: Prepared, norm2: nn.LayerNorm, mlp: MLP, x: torch.Tensor, fold: Optional[LNFold] = None,
