@@ -4,7 +4,9 @@ imports /root/reference through make_golden.py's shims).  The reference runs its
 (train.py:150-155, scripts/inference_with_video_mesh.py:207-211); here the same module runs on CPU once in fp32 and once under
 torch.autocast("cpu", bfloat16) on the c1 inputs, with the synthetic weights and with the trained-like ones.  Output:
 tests/golden/trained_like_band.json = {"synthetic": rel err, "trained_like": rel err, ...} -- the band the HIP path's bf16 mode is
-held against (data, no reference source)."""
+held against (data, no reference source).  Round 6 adds the same pair at the c2 TRUNK LENGTH (10368 tokens through the global
+blocks, shallow depth: "..._c2_trunk") and the gradient band of one training step of the tiny configuration ("train_tiny_*":
+the reference's autocast(bf16) forward + backward against its own fp32 one)."""
 import json, os, sys, time
 
 import numpy as np
@@ -42,23 +44,67 @@ def build(sd_np, dm):
     return model
 
 
+def _forward_band(model, sample):
+    with torch.no_grad():
+        ref = model(dict(sample))["pcd_moved"].float()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            low = model(dict(sample))["pcd_moved"].float()
+    return float((low - ref).norm() / ref.norm())
+
+
+def _grad_band(model, sample):
+    """One training-mode forward + backward of the reference in fp32 and under autocast(bf16) (train.py:150-166): loss and
+    gradients of every trainable tensor; returns (relative loss difference, global gradient error, worst per-tensor error)."""
+    model.train()
+    grads = []
+    losses = []
+    for low in (False, True):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=low):
+            ret = model(dict(sample))
+        loss = ret.loss_metrics.loss
+        loss.backward()
+        losses.append(float(loss))
+        grads.append({n: p.grad.detach().double().clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None})
+    g32, g16 = grads
+    num = sum(float((g16[n] - g32[n]).pow(2).sum()) for n in g32)
+    den = sum(float(g32[n].pow(2).sum()) for n in g32)
+    per = {n: float((g16[n] - g32[n]).norm() / g32[n].norm().clamp_min(1e-30)) for n in g32}
+    worst = max(per.items(), key=lambda kv: kv[1])
+    model.eval()
+    return abs(losses[1] - losses[0]) / abs(losses[0]), (num / den) ** 0.5, worst
+
+
 def main():
-    spec = G.CASES["c1"]
-    dm = synth.Dims(**spec["dims"])
-    B, T, N, S, HW = spec["shape"]
-    sample = oracle.to_torch(synth.synth_inputs(B, T, N, S, HW, seed=1))
+    from test_trained_like_gpu import GUARD_DIMS, GUARD_SHAPE
+    from conftest import CASES as TEST_CASES
+    out = {"autocast": "torch.autocast('cpu', dtype=torch.bfloat16) around the reference's forward (and backward)"}
+    # 1. inference at the c1 size (round 5) and at the c2 trunk length: 32 frames x 324 tokens = 10368 rows through the global
+    #    blocks, shallow depth (the configuration of the scores-bounded guard test) -- round 6
+    for tag, dims, shape, seed in (("", G.CASES["c1"]["dims"], G.CASES["c1"]["shape"], 1), ("_c2_trunk", GUARD_DIMS, GUARD_SHAPE, 7)):
+        dm = synth.Dims(**dims)
+        B, T, N, S, HW = shape
+        sample = oracle.to_torch(synth.synth_inputs(B, T, N, S, HW, seed=seed))
+        base = synth.synth_state_dict(dm, seed=0)
+        for name, sd_np in (("synthetic", base), ("trained_like", trained_like(base))):
+            model = build(sd_np, dm)
+            t0 = time.time()
+            err = _forward_band(model, sample)
+            print(f"[{name}{tag}] reference autocast(bf16) vs its own fp32: rel err {err:.3e}  ({time.time() - t0:.1f} s)", flush=True)
+            out[name + tag] = err
+    out["case"], out["shape"] = "c1", list(G.CASES["c1"]["shape"])
+    out["case_c2_trunk"], out["shape_c2_trunk"] = dict(GUARD_DIMS), list(GUARD_SHAPE)
+    # 2. one training step (forward + backward) of the tiny configuration: the gradient band of the reference's own autocast
+    dims, (B, T, N, S, HW) = TEST_CASES["tiny"]["dims"], TEST_CASES["tiny"]["shape"]
+    dm = synth.Dims(**dims)
+    sample = oracle.to_torch(synth.synth_inputs(B, T, N, S, HW, seed=1, with_target=True))
     base = synth.synth_state_dict(dm, seed=0)
-    out = {"case": "c1", "shape": list(spec["shape"]), "autocast": "torch.autocast('cpu', dtype=torch.bfloat16) around the reference's forward"}
     for name, sd_np in (("synthetic", base), ("trained_like", trained_like(base))):
         model = build(sd_np, dm)
-        t0 = time.time()
-        with torch.no_grad():
-            ref = model(dict(sample))["pcd_moved"].float()
-            with torch.autocast("cpu", dtype=torch.bfloat16):
-                low = model(dict(sample))["pcd_moved"].float()
-        err = float((low - ref).norm() / ref.norm())
-        print(f"[{name}] reference autocast(bf16) vs its own fp32: rel err {err:.3e}  ({time.time() - t0:.1f} s)", flush=True)
-        out[name] = err
+        dl, gerr, worst = _grad_band(model, sample)
+        print(f"[train tiny, {name}] reference autocast(bf16) vs its own fp32: loss {dl:.3e}, all gradients {gerr:.3e}, worst tensor {worst[0]} {worst[1]:.3e}",
+              flush=True)
+        out["train_tiny_" + name] = {"loss": dl, "grad": gerr, "worst_tensor": worst[0], "worst": worst[1]}
     json.dump(out, open(os.path.join(HERE, "trained_like_band.json"), "w"), indent=1)
 
 
