@@ -281,6 +281,7 @@ def test_bf16_training_step_gradient_band_against_oracle_autograd(weights):
     assert res["bf16"][1] < TRAIN_STEP_BF16_TOL[weights]
 
 
-# gates = band measured on MI355X (round 6, profiles/r06_parity_trained_like.md) + 25 %
-TRAINED_LIKE_C2_TRUNK_BF16_TOL = 1.0
-TRAIN_STEP_BF16_TOL = {"synthetic": 1.0, "trained_like": 1.0}
+# gates = band measured on MI355X (round 6, profiles/r06_parity_trained_like.md: c2 trunk length 8.56e-3; one training step, all
+# gradients: synthetic 3.64e-3, trained-like 1.10e-2) + 25 %
+TRAINED_LIKE_C2_TRUNK_BF16_TOL = 1.1e-2
+TRAIN_STEP_BF16_TOL = {"synthetic": 4.6e-3, "trained_like": 1.4e-2}

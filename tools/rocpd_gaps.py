@@ -40,6 +40,22 @@ def main():
         b = "<1us" if g < 1000 else "1-2us" if g < 2000 else "2-4us" if g < 4000 else "4-8us" if g < 8000 else ">=8us"
         hist[b] = hist.get(b, 0) + 1
     print("gap histogram per clip:", {k: round(v / n, 1) for k, v in hist.items()})
+    # where the idle time sits: the repetition cut into 40 equal time slices, idle microseconds per slice
+    t0, per = seg[0][0], span / 40.0
+    slices = [0.0] * 40
+    cur_e = seg[0][1]
+    for s_, e_, _k in seg[1:]:
+        if s_ > cur_e:
+            slices[min(39, int((cur_e - t0) / per))] += (s_ - cur_e) / 1e3 / n
+        cur_e = max(cur_e, e_)
+    print("idle us per 1/40 of the repetition(s):", " ".join(f"{x:.0f}" for x in slices))
+    byk = {}
+    for g, k in gaps:
+        kk = k.split("(")[0][-60:]
+        byk[kk] = byk.get(kk, 0.0) + g / 1e3 / n
+    print("idle us per repetition by the kernel that follows the gap:")
+    for kk, v in sorted(byk.items(), key=lambda t: -t[1])[:14]:
+        print(f"  {v:8.1f}  {kk}")
     big = sorted(gaps, key=lambda t: -t[0])[:12]
     print("largest gaps (us, kernel that follows):")
     for g, k in big:
