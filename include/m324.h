@@ -324,6 +324,21 @@ int m324_transpose(const void* in, long ld_in, void* out, long ld_out, int rows,
 int m324_colsum(const void* x, long ld, float* out, int rows, int cols, int dtype, int accumulate,
                 float* scratch, int scratch_rows, void* stream);
 /*   scratch (optional, scratch_rows x cols floats): lets tall inputs be reduced by row chunks in parallel. */
+/* Many fp32 column sums in ONE launch (ABI 20): the split-K partials of the weight gradients, the per-workgroup partials of
+ * the LayerNorm / RMSNorm weight gradients -- ~350 m324_colsum launches of a training step (train.py:166) become ~40.
+ *   items[i]: dst[c] (+)= sum over rows of src[r * ld + c], c < cols.  chain = 1: the item CONTINUES item i - 1 (same dst, same
+ *   cols): its sum is added to the running value by the same thread right behind it -- exactly what consecutive m324_colsum
+ *   calls with accumulate = 1 compute, in the same order (deterministic; bit-identical to them for rows <= 64).
+ *   Up to 64 items per launch (the table travels in the kernel arguments; longer lists are cut into several launches). */
+typedef struct {
+    float* dst;
+    const float* src;
+    long ld;
+    int rows, cols;
+    int accumulate;
+    int chain;
+} m324_colsum_item;
+int m324_colsum_multi(const m324_colsum_item* items, int n, void* stream);
 /* h = gelu_erf(z);  dz = dh * gelu'(z)  (nn.GELU, transformer.py:58), elementwise over n values. */
 int m324_gelu(const void* z, void* h, long n, int dtype, void* stream);
 int m324_gelu_bwd(const void* z, const void* dh, void* dz, long n, int dtype, void* stream);

@@ -40,12 +40,28 @@ class GradStore:
         if sink is not None:
             sink.begin_step()
 
-    def add(self, param: Optional[torch.nn.Parameter], g: torch.Tensor) -> None:
+    def add(self, param: Optional[torch.nn.Parameter], g) -> None:
         if param is None or not param.requires_grad:
             return
+        if isinstance(g, ops.Rows):
+            # the gradient is the column sum of g.t (per-workgroup partials): queued straight into the gradient's own memory --
+            # the optimizer's flat buffer, the gradient this parameter already holds, or a new tensor; nobody reads it before
+            # done() / get() flush the queue
+            k = id(param)
+            if k in self.grads and self.grads[k].dtype == torch.float32 and self.grads[k].is_contiguous():
+                ops.COLSUMS.defer(g.t, self.grads[k].view(-1), True)
+                return
+            if k not in self.grads:
+                view = self.sink.grad_of(param) if (self.sink is not None and self.sink.owns(param)) else \
+                    torch.empty(param.shape, dtype=torch.float32, device=g.t.device)
+                ops.COLSUMS.defer(g.t, view.view(-1), False)
+                self.grads[k], self.params[k] = view, param
+                return
+            g = g.reduce()
         g = g.reshape(param.shape)
         k = id(param)
         if k in self.grads:
+            ops.COLSUMS.flush()         # queued sums into this gradient come first
             self.grads[k] += g          # accumulation of a few small tensors (shared weights): torch add on fp32
             return
         if self.sink is not None and self.sink.owns(param):
@@ -76,11 +92,13 @@ class GradStore:
         self.params[id(param)] = param
 
     def get(self, param) -> Optional[torch.Tensor]:
+        ops.COLSUMS.flush()             # a reader: every queued column sum lands first
         return self.grads.get(id(param))
 
     def done(self, params) -> None:
         """No further add() will touch these parameters in this step (parameters that received no gradient get zeros,
         what autograd would deliver)."""
+        ops.COLSUMS.flush()             # the block's queued column sums (weight-gradient partials, norm weights): one launch
         if self.sink is None:
             return
         params = [p for p in params if p is not None and p.requires_grad]
@@ -162,7 +180,7 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
         elif eb is not None:
             ops.colsum(dy, out=eb.view(-1), accumulate=True)
         else:
-            G.add(bias, dy_colsum if dy_colsum is not None else ops.colsum(dy))
+            G.add(bias, dy_colsum if dy_colsum is not None else ops.colsum(dy))     # dy_colsum: a vector or ops.Rows (queued)
     k_true = weight[0].numel()
     tw = G.target(weight) if k_true == a.shape[1] else None
     ex = G.existing(weight) if tw is None and k_true == a.shape[1] else None
@@ -206,9 +224,9 @@ class Carry:
     def ln_bwd(self, P: Prepared, x, w, eps, dy, dx, accumulate=True, row_map=(0, 0, 0)):
         """ops.layernorm_bwd that also fills the carry for dx (bf16 mode); returns (dw, db)."""
         if P.dtype != torch.bfloat16:
-            return ops.layernorm_bwd(x, w, eps, dy, dx, accumulate=accumulate, row_map=row_map)
+            return ops.layernorm_bwd(x, w, eps, dy, dx, accumulate=accumulate, row_map=row_map, reduce=not ops.DEFER_COLSUM)
         c = torch.empty(dx.shape, dtype=torch.bfloat16, device=dx.device)
-        dw, db, cs = ops.layernorm_bwd(x, w, eps, dy, dx, accumulate=accumulate, row_map=row_map, cast_out=c)
+        dw, db, cs = ops.layernorm_bwd(x, w, eps, dy, dx, accumulate=accumulate, row_map=row_map, cast_out=c, reduce=not ops.DEFER_COLSUM)
         self.dx, self.bf16, self.colsum, self.version = dx, c, cs, dx._version
         return dw, db
 
@@ -292,7 +310,7 @@ def self_attn_block_bwd(blk, P: Prepared, G: GradStore, x_in: torch.Tensor, dx: 
     dQ, dK, dV = _attention_bwd(P, sp, sp, do, lse, D, B, L, H, shared_q=False)
     dqkv = torch.empty((rows, 3 * C), dtype=P.dtype, device=dev)
     dqw, dkw = ops.qkv_split_bwd(dQ, dK, dV, qkv[:, :C], qkv[:, C:2 * C], qw, kw, RMS_EPS, B, L, H, dqkv[:, :C],
-                                 dqkv[:, C:2 * C], dqkv[:, 2 * C:])
+                                 dqkv[:, C:2 * C], dqkv[:, 2 * C:], reduce=not ops.DEFER_COLSUM)
     if a.use_qk_norm:
         G.add(a.q_norm.weight, dqw)
         G.add(a.k_norm.weight, dkw)
@@ -363,7 +381,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
     dQ, dK, dV = _attention_bwd(P, spq, spk, do, lse, D, B, Lq, H, shared_q=shared_q)
     # key / value path
     dkvp = torch.empty((B * Lk, 2 * C), dtype=P.dtype, device=dev)
-    _, dkw = ops.qkv_split_bwd(None, dK, dV, None, kvp[:, :C], None, kw, RMS_EPS, B, Lk, H, None, dkvp[:, :C], dkvp[:, C:])
+    _, dkw = ops.qkv_split_bwd(None, dK, dV, None, kvp[:, :C], None, kw, RMS_EPS, B, Lk, H, None, dkvp[:, :C], dkvp[:, C:], reduce=not ops.DEFER_COLSUM)
     if a.use_qk_norm:
         G.add(a.k_norm.weight, dkw)
     if a.to_k.bias is not None:
@@ -378,7 +396,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
         dkn = torch.empty((B * Lk, C), dtype=P.dtype, device=dev)
         ops.gemm(dkvp, Wt, dkn)
         dw, db = ops.layernorm_bwd(kv, P.vec(blk.norm_kv.weight), blk.norm_kv.eps, dkn, d_kv, accumulate=True,
-                                   row_map=kv_row_map)
+                                   row_map=kv_row_map, reduce=not ops.DEFER_COLSUM)
     else:
         # the weight gradient of norm_kv is still needed even when the kv rows themselves are inputs
         Wt = P.derived("catT", (a.to_k.weight, a.to_v.weight), lambda: ops.transpose(w_kv))
@@ -386,7 +404,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
         ops.gemm(dkvp, Wt, dkn)
         scratch = torch.empty_like(kv)
         dw, db = ops.layernorm_bwd(kv, P.vec(blk.norm_kv.weight), blk.norm_kv.eps, dkn, scratch, accumulate=False,
-                                   row_map=kv_row_map)
+                                   row_map=kv_row_map, reduce=not ops.DEFER_COLSUM)
     G.add(blk.norm_kv.weight, dw)
     G.add(blk.norm_kv.bias, db)
     # query path
@@ -394,7 +412,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
     if shared_q:                                              # one query set: sum the per-batch gradients
         dQs = ops.colsum(dQ.reshape(B, -1)).to(P.dtype).reshape(1, H, Lq, 64)
     dqp = torch.empty((Bq * Lq, C), dtype=P.dtype, device=dev)
-    dqw, _ = ops.qkv_split_bwd(dQs, None, None, qp, None, qw, None, RMS_EPS, Bq, Lq, H, dqp, None, None)
+    dqw, _ = ops.qkv_split_bwd(dQs, None, None, qp, None, qw, None, RMS_EPS, Bq, Lq, H, dqp, None, None, reduce=not ops.DEFER_COLSUM)
     if a.use_qk_norm:
         G.add(a.q_norm.weight, dqw)
     dqn = linear_bwd(P, G, a.to_q.weight, a.to_q.bias, qn, dqp)
@@ -403,7 +421,7 @@ def cross_attn_block_bwd(blk, P: Prepared, G: GradStore, query: torch.Tensor, kv
         dquery = ops.colsum(dx.reshape(B, -1)).reshape(Lq, C).contiguous()
     else:
         dquery = dx
-    dw, db = ops.layernorm_bwd(query, P.vec(blk.norm_q.weight), blk.norm_q.eps, dqn, dquery, accumulate=True)
+    dw, db = ops.layernorm_bwd(query, P.vec(blk.norm_q.weight), blk.norm_q.eps, dqn, dquery, accumulate=True, reduce=not ops.DEFER_COLSUM)
     G.add(blk.norm_q.weight, dw)
     G.add(blk.norm_q.bias, db)
     return dquery if need_dquery else None

@@ -655,6 +655,95 @@ __global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ 
     }
 }
 
+// m324_colsum_multi: one launch for many (destination, chain of fp32 row blocks) pairs.  The table travels in the kernel arguments.
+// A destination's workgroups: "wide" (every source of its chain has <= 64 rows: the split-K partials of a weight gradient) -- a thread
+// owns four neighbouring columns and walks the rows, then the chain, in order (colsum_wide_kernel's arithmetic); "tall" (the
+// per-workgroup partials of a LayerNorm backward: few columns, hundreds of rows) -- 64 columns per workgroup, wave w takes rows w,
+// w + 4, ..., the four partial sums are added in wave order (colsum_kernel's arithmetic).
+constexpr int CSM_MAX = 64;
+struct CsmTable {
+    m324_colsum_item it[CSM_MAX];
+    int blk0[CSM_MAX + 1];          // first workgroup of item i's destination (heads only; a chained item repeats its head's)
+    int n;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const CsmTable t) {
+    __shared__ float red[4][64];
+    const int bid = blockIdx.x;
+    int lo = 0, hi = t.n;                                    // the head whose workgroup range holds bid: blk0[lo] <= bid < blk0 of the next head
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.blk0[mid] <= bid) lo = mid; else hi = mid;
+    }
+    while (lo > 0 && t.it[lo].chain) --lo;                   // a chained item shares its head's range
+    const int head = lo;
+    int last = head;
+    bool tall = t.it[head].rows > 64, vec = true;
+    while (last + 1 < t.n && t.it[last + 1].chain) ++last;
+    for (int i = head; i <= last; ++i) {
+        tall = tall || t.it[i].rows > 64;
+        vec = vec && (t.it[i].ld & 3) == 0 && (((unsigned long)t.it[i].src) & 15) == 0;
+    }
+    const m324_colsum_item h0 = t.it[head];
+    vec = vec && (h0.cols & 3) == 0 && (((unsigned long)h0.dst) & 15) == 0;
+    const int local = bid - t.blk0[head];
+    if (tall) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = local * 64 + lane;
+        float val = 0.f;
+        for (int i = head; i <= last; ++i) {
+            const m324_colsum_item it = t.it[i];
+            float s = 0.f;
+            if (c < it.cols)
+                for (int r = w; r < it.rows; r += 4) s += it.src[(long)r * it.ld + c];
+            __syncthreads();
+            red[w][lane] = s;
+            __syncthreads();
+            if (w == 0 && c < it.cols) {
+                const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+                val = i == head ? (it.accumulate ? it.dst[c] + v : v) : val + v;
+            }
+        }
+        if (w == 0 && c < h0.cols) h0.dst[c] = val;
+        return;
+    }
+    if (vec) {
+        const long c = ((long)local * 256 + threadIdx.x) * 4;
+        if (c >= h0.cols) return;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = head; i <= last; ++i) {
+            const m324_colsum_item it = t.it[i];
+            const float* p = it.src + c;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int r = 0; r < it.rows; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(p + (long)r * it.ld);
+                s.x += x.x, s.y += x.y, s.z += x.z, s.w += x.w;
+            }
+            if (i == head) {
+                if (it.accumulate) {
+                    const float4 d = *reinterpret_cast<const float4*>(it.dst + c);
+                    val = make_float4(d.x + s.x, d.y + s.y, d.z + s.z, d.w + s.w);
+                } else {
+                    val = s;
+                }
+            } else {
+                val.x += s.x, val.y += s.y, val.z += s.z, val.w += s.w;
+            }
+        }
+        *reinterpret_cast<float4*>(h0.dst + c) = val;
+        return;
+    }
+    const long c = (long)local * 256 + threadIdx.x;          // unaligned operands: one column per thread
+    if (c >= h0.cols) return;
+    float val = 0.f;
+    for (int i = head; i <= last; ++i) {
+        const m324_colsum_item it = t.it[i];
+        float s = 0.f;
+        for (int r = 0; r < it.rows; ++r) s += it.src[(long)r * it.ld + c];
+        val = i == head ? (it.accumulate ? it.dst[c] + s : s) : val + s;
+    }
+    h0.dst[c] = val;
+}
+
 // GELU forward on a stored pre-activation and its backward: dz = dh * (Phi(z) + z * phi(z)).
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ z, T* __restrict__ h, long n) {
@@ -1134,6 +1223,54 @@ extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int col
                                           cols, accumulate));
     }
     M324_CHECK_LAUNCH("m324_colsum");
+    return M324_OK;
+}
+
+extern "C" int m324_colsum_multi(const m324_colsum_item* items, int n, void* stream) {
+    M324_REQUIRE(items && n > 0, "m324_colsum_multi: no items");
+    M324_REQUIRE(!items[0].chain, "m324_colsum_multi: the first item cannot continue a chain");
+    for (int i = 0; i < n; ++i) {
+        const m324_colsum_item& it = items[i];
+        M324_REQUIRE(it.dst && it.src && it.rows > 0 && it.cols > 0 && it.ld >= it.cols, "m324_colsum_multi: item %d: bad arguments", i);
+        M324_REQUIRE(!it.chain || (it.dst == items[i - 1].dst && it.cols == items[i - 1].cols), "m324_colsum_multi: item %d continues another destination", i);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int i0 = 0;
+    while (i0 < n) {
+        // as many whole chains as fit the table; a chain longer than the table is cut: its continuation accumulates into the destination
+        CsmTable t;
+        int cnt = 0, blocks = 0, i = i0;
+        bool cut = false;
+        while (i < n && cnt < CSM_MAX) {
+            int j = i + 1;
+            while (j < n && items[j].chain) ++j;                       // chain [i, j)
+            if (cnt + (j - i) > CSM_MAX) {
+                if (cnt > 0) break;                                    // next launch starts with this chain
+                j = i + CSM_MAX, cut = true;                           // one chain longer than the table
+            }
+            bool tall = false, vec = true;
+            for (int k = i; k < j; ++k) {
+                tall = tall || items[k].rows > 64;
+                vec = vec && (items[k].ld & 3) == 0 && (((uintptr_t)items[k].src) & 15) == 0;
+            }
+            vec = vec && (items[i].cols & 3) == 0 && (((uintptr_t)items[i].dst) & 15) == 0;
+            const int nb = tall ? ceil_div(items[i].cols, 64) : vec ? ceil_div(items[i].cols, 1024) : ceil_div(items[i].cols, 256);
+            for (int k = i; k < j; ++k) {
+                t.it[cnt] = items[k];
+                if (k == i && i == i0 && i0 > 0 && items[i].chain) t.it[cnt].chain = 0, t.it[cnt].accumulate = 1;   // continuation of a cut chain
+                t.blk0[cnt] = blocks;
+                ++cnt;
+            }
+            blocks += nb;
+            i = j;
+            if (cut) break;
+        }
+        for (int k = cnt; k <= CSM_MAX; ++k) t.blk0[k] = blocks;
+        t.n = cnt;
+        hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+        M324_CHECK_LAUNCH("m324_colsum_multi");
+        i0 = i;
+    }
     return M324_OK;
 }
 

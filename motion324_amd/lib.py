@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 ERR_UNSUPPORTED = -3          # m324_status M324_ERR_UNSUPPORTED
 
 
@@ -44,6 +44,11 @@ class GemmArgs(C.Structure):
         ("ln_stats_out", C.c_void_p),
         ("ln_copy_out", C.c_void_p), ("ln_ldcopy", C.c_long), ("ln_ncb", C.c_int), ("ln_eps", C.c_float),
     ]
+
+
+class ColsumItem(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("ld", C.c_long), ("rows", C.c_int), ("cols", C.c_int),
+                ("accumulate", C.c_int), ("chain", C.c_int)]
 
 
 _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
@@ -82,6 +87,7 @@ SIGNATURES = {
     "m324_nearest_point": [_P, _I, _P, _I, _P, _P],
     "m324_transpose": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
     "m324_colsum": [_P, _L, _P, _I, _I, _I, _I, _P, _I, _P],
+    "m324_colsum_multi": [C.POINTER(ColsumItem), _I, _P],
     "m324_gelu": [_P, _P, _L, _I, _P],
     "m324_gelu_bwd": [_P, _P, _P, _L, _I, _P],
     "m324_cast": [_P, _L, _I, _P, _L, _I, _I, _I, _P],

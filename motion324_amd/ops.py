@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 
 from . import lib as L
+from . import switches
 from .timing import active as _timing, span
 
 F32, BF16 = L.F32, L.BF16
@@ -143,6 +144,8 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1, out: Optional[tor
     if accumulate and out is None:
         raise L.M324Error("gemm_tn: accumulate needs out")
     direct = out is not None and slices == 1 and not accumulate
+    if direct and COLSUMS.busy(out.view(-1)):
+        COLSUMS.flush()
     part = out.view(1, N, Kc) if direct else torch.empty((slices, N, Kc), dtype=torch.float32, device=x.device)
     px, ldx = _rows(x, "x")
     py, ldy = _rows(y, "y")
@@ -152,6 +155,11 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1, out: Optional[tor
     if slices == 1 and not accumulate:
         return out if direct else part[0]
     if out is not None:
+        if DEFER_COLSUM:
+            # nobody reads a weight gradient before its bucket is declared done (backward.GradStore.done flushes): the sum of the
+            # slice partials joins the queue and leaves with the other sums of the block in one m324_colsum_multi launch
+            COLSUMS.defer(part.reshape(slices, N * Kc), out.view(-1), accumulate)
+            return out
         colsum(part.reshape(slices, N * Kc), out=out.view(-1), accumulate=accumulate)
         _wrote(out)
         return out
@@ -634,6 +642,8 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     if out is None:
         out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
         accumulate = False
+    elif COLSUMS.busy(out):                        # queued sums into this destination come first
+        COLSUMS.flush()
     scratch, srows = None, 0
     if R >= 256:                                   # two-stage: row chunks in parallel, then a short fixed-order sum
         srows = 64 if R >= 2048 else 16
@@ -641,6 +651,73 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
     L.check(L.load().m324_colsum(px, ld, _vec(out, Cc, "out"), R, Cc, code_of(x.dtype), int(accumulate), _p(scratch), srows,
                                  _stream()), "m324_colsum")
     return out
+
+
+class _ColsumQueue:
+    """Column sums that nobody reads yet, collected and launched together (m324_colsum_multi): the split-K partials of the weight
+    gradients, the per-workgroup partials of LayerNorm / RMSNorm weight gradients.  ``defer(src, dst, accumulate)`` = what
+    ``colsum(src, out=dst, accumulate=...)`` would do, later.  At the flush the entries are grouped by destination (order kept
+    within a destination; destinations are independent of each other): one destination = one chain, summed in order by the same
+    threads -- the arithmetic of consecutive m324_colsum calls.  ``flush()`` MUST run before anyone reads or torch-writes a
+    destination (backward.GradStore does: done(), add() on a gradient it already holds, get(); colsum(out=...) checks too)."""
+
+    LIMIT = 256
+
+    def __init__(self):
+        self.by_dst = {}         # data_ptr of a destination -> [(dst 1-D fp32 view, src 2-D fp32, accumulate)]
+        self.count = 0
+
+    def defer(self, src: torch.Tensor, dst: torch.Tensor, accumulate: bool) -> None:
+        if src.dtype != torch.float32 or dst.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1 or not dst.is_contiguous() \
+                or dst.numel() != src.shape[1]:
+            raise L.M324Error(f"colsum queue: fp32 [rows, cols] -> contiguous fp32 [cols], got {src.dtype}{tuple(src.shape)} -> {dst.dtype}{tuple(dst.shape)}")
+        chain = self.by_dst.setdefault(dst.data_ptr(), [])
+        if chain and not accumulate:
+            raise L.M324Error("colsum queue: a second sum into a pending destination must accumulate")
+        chain.append((dst.view(-1), src, bool(accumulate)))
+        self.count += 1
+        if self.count >= self.LIMIT:
+            self.flush()
+
+    def busy(self, t: torch.Tensor) -> bool:
+        return self.count > 0 and t.data_ptr() in self.by_dst
+
+    def clear(self) -> None:
+        """Drops the queue (a step that failed half way: its partial buffers are gone)."""
+        self.by_dst, self.count = {}, 0
+
+    def flush(self) -> None:
+        if not self.count:
+            return
+        arr = (L.ColsumItem * self.count)()
+        k, dsts = 0, []
+        for chain in self.by_dst.values():
+            for j, (dst, src, acc) in enumerate(chain):
+                it = arr[k]
+                it.dst, it.src, it.ld, it.rows, it.cols = dst.data_ptr(), src.data_ptr(), src.stride(0), src.shape[0], src.shape[1]
+                it.accumulate, it.chain = int(acc and j == 0), int(j > 0)
+                k += 1
+            dsts.append(chain[0][0])
+        keep = self.by_dst                                # the sources stay referenced until the launch is enqueued
+        self.by_dst, self.count = {}, 0
+        L.check(L.load().m324_colsum_multi(arr, k, _stream()), "m324_colsum_multi")
+        _wrote(*dsts)
+        del keep
+
+
+class Rows:
+    """Marks an fp32 [rows, cols] tensor whose COLUMN SUMS are a gradient (the per-workgroup partials of a norm-weight gradient):
+    backward.GradStore.add queues the sum into the gradient's own memory instead of taking a reduced temporary and copying it."""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+    def reduce(self) -> torch.Tensor:
+        return colsum(self.t)
+
+
+COLSUMS = _ColsumQueue()
+DEFER_COLSUM = switches.flag("M324_DEFER_COLSUM")
 
 
 def gelu(z: torch.Tensor) -> torch.Tensor:
@@ -658,10 +735,12 @@ def gelu_bwd(z: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
 
 
 def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool,
-                  row_map=(0, 0, 0), cast_out: Optional[torch.Tensor] = None):
+                  row_map=(0, 0, 0), cast_out: Optional[torch.Tensor] = None, reduce: bool = True):
     """dx[in_row(r)] (+)= LN backward of row r; returns (dw [C], db [C]) fp32.  x, dx fp32; dy in the compute dtype.
     cast_out (bf16, shaped like dx): also receives the resulting dx rounded to bf16, and a third vector is returned: the
-    column sums of that rounded copy (m324_layernorm_bwd_cast: one pass instead of LayerNorm backward + cast + column sum)."""
+    column sums of that rounded copy (m324_layernorm_bwd_cast: one pass instead of LayerNorm backward + cast + column sum).
+    reduce=False: the vectors come back as ops.Rows -- the per-workgroup partial rows, whose column sums the caller queues
+    (backward.GradStore.add) instead of reducing them here with a launch each."""
     if x.dtype != torch.float32 or dx.dtype != torch.float32:
         raise L.M324Error("layernorm_bwd: x and dx must be fp32")
     rows, Cdim = dy.shape
@@ -669,7 +748,9 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     pdy, ldy = _rows(dy, "dy")
     pdx, lddx = _rows(dx, "dx")
     _wrote(dx)
-    n_partial = min(512, (rows + 7) // 8)               # workgroups of 8 waves, one row per wave at a time
+    # workgroups of 8 waves, one row per wave at a time; their partial rows are summed by m324_colsum (two stages from 256 rows
+    # on) -- or (reduce=False) queued for the block's m324_colsum_multi launch, whose tall form wants <= 256 rows
+    n_partial = min(512 if reduce else 256, (rows + 7) // 8)
     nb = 2 if cast_out is None else 3
     partial = torch.empty((n_partial, nb * Cdim), dtype=torch.float32, device=x.device)
     gin, gout, off = row_map
@@ -677,6 +758,8 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
         L.check(L.load().m324_layernorm_bwd(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
                                             int(accumulate), _p(partial), n_partial, rows, Cdim, gin, gout, off, _stream()),
                 "m324_layernorm_bwd")
+        if not reduce:
+            return Rows(partial[:, :Cdim]), Rows(partial[:, Cdim:])
         both = colsum(partial)
         return both[:Cdim], both[Cdim:]
     if cast_out.dtype != torch.bfloat16 or cast_out.shape != dx.shape:
@@ -686,6 +769,8 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     L.check(L.load().m324_layernorm_bwd_cast(px, ldx, _vec(w, Cdim, "w"), eps, pdy, ldy, code_of(dy.dtype), pdx, lddx,
                                              int(accumulate), _p(partial), n_partial, rows, Cdim, gin, gout, off, pc, ldc,
                                              _stream()), "m324_layernorm_bwd_cast")
+    if not reduce:
+        return Rows(partial[:, :Cdim]), Rows(partial[:, Cdim:2 * Cdim]), Rows(partial[:, 2 * Cdim:])
     three = colsum(partial)
     return three[:Cdim], three[Cdim:2 * Cdim], three[2 * Cdim:]
 
@@ -742,11 +827,11 @@ def attention_bwd_mfma(spq: dict, spk: dict, spdo: dict, lse, D, *, shared_q: bo
     return dQ, dK, dV
 
 
-def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: int, H: int, dq_out, dk_out, dv_out):
+def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: int, H: int, dq_out, dk_out, dv_out, reduce: bool = True):
     """Writes token-major gradients into dq_out / dk_out / dv_out (2-D views, any may be None with its dX);
     returns (dq_norm_w [64] or None, dk_norm_w [64] or None)."""
     dtype = next(t for t in (dQ, dK, dV) if t is not None).dtype
-    n_partial = min(1024, max(1, (B * Lq * H + 31) // 32))      # a workgroup takes 32 (token, head) rows per pass
+    n_partial = min(1024 if reduce else 256, max(1, (B * Lq * H + 31) // 32))      # a workgroup takes 32 (token, head) rows per pass
     dev = next(t for t in (dQ, dK, dV) if t is not None).device
     partial = torch.empty((n_partial, 128), dtype=torch.float32, device=dev)
 
@@ -760,6 +845,9 @@ def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: in
     L.check(L.load().m324_qkv_split_bwd(_p(dQ), _p(dK), _p(dV), pq, ldq, pk, ldk, _vec(q_w, 64, "q_w"), _vec(k_w, 64, "k_w"),
                                         eps, poq, ldoq, pok, ldok, pov, ldov, _p(partial), n_partial, B, Lq, H, code_of(dtype),
                                         _stream()), "m324_qkv_split_bwd")
+    if not reduce:                                          # ops.Rows: see layernorm_bwd
+        return (Rows(partial[:, :64]) if (dQ is not None and q_w is not None) else None,
+                Rows(partial[:, 64:]) if (dK is not None and k_w is not None) else None)
     both = colsum(partial)
     return (both[:64] if (dQ is not None and q_w is not None) else None,
             both[64:] if (dK is not None and k_w is not None) else None)

@@ -30,6 +30,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_TRAIN_STORE": ("1", "training.TRAIN_STORE", "training: the forward keeps block internals while they fit half of the free HBM (0: always recompute, the reference's checkpoint policy)"),
     "M324_DIRECT_GRADS": ("1", "backward.DIRECT_GRADS", "training: weight / bias gradients are written straight into the optimizer's flat gradient buffer (0: temporary + copy)"),
     "M324_ACC_GRADS": ("1", "backward.ACC_GRADS", "training: later gradients of a shared weight (the decoder's per-sample passes) are summed into the one it holds by the weight-gradient kernel's own reduction (0: temporary + torch add)"),
+    "M324_DEFER_COLSUM": ("1", "ops.DEFER_COLSUM", "training: the sums of the weight gradients' split-K partials and of the norm-weight partials wait in a queue and leave in one m324_colsum_multi launch per block (0: one m324_colsum launch each, at once)"),
     "M324_PRECISION": ("", "prepared.compute_dtype()", "force bf16 / fp32 (default: follow torch.autocast like the reference)"),
     "M324_LIB": ("", "lib.LIB_PATH", "path of an alternative libm324.so (lab builds)"),
     "M324_RCCL_LIB": ("", "csrc/comm.hip", "m324_comm_*: path of the RCCL library to bind (default: the copy already loaded, else librccl.so)"),

@@ -74,6 +74,7 @@ def forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float =
         try:
             return _forward_backward(model, sample, grad_scale, drop_seed, sink)
         except torch.cuda.OutOfMemoryError:
+            ops.COLSUMS.clear()                    # queued column sums of the failed attempt: their partial buffers are gone
             # The keep-internals budget is an estimate taken before the forward (half of the free memory); on a shared or
             # smaller device the backward's own peak can still exceed what is left.  One retry with the reference's policy
             # (checkpoint every block, recompute in the backward) -- unless this step already sent gradient buckets to the
@@ -226,7 +227,7 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
         dz2 = ops.gelu_bwd(z2, dh2)
         dh = bw.linear_bwd(P, G, head_fc1.weight, head_fc1.bias, h, dz2)
         dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
-        dw, db = ops.layernorm_bwd(x, P.vec(head_ln.weight), head_ln.eps, dh, dx, accumulate=False)
+        dw, db = ops.layernorm_bwd(x, P.vec(head_ln.weight), head_ln.eps, dh, dx, accumulate=False, reduce=not ops.DEFER_COLSUM)
         G.add(head_ln.weight, dw)
         G.add(head_ln.bias, db)
         d_pf = bw.cross_attn_block_bwd(dec, P, G, pf, tok_b, dx, T, N, K, kv_row_map=(K, Lt, 4), shared_q=True,
@@ -253,7 +254,7 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     pre = ops.assemble_tokens(dino_x, P.vec(enc_m.norm.weight), P.vec(enc_m.norm.bias), DINO_EPS, pos, sp0, spr, mesh,
                               None, ln_in.eps, B, T, K, Pn, drop_p, drop_seed)
     d_pre = torch.empty_like(pre)
-    dw, _ = ops.layernorm_bwd(pre, P.vec(ln_in.weight), ln_in.eps, d_tok, d_pre, accumulate=False)
+    dw, _ = ops.layernorm_bwd(pre, P.vec(ln_in.weight), ln_in.eps, d_tok, d_pre, accumulate=False, reduce=not ops.DEFER_COLSUM)
     G.add(ln_in.weight, dw)
     d4 = d_pre.reshape(B, T, Lt, C)
     G.add(model.special_token_0, ops.colsum(d4[:, 0, :4].reshape(B, 4 * C).contiguous()).reshape(1, 4, C))

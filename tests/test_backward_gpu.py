@@ -42,6 +42,86 @@ def test_colsum_and_accumulate(dtype):
     assert rel_err(s, 2 * x.double().sum(0)) < 1e-5
 
 
+def test_colsum_multi_is_the_sequence_of_single_column_sums():
+    """m324_colsum_multi (ABI 20): many (destination, chain of fp32 row blocks) pairs in one launch -- against the same sums done
+    one m324_colsum call after the other: bit-identical for the wide form (<= 64 rows per source: the split-K partials of the weight
+    gradients), equal to fp64 sums within fp32 rounding for the tall form (per-workgroup partials of a LayerNorm backward), with
+    unaligned column counts, strided sources (column slices of one partial buffer), accumulation into a destination that already
+    holds a value, and more items than one launch's table takes."""
+    from motion324_amd import ops
+    g = torch.Generator().manual_seed(5)
+    q = ops._ColsumQueue()
+    want, want64, dsts = [], [], []
+    big = torch.randn((256, 3 * 192), generator=g).to(DEV)                  # a LayerNorm-backward partial: three column groups
+    specs = [(7, 2304 * 768 // 64, False, 1), (28, 4096, True, 1), (3, 1000, False, 3), (64, 64, True, 2), (1, 20, False, 1), (5, 333, True, 2)]
+    specs += [(2 + k % 5, 128 + 4 * k, bool(k % 2), 1 + k % 3) for k in range(40)]      # > 64 items in all
+    for rows, cols, acc, nchain in specs:
+        dst = torch.randn((cols,), generator=g).to(DEV)
+        ref = dst.clone()
+        r64 = dst.double().cpu() if acc else torch.zeros(cols, dtype=torch.float64)
+        for c in range(nchain):
+            src = torch.randn((rows + c, cols), generator=g).to(DEV)
+            q.defer(src, dst, acc or c > 0)
+            ops.colsum(src, out=ref, accumulate=acc or c > 0)
+            r64 = r64 + src.double().cpu().sum(0)
+        want.append(ref), want64.append(r64), dsts.append(dst)
+    tall = []
+    for k in range(3):
+        dst = torch.zeros((192,), device=DEV)
+        q.defer(big[:, k * 192:(k + 1) * 192], dst, False)
+        tall.append((dst, big[:, k * 192:(k + 1) * 192].double().cpu().sum(0)))
+    assert q.count == sum(n for *_x, n in specs) + 3 > 64
+    q.flush()
+    torch.cuda.synchronize()
+    for dst, ref, r64 in zip(dsts, want, want64):
+        assert torch.equal(dst, ref), float((dst - ref).abs().max())
+        assert rel_err(dst, r64) < 1e-5
+    for dst, r64 in tall:
+        assert rel_err(dst, r64) < 1e-5
+    with pytest.raises(Exception, match="must accumulate"):
+        q.defer(torch.zeros((2, 8), device=DEV), dsts[0][:8].contiguous(), False)
+        q.defer(torch.zeros((2, 8), device=DEV), dsts[0][:8].contiguous(), False)
+
+
+def test_queued_column_sums_give_the_same_training_step(monkeypatch):
+    """M324_DEFER_COLSUM: the sums of the weight gradients' split-K partials and of the norm-weight partials leave in one launch
+    per block instead of one m324_colsum each.  Same step: loss and output bit for bit, every weight gradient whose partials
+    are few rows bit for bit, the rest (tall partials: another summation order) to fp32 rounding."""
+    import motion324_amd as m
+    from motion324_amd import ops, synth, training
+    from motion324_amd.optim import FusedAdamW, backward_completion_order
+    from conftest import CASES, synth_sd
+    dims, (B, T, N, S, HW) = CASES["tiny"]["dims"], CASES["tiny"]["shape"]
+    dm = synth.Dims(**dims)
+    cfg = synth.make_config(frames=dm.frames, d=dm.d, d_head=dm.d_head, tokens=dm.tokens, pcd_layers=dm.pcd_layers, n_layer=dm.n_layer)
+    cfg["model"]["dino"] = {"depth": dm.dino_depth}
+    model = m.Motion_Latent_Model(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_sd(dims).items()}, strict=False)
+    model = model.train().to(DEV)
+    model.drop_rate = 0.0
+    sample = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_inputs(B, T, N, S, HW, seed=1, with_target=True).items()}
+    res = {}
+    m.set_precision("bf16")
+    try:
+        for defer in (False, True):
+            monkeypatch.setattr(ops, "DEFER_COLSUM", defer)
+            for with_sink in (False, True):
+                opt = FusedAdamW(model.named_parameters(), lr=1e-3, order=backward_completion_order(model)) if with_sink else None
+                loss, out, G = training.forward_backward(model, sample, sink=opt)
+                assert ops.COLSUMS.count == 0                                   # the last done() flushed the queue
+                res[(defer, with_sink)] = (float(loss), out.clone(), {n: G.get(p).clone() for n, p in model.named_parameters() if p.requires_grad})
+    finally:
+        m.set_precision(None)
+    for with_sink in (False, True):
+        l0, o0, g0 = res[(False, with_sink)]
+        l1, o1, g1 = res[(True, with_sink)]
+        assert l0 == l1 and torch.equal(o0, o1)
+        worst = max(rel_err(g1[n], g0[n]) for n in g0)
+        exact = sum(int(torch.equal(g1[n], g0[n])) for n in g0)
+        print(f"[queued column sums, sink={with_sink}] {exact} of {len(g0)} gradients bit-identical, worst {worst:.2e}")
+        assert worst < 1e-5 and exact >= len(g0) // 2
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gelu_forward_backward(dtype):
     from motion324_amd import ops
