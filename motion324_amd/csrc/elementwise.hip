@@ -658,16 +658,17 @@ __global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ 
 // m324_colsum_multi: one launch for many (destination, chain of fp32 row blocks) pairs.  The table travels in the kernel arguments.
 // A destination's workgroups: "wide" (every source of its chain has <= 64 rows: the split-K partials of a weight gradient) -- a thread
 // owns four neighbouring columns and walks the rows, then the chain, in order (colsum_wide_kernel's arithmetic); "tall" (the
-// per-workgroup partials of a LayerNorm backward: few columns, hundreds of rows) -- 64 columns per workgroup, wave w takes rows w,
-// w + 4, ..., the four partial sums are added in wave order (colsum_kernel's arithmetic).
-constexpr int CSM_MAX = 64;
+// per-workgroup partials of a LayerNorm backward: few columns, hundreds of rows) -- 64 columns per workgroup, wave w of 16 takes rows
+// w, w + 16, ..., the sixteen partial sums are added in wave order.
+constexpr int CSM_MAX = 64, CSM_THREADS = 1024, CSM_WAVES = CSM_THREADS / 64;
 struct CsmTable {
     m324_colsum_item it[CSM_MAX];
     int blk0[CSM_MAX + 1];          // first workgroup of item i's destination (heads only; a chained item repeats its head's)
     int n;
 };
-__global__ __launch_bounds__(256) void colsum_multi_kernel(const CsmTable t) {
-    __shared__ float red[4][64];
+// 1024 threads: a tall source (up to 1024 partial rows of 64 .. 2304 columns) is walked by 16 waves at once, rows w, w + 16, ...
+__global__ __launch_bounds__(CSM_THREADS) void colsum_multi_kernel(const CsmTable t) {
+    __shared__ float red[CSM_WAVES][64];
     const int bid = blockIdx.x;
     int lo = 0, hi = t.n;                                    // the head whose workgroup range holds bid: blk0[lo] <= bid < blk0 of the next head
     while (hi - lo > 1) {
@@ -692,13 +693,18 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const CsmTable t) {
         for (int i = head; i <= last; ++i) {
             const m324_colsum_item it = t.it[i];
             float s = 0.f;
-            if (c < it.cols)
-                for (int r = w; r < it.rows; r += 4) s += it.src[(long)r * it.ld + c];
+            if (c < it.cols) {
+                const float* p = it.src + c;
+#pragma unroll 4
+                for (int r = w; r < it.rows; r += CSM_WAVES) s += p[(long)r * it.ld];
+            }
             __syncthreads();
             red[w][lane] = s;
             __syncthreads();
             if (w == 0 && c < it.cols) {
-                const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+                float v = red[0][lane];
+#pragma unroll
+                for (int k = 1; k < CSM_WAVES; ++k) v += red[k][lane];
                 val = i == head ? (it.accumulate ? it.dst[c] + v : v) : val + v;
             }
         }
@@ -706,17 +712,18 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const CsmTable t) {
         return;
     }
     if (vec) {
-        const long c = ((long)local * 256 + threadIdx.x) * 4;
+        const long c = ((long)local * CSM_THREADS + threadIdx.x) * 4;
         if (c >= h0.cols) return;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = head; i <= last; ++i) {
             const m324_colsum_item it = t.it[i];
             const float* p = it.src + c;
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+#pragma unroll 8
             for (int r = 0; r < it.rows; ++r) {
-                const float4 x = *reinterpret_cast<const float4*>(p + (long)r * it.ld);
-                s.x += x.x, s.y += x.y, s.z += x.z, s.w += x.w;
+                typedef float csm_f4 __attribute__((ext_vector_type(4)));
+                const csm_f4 x = __builtin_nontemporal_load(reinterpret_cast<const csm_f4*>(p + (long)r * it.ld));     // read once
+                s.x += x[0], s.y += x[1], s.z += x[2], s.w += x[3];
             }
             if (i == head) {
                 if (it.accumulate) {
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const CsmTable t) {
         *reinterpret_cast<float4*>(h0.dst + c) = val;
         return;
     }
-    const long c = (long)local * 256 + threadIdx.x;          // unaligned operands: one column per thread
+    const long c = (long)local * CSM_THREADS + threadIdx.x;  // unaligned operands: one column per thread
     if (c >= h0.cols) return;
     float val = 0.f;
     for (int i = head; i <= last; ++i) {
@@ -1254,7 +1261,7 @@ extern "C" int m324_colsum_multi(const m324_colsum_item* items, int n, void* str
                 vec = vec && (items[k].ld & 3) == 0 && (((uintptr_t)items[k].src) & 15) == 0;
             }
             vec = vec && (items[i].cols & 3) == 0 && (((uintptr_t)items[i].dst) & 15) == 0;
-            const int nb = tall ? ceil_div(items[i].cols, 64) : vec ? ceil_div(items[i].cols, 1024) : ceil_div(items[i].cols, 256);
+            const int nb = tall ? ceil_div(items[i].cols, 64) : vec ? ceil_div(items[i].cols, 4 * CSM_THREADS) : ceil_div(items[i].cols, CSM_THREADS);
             for (int k = i; k < j; ++k) {
                 t.it[cnt] = items[k];
                 if (k == i && i == i0 && i0 > 0 && items[i].chain) t.it[cnt].chain = 0, t.it[cnt].accumulate = 1;   // continuation of a cut chain
@@ -1267,7 +1274,7 @@ extern "C" int m324_colsum_multi(const m324_colsum_item* items, int n, void* str
         }
         for (int k = cnt; k <= CSM_MAX; ++k) t.blk0[k] = blocks;
         t.n = cnt;
-        hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+        hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(CSM_THREADS), 0, s, t);
         M324_CHECK_LAUNCH("m324_colsum_multi");
         i0 = i;
     }

@@ -691,7 +691,8 @@ class _ColsumQueue:
             return
         arr = (L.ColsumItem * self.count)()
         k, dsts = 0, []
-        for chain in self.by_dst.values():
+        # tall sources first: their workgroups (16 waves over up to 1024 rows) are the longest-running of the launch
+        for chain in sorted(self.by_dst.values(), key=lambda ch: -max(src.shape[0] for _, src, _a in ch)):
             for j, (dst, src, acc) in enumerate(chain):
                 it = arr[k]
                 it.dst, it.src, it.ld, it.rows, it.cols = dst.data_ptr(), src.data_ptr(), src.stride(0), src.shape[0], src.shape[1]
@@ -749,8 +750,8 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     pdx, lddx = _rows(dx, "dx")
     _wrote(dx)
     # workgroups of 8 waves, one row per wave at a time; their partial rows are summed by m324_colsum (two stages from 256 rows
-    # on) -- or (reduce=False) queued for the block's m324_colsum_multi launch, whose tall form wants <= 256 rows
-    n_partial = min(512 if reduce else 256, (rows + 7) // 8)
+    # on) -- or (reduce=False) queued for the block's m324_colsum_multi launch
+    n_partial = min(512, (rows + 7) // 8)
     nb = 2 if cast_out is None else 3
     partial = torch.empty((n_partial, nb * Cdim), dtype=torch.float32, device=x.device)
     gin, gout, off = row_map
@@ -831,7 +832,7 @@ def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: in
     """Writes token-major gradients into dq_out / dk_out / dv_out (2-D views, any may be None with its dX);
     returns (dq_norm_w [64] or None, dk_norm_w [64] or None)."""
     dtype = next(t for t in (dQ, dK, dV) if t is not None).dtype
-    n_partial = min(1024 if reduce else 256, max(1, (B * Lq * H + 31) // 32))      # a workgroup takes 32 (token, head) rows per pass
+    n_partial = min(1024, max(1, (B * Lq * H + 31) // 32))      # a workgroup takes 32 (token, head) rows per pass
     dev = next(t for t in (dQ, dK, dV) if t is not None).device
     partial = torch.empty((n_partial, 128), dtype=torch.float32, device=dev)
 

@@ -52,8 +52,8 @@ def test_colsum_multi_is_the_sequence_of_single_column_sums():
     g = torch.Generator().manual_seed(5)
     q = ops._ColsumQueue()
     want, want64, dsts = [], [], []
-    big = torch.randn((256, 3 * 192), generator=g).to(DEV)                  # a LayerNorm-backward partial: three column groups
-    specs = [(7, 2304 * 768 // 64, False, 1), (28, 4096, True, 1), (3, 1000, False, 3), (64, 64, True, 2), (1, 20, False, 1), (5, 333, True, 2)]
+    big = torch.randn((700, 3 * 192), generator=g).to(DEV)                  # a LayerNorm-backward partial: three column groups
+    specs = [(7, 2304 * 768 // 64, False, 1), (28, 4096, True, 1), (3, 1000, False, 3), (62, 64, True, 2), (1, 20, False, 1), (5, 333, True, 2)]
     specs += [(2 + k % 5, 128 + 4 * k, bool(k % 2), 1 + k % 3) for k in range(40)]      # > 64 items in all
     for rows, cols, acc, nchain in specs:
         dst = torch.randn((cols,), generator=g).to(DEV)
