@@ -42,7 +42,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges, bit 1 4 x 2 group order for wide weights, bit 2 force it; bit 3: the ring GEMMs' look-ahead pieces past the end of K fetch the last stage again (rounds 1-4) instead of nothing (A/B)"),
     "M324_ATTN_NW": ("0", "attention forward: waves per workgroup (4 | 8); 0 = by sequence length"),
     "M324_ATTN_FLAT": ("1", "XCD-aware flat grid: 1 = global and per-frame attention, 2 = the 8-wave global attention only, 0 = 3-D grid"),
-    "M324_ATTN_OCC": ("0", "attention: occupancy hint"),
+    "M324_ATTN_OCC": ("0", "attention A/B: 1 = no one-tile form, 2 = two workgroups per CU (padded LDS), 3 = the per-frame attentions (row-major V, short sequences) keep the three-stage ring, three workgroups per CU (default since round 6: two stages, four per CU)"),
     "M324_ATTN_NQ2": ("0", "attention: 64 queries per wave"),
     "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup (4 | 8); 0 = 8 from 256 keys on"),
     "M324_ATTN_EXP": ("0", "attention A/B bits: 1 static priority for the younger half of an 8-wave workgroup, 2 direct stores in the one-tile form, 4 no idle-wave skip in partly filled query tiles, 8 one workgroup per frame in the shared-query one-tile form, 16 its frame-pair form with plain (not nontemporal) stores"),
