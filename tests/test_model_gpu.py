@@ -267,7 +267,7 @@ def test_auto_graph_survives_inference_mode_deepcopy_and_a_failed_capture(monkey
     """Round-2 advisor findings on the automatic graph replay: (1) a capture made under torch.inference_mode() must serve a
     later call under plain no_grad (static buffers live outside inference mode); (2) copy.deepcopy(model) works once graphs
     exist (they are process-local and stay behind); (3) a capture that raises falls back to the eager path and switches the
-    feature off for that model instead of propagating; (4) shape sets are kept LRU, at most two."""
+    feature off for that model instead of propagating; (4) shape sets are kept LRU, at most three."""
     import copy
     import motion324_amd as m
     import motion324_amd.graph as mg
@@ -289,14 +289,15 @@ def test_auto_graph_survives_inference_mode_deepcopy_and_a_failed_capture(monkey
         assert "_ag" not in twin.__dict__
         with torch.no_grad():
             assert torch.equal(twin(sample).pcd_moved, eager)
-        # (4) three shape sets: only the two most recent stay captured
+        # (4) four shape sets: only the three most recent stay captured (the long-video driver alone uses two: its first window
+        # and the windows behind it)
         def shaped(n):
             return {k: (v[:, :n].contiguous() if k in ("ref_pcd", "ref_normal", "ref_rgb") else v) for k, v in sample.items()}
         with torch.no_grad():
-            for n in (30, 20):
+            for n in (30, 20, 10):
                 for _ in range(3):
                     model(shaped(n))
-        assert len(model.__dict__["_ag"]._graphs) == 2
+        assert len(model.__dict__["_ag"]._graphs) == 3
         # (3) a capture that fails: the call is still served, eagerly, and the model stops trying
         def boom(self, sample):
             raise RuntimeError("capture invalidated")
