@@ -28,6 +28,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_FUSE_QKV": ("1", "transformer.FUSE_QKV", "bf16 inference: q|k|v projection epilogue writes head-major Q / K / V (RMSNorm, pre-scale)"),
     "M324_FUSE_QKV_VT": ("1", "transformer.FUSE_QKV_VT", "the same for long sequences: the epilogue writes the transposed, key-permuted V"),
     "M324_TRAIN_STORE": ("1", "training.TRAIN_STORE", "training: the forward keeps block internals while they fit half of the free HBM (0: always recompute, the reference's checkpoint policy)"),
+    "M324_TRAIN_DINO_FUSED": ("1", "training.DINO_FUSED", "training: the frozen DINOv2 encoder (no gradient flows through it) runs its inference form -- LayerNorm fold, fused q|k|v epilogue -- and is enqueued first in the step (0: the unfused form the trainable blocks use)"),
     "M324_DIRECT_GRADS": ("1", "backward.DIRECT_GRADS", "training: weight / bias gradients are written straight into the optimizer's flat gradient buffer (0: temporary + copy)"),
     "M324_ACC_GRADS": ("1", "backward.ACC_GRADS", "training: later gradients of a shared weight (the decoder's per-sample passes) are summed into the one it holds by the weight-gradient kernel's own reduction (0: temporary + torch add)"),
     "M324_DEFER_COLSUM": ("1", "ops.DEFER_COLSUM", "training: the sums of the weight gradients' split-K partials and of the norm-weight partials wait in a queue and leave in one m324_colsum_multi launch per block (0: one m324_colsum launch each, at once)"),

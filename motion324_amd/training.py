@@ -46,6 +46,7 @@ def _point_features_bwd(model, P: Prepared, G: bw.GradStore, enc, feat, d_pf: to
     bw.linear_bwd(P, G, model.point_embed.mlp.weight, model.point_embed.mlp.bias, enc, demb, need_da=False)
 
 
+DINO_FUSED = switches.flag("M324_TRAIN_DINO_FUSED")          # the frozen image encoder runs its inference form inside a training step
 TRAIN_STORE = switches.get("M324_TRAIN_STORE")             # "1": keep block internals while they fit, "0": always recompute
 
 
@@ -125,6 +126,18 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     weight = float(model.loss_computer._weight)
 
     # ================================================================ forward (block inputs kept)
+    # The image encoder first: it is frozen (no gradient flows through it: it runs its inference form, LayerNorm fold and fused
+    # q|k|v epilogue included), and its chip-filling launches give the GPU a backlog while the host enqueues the shape encoder's
+    # ~120 latency-bound ones -- a step starts right behind the optimizer's host read, with an empty queue.
+    from .transformer import fusion_allowed
+    video = _f32c(sample["rgb_video"])
+    _, _, Hin, Win, _ = video.shape
+    if DINO_FUSED:
+        with fusion_allowed(), torch.no_grad():
+            dino_x = model.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3), two_streams=False)
+    else:
+        dino_x = model.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))
+
     pts, enc_s, feat_s = _point_features_train(model, P, _f32c(sample["ref_shape_pcd"]).reshape(-1, 3),
                                                _f32c(sample["ref_shape_normals"]), _f32c(sample["ref_shape_rgbs"]))
     query = P.f32(model.learnable_tokens).reshape(K, C).repeat(B, 1)
@@ -133,10 +146,6 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
     for blk in model.points_transformer_blocks:
         mesh_in.append(mesh.clone())
         blk.run(P, mesh, B, K)
-
-    video = _f32c(sample["rgb_video"])
-    _, _, Hin, Win, _ = video.shape
-    dino_x = model.image_encoder.run(P, video.reshape(B * T, Hin, Win, 3))            # frozen: no gradient
     enc_m = model.image_encoder.model
     pos = model._video_pos(P, T)
     sp0, spr = P.f32(model.special_token_0).reshape(4, C), P.f32(model.special_token_rest).reshape(4, C)

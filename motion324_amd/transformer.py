@@ -233,6 +233,20 @@ class fusion_disabled:
         _FUSE_OFF -= 1
 
 
+class fusion_allowed:
+    """Inside a training step's fusion_disabled(): a frozen sub-network that no gradient flows through (the DINOv2 image encoder,
+    reference dinov2.py:126-131) may run its inference form -- LayerNorm fold, head-major q|k|v epilogue -- when the caller also
+    switches grad mode off for it."""
+
+    def __enter__(self):
+        global _FUSE_OFF
+        self._saved, _FUSE_OFF = _FUSE_OFF, 0
+
+    def __exit__(self, *exc):
+        global _FUSE_OFF
+        _FUSE_OFF = self._saved
+
+
 def fuse_qkv(P: Prepared, rows: int, L: int) -> bool:
     """Per-frame blocks (L < 2048): head-major Q / K / V, attention with the row-major-V kernel.  Long sequences (the
     global blocks) keep the faster transposed-V attention; the projection epilogue writes Vt itself when L % 128 == 0."""
