@@ -976,7 +976,8 @@ static bool use_pwg(bool prescaled, bool vrow, bool nq2, int fnw, int Lq, int Lk
 // the per-frame attentions (row-major V from the fused q|k|v epilogue, pre-scaled q, four waves, a handful of key tiles): the
 // two-stage, four-per-CU instantiation
 static bool two_stage(bool vrow, bool prescaled, bool w8, int Lk) {
-    return vrow && prescaled && !w8 && Lk <= 16 * KV && m324::tunable(m324::TUN_ATTN_OCC) != 3;
+    (void)vrow;                                   // both V layouts (the training step's per-frame blocks read the transposed Vt)
+    return prescaled && !w8 && Lk > KV && Lk <= 16 * KV && m324::tunable(m324::TUN_ATTN_OCC) != 3;
 }
 
 extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, const void* Vt, void* O, long ldo, int B,
@@ -1036,8 +1037,12 @@ extern "C" int m324_attention(const void* Q, long q_bstride, const void* K, cons
         if (two_stage(vrow, q_prescaled != 0, w8, Lk)) {
             // per-frame blocks (round 6): four workgroups per CU instead of three (two LDS stages, 128 registers); microbench, interleaved
             // A/B on one box: L = 324 26.6 -> 24.5 us, L = 257 22.6 -> 21.2 us; M324_ATTN_OCC=3 keeps the three-stage form (A/B)
-            hipLaunchKernelGGL((attn_bf16_kernel<true, 1, 4, true, 2>), g2, dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K,
-                               (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt, xfl);
+            if (vrow)
+                hipLaunchKernelGGL((attn_bf16_kernel<true, 1, 4, true, 2>), g2, dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K,
+                                   (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt, xfl);
+            else
+                hipLaunchKernelGGL((attn_bf16_kernel<true, 1, 4, false, 2>), g2, dim3(256), 0, s, (const bf16_t*)Q, q_bstride, (const bf16_t*)K,
+                                   (const bf16_t*)Vt, (bf16_t*)O, ldo, H, Lq, Lk, Lkp, sl, lse, nqt, xfl);
         } else if (vrow) {
             if (q_prescaled) { if (w8) M324_ATTN_VR(true, 8); else M324_ATTN_VR(true, 4); }
             else { if (w8) M324_ATTN_VR(false, 8); else M324_ATTN_VR(false, 4); }
