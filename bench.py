@@ -38,7 +38,7 @@ sys.path.insert(0, REPO)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PROFILE_ROUND = "r05"          # profiles/<round>_* hold the rocprofv3 summaries the roofline rows are checked against
+PROFILE_ROUND = "r06"          # profiles/<round>_* hold the rocprofv3 summaries the roofline rows are checked against
 
 WORKLOAD = dict(B=1, T=32, N=2048, S=4096, HW=512, frames=32)   # BASELINE.json configs[1]
 
@@ -306,7 +306,7 @@ def class_totals(summ, steps: int, peak: float):
 def committed_traffic(symbol: str):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes (counters cannot be read in-process):
     profiles/<round>_traffic.json, written by tools/pmc_traffic.py from FETCH_SIZE / WRITE_SIZE passes."""
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02", "r01"):
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", f"{rnd}_traffic.json")))
         except (OSError, ValueError):
@@ -869,7 +869,7 @@ def run_train(args, D: Dist):
                                 if training.TRAIN_STORE != "0" else "checkpoint per block + recompute (M324_TRAIN_STORE=0)"),
                 "roofline": roofline_from(rec, 1, args.precision, "HIP events around every GEMM / attention-forward launch of one extra "
                                           "training step (forward, dgrad, wgrad; the attention backward kernels are "
-                                          f"not in the classes); symbols as in profiles/{PROFILE_ROUND}_p7_train_kernel_stats.md"),
+                                          f"not in the classes); symbols as in profiles/{PROFILE_ROUND}_train_p1_kernel_stats.md"),
                 "cpu_baseline": None}
     return line
 
