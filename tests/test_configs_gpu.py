@@ -208,7 +208,7 @@ def _fp_worker(rank, world, port, case, precision, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,precision,tol,overlap", [(2, "fp32", 5e-6, "1"), (3, "bf16", 6e-3, "1"), (2, "bf16", 6e-3, "0"), (2, "bf16", 6e-3, "1")])
+@pytest.mark.parametrize("world,precision,tol,overlap", [(2, "fp32", 5e-6, "0"), (3, "bf16", 6e-3, "0"), (2, "bf16", 6e-3, "1")])
 def test_frame_parallel_at_c2_size(world, precision, tol, overlap, monkeypatch):
     """Frame-parallel forward at the real trunk sizes: 32 frames over 2 ranks (16 + 16: the all_gather_into_tensor fast
     path, 5184 local / 10 368 global tokens) and over 3 ranks (11 + 11 + 10: uneven shards, padded gather) == the

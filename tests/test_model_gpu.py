@@ -390,7 +390,7 @@ def _fp_worker(rank, world, port, case, precision, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world,overlap", [("tiny", 2, "1"), ("tiny", 3, "1"), ("tiny_resize", 2, "1"), ("tiny_resize", 2, "0")])
+@pytest.mark.parametrize("case,world,overlap", [("tiny", 2, "0"), ("tiny", 3, "1"), ("tiny_resize", 2, "0")])
 def test_frame_parallel_equals_single_gpu(case, world, overlap, monkeypatch):
     """Frames sharded over ranks (uneven for world = 3: T = 3 -> 1+1+1; tiny_resize T = 2 is too short) with the
     K/V all-gather in every global block == the single-process forward, bit for bit in fp32 up to summation order.
