@@ -1009,7 +1009,8 @@ static bool vec_ok(const m324_gemm_args* a) {
 // it (tests, lab), bit 3 = the ring kernels' look-ahead past the end of K fetches the last stage again instead of nothing (A/B).  Default 3.
 static int xcd_mode(const m324_gemm_args* a) {
     const int t = m324::tunable(m324::TUN_XCD);
-    const int old_refetch = t & 8;               // bit 3 (A/B): look-ahead pieces past the end of K fetch the last stage again (rounds 1-4)
+    const int old_refetch = t & (8 | 16);        // A/B bits handed through to the kernels: 3 = look-ahead pieces past the end of K fetch the
+                                                 // last stage again (rounds 1-4); 4 = v12 without the residual prefetch (round 6)
     if (!(t & 1)) return old_refetch;
     const long wbytes = (long)a->N * a->K * (a->in_dtype == M324_BF16 ? 2 : 4);
     if ((t & 4) || ((t & 2) && wbytes > (5l << 19) && a->N >= 2 * a->K)) return 3 | old_refetch;

@@ -263,6 +263,15 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
         M324_SG(0x008, 1); M324_SG(0x020, 1); M324_SG(0x008, 1); M324_SG(0x020, 2);
     };
 
+    // fp32 residual stream (the trunk's / DINO's out-projection and fc2: plain rows, RES == 1): its values for the epilogue are
+    // requested first of all (gemm_tile.h res_prefetch; 128 registers of the 284 this one-wave-per-SIMD kernel leaves unused).  They
+    // are older than every ring piece, so the counted waits below retire them with stage 0.
+    constexpr bool PRE_RES = RES == 1 && sizeof(TOUT) == 4;
+    ResPre<4> pres;
+    const bool use_pres = PRE_RES && ep.residual != nullptr && (xcd_remap & 16) == 0;       // bit 4: A/B (M324_XCD)
+    if constexpr (PRE_RES) {
+        if (use_pres) res_prefetch<4>(ep, M, N, m0 + wm * 128, n0 + wn * 64, lane, pres);
+    }
     // prologue: the whole ring (stages 0, 1, 2); stage 0 then has nothing to issue and is peeled
     issue3(0, 0, 0); issue3(3, 0, 0); issue3(6, 0, 0); issue3(9, 0, 0);
     {
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256) void gemm_ring3_kernel(const bf16_t* __restric
 #undef M324_SG
     M324_BARRIER();
     store_tile_lds<TOUT, ACT, RES, 4>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 128,
-                                      n0 + wn * 64, lane, ep);
+                                      n0 + wn * 64, lane, ep, nullptr, PRE_RES ? &pres : nullptr, use_pres);
 }
 
 

@@ -611,9 +611,46 @@ __device__ __forceinline__ float2 ln_row_direct(const Epilogue& ep, int M, int r
 // unrolled passes splits them into basic blocks, and the loads / stores of a block are then no longer issued as batches
 // (measured: +6 us on a 56 us GEMM whose fold work is 2 FMAs per element); the instantiations without the bits are
 // untouched.
+// The fp32 residual values of a wave's MI x 32 x 64 block in the row-owning layout of store_tile_lds's `body` (lane -> row
+// mw + 32 i + (lane >> 4) + 4 p, columns nw + 4 (lane & 15) ..): round 6, single-round kernels (v12: one 256 x 128 tile per CU)
+// fetch them BEFORE the main loop.  Their epilogue otherwise pays MI dependent HBM round trips at the very end, when all 246
+// workgroups of the launch reach it at once (the residual IS the output stream: the loads of row block i + 1 cannot be hoisted
+// above the stores of block i), while HBM sits idle during the main loop, whose operands come out of the L2s.
+// (32-float vector VALUES per row block, not a float4 array: an array indexed by the row-block loop is still a memory object when
+// the register-promotion pass runs -- the loops are unrolled later -- and went to scratch; LnPreT above met the same.)
+typedef float res_f32x32 __attribute__((ext_vector_type(32)));
+template <int MI>
+struct ResPre {
+    res_f32x32 v0, v1, v2, v3;                      // row blocks 0 .. 3 (MI <= 4): element 4 p + e = pass p, column e
+    __device__ __forceinline__ float4 get(int i, int p) const {
+        const res_f32x32 v = i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3));
+        return make_float4(v[4 * p], v[4 * p + 1], v[4 * p + 2], v[4 * p + 3]);
+    }
+};
+template <int MI>
+__device__ __forceinline__ void res_prefetch(const Epilogue& ep, int M, int N, int mw, int nw, int lane, ResPre<MI>& pr) {
+    static_assert(MI <= 4, "ResPre holds four row blocks");
+    const int rr = lane >> 4, ncl = min(nw + (lane & 15) * 4, N - 4);
+    auto block = [&](int i) {
+        res_f32x32 v;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float4 x = *reinterpret_cast<const float4*>(ep.residual + (long)min(mw + i * 32 + rr + 4 * p, M - 1) * ep.ldr + ncl);
+            v[4 * p] = x.x, v[4 * p + 1] = x.y, v[4 * p + 2] = x.z, v[4 * p + 3] = x.w;
+        }
+        return v;
+    };
+    pr.v0 = block(0);
+    if (MI > 1) pr.v1 = block(1);
+    if (MI > 2) pr.v2 = block(2);
+    if (MI > 3) pr.v3 = block(3);
+    asm volatile("" ::: "memory");                  // the loads are issued HERE: nothing below may be scheduled above them, nor they below
+}
+
 template <typename TOUT, int ACTX, int RES, int MI>
 __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float* scr, TOUT* C, long ldc, int M, int N, int mw,
-                                               int nw, int lane, const Epilogue& ep, const LnPreT<MI>* pre = nullptr) {
+                                               int nw, int lane, const Epilogue& ep, const LnPreT<MI>* pre = nullptr,
+                                               const ResPre<MI>* pres = nullptr, bool use_pres = false) {
     constexpr int ACT = ACTX & 7;
     constexpr bool fold = (ACTX & 8) != 0, STATS = (ACTX & 16) != 0, COPY = (ACTX & 32) != 0;
     // The 256-wide kernels call this once per tile from a persistent loop that runs at the register limit.  Lane-derived
@@ -671,7 +708,10 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
 #pragma unroll
                 for (int p = 0; p < 8; ++p) rs[p] = rsl[i * 32 + rr + 4 * p];
             }
-            if (has_res) {
+            if (has_res && pres && use_pres) {      // (pres: a compile-time constant per call site; the values stay in registers)
+#pragma unroll
+                for (int p = 0; p < 8; ++p) res[p] = pres->get(i, p);
+            } else if (has_res) {
                 // broadcast residual (the decoder's out-projection: the same 2048 point rows under every frame): ONE
                 // division per 32-row block, then a compare-subtract per pass (an integer modulo per row cost this
                 // epilogue 25 us of the 115 us GEMM); periods shorter than a block keep the per-row form
