@@ -578,6 +578,14 @@ __device__ __forceinline__ void ring2_tile(const bf16_t* __restrict__ A, long ld
         M324_SG(0x008, 1); M324_SG(0x100, 2); M324_SG(0x008, 1); M324_SG(0x020, 2);
     };
 
+    // fp32 residual stream with plain rows (the out-projections of the trunk and of DINO): the epilogue's residual values are requested
+    // in front of the ring's first pieces (gemm_tile.h res_prefetch; 64 registers, 226 of the 256 two workgroups per CU leave a wave)
+    constexpr bool PRE_RES = RES == 1 && sizeof(TOUT) == 4;
+    ResPre<2> pres;
+    const bool use_pres = PRE_RES && ep.residual != nullptr && (xcd_remap & 16) == 0;       // M324_XCD bit 4: A/B
+    if constexpr (PRE_RES) {
+        if (use_pres) res_prefetch<2>(ep, M, N, m0 + wm * 64, n0 + wn * 64, lane, pres);
+    }
     LnPreT<2> ln_pre;
     ln_prefetch<ACT, 2>(ep, M, N, m0 + wm * 64, n0 + wn * 64, lane, ln_pre);
     {
@@ -627,7 +635,7 @@ __device__ __forceinline__ void ring2_tile(const bf16_t* __restrict__ A, long ld
 #undef M324_SG
     M324_BARRIER();
     store_tile_lds<TOUT, ACT, RES, 2>(acc, reinterpret_cast<float*>(smem) + wave * ep_wave_floats(ACT), C, ldc, M, N, m0 + wm * 64,
-                                      n0 + wn * 64, lane, ep, &ln_pre);
+                                      n0 + wn * 64, lane, ep, &ln_pre, PRE_RES ? &pres : nullptr, use_pres);
 }
 
 template <typename TOUT, int ACT, int RES>
