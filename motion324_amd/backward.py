@@ -37,6 +37,7 @@ class GradStore:
         self.grads: Dict[int, torch.Tensor] = {}
         self.params: Dict[int, torch.nn.Parameter] = {}
         self.sink = sink
+        ops.COLSUMS.clear()             # a new step: whatever an aborted one left in the queue belongs to gradients nobody keeps
         if sink is not None:
             sink.begin_step()
 
