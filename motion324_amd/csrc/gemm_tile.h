@@ -797,31 +797,6 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
         float4 cs0 = make_float4(0.f, 0.f, 0.f, 0.f), cs1 = cs0;
         if (fold) { cs0 = *reinterpret_cast<const float4*>(csl + c8); cs1 = *reinterpret_cast<const float4*>(csl + c8 + 4); }
         const float* rd8 = scr + r8 * EP_LD + c8;
-        // residual rows of a 32-row block's 4 passes: same row, or row modulo res_rows (one division per block, then steps of 8);
-        // 16 bytes per lane when the residual is the bf16 stream itself, two float4 when it is fp32.  Round 6: block i + 1's values
-        // are requested BEFORE block i's arithmetic and stores (one block of look-ahead, two register sets): the stores of a block
-        // may alias the loads behind them as far as the compiler knows, so every block used to wait out its own L2 / HBM round trip.
-        float4 rres[2][4], sres[2][4];
-        auto fetch_res = [&](int i, float4 (&ra)[4], float4 (&rb)[4]) {
-            int mr = mw + i * 32 + r8;
-            if (res_mod) mr %= ep.res_rows;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (ep.res_out) {
-                    const TOUT* rp = reinterpret_cast<const TOUT*>(ep.residual) + (long)mr * ep.ldr + n8;
-                    ra[p] = load4_out<TOUT>(rp);
-                    rb[p] = load4_out<TOUT>(rp + 4);
-                } else {
-                    const float* rp = ep.residual + (long)mr * ep.ldr + n8;
-                    ra[p] = *reinterpret_cast<const float4*>(rp);
-                    rb[p] = *reinterpret_cast<const float4*>(rp + 4);
-                }
-                mr += 8;
-                if (res_mod) { while (mr >= ep.res_rows) mr -= ep.res_rows; }
-            }
-        };
-        constexpr bool PIPE = RES != 0 && ACT != 1 && ACT != 2;      // (GELU + residual: no model shape; v10 would spill the second set)
-        if constexpr (PIPE) fetch_res(0, rres[0], sres[0]);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             float4 xa[4], ya[4];                             // STATS: the stored values of the 4 passes
@@ -836,8 +811,7 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<float4*>(wr + j * 32 + 8 * g) =
                         make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            float4 v0[4], v1[4], z0[4], z1[4];
-            float4 (&ra)[4] = rres[PIPE ? (i & 1) : 0], (&rb)[4] = sres[PIPE ? (i & 1) : 0];
+            float4 v0[4], v1[4], z0[4], z1[4], ra[4], rb[4];
             if constexpr (ACT == 3) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -846,10 +820,25 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     z1[p] = load4_out<TOUT>(zp + 4);
                 }
             }
-            if constexpr (PIPE) {
-                if (i + 1 < MI) fetch_res(i + 1, rres[(i + 1) & 1], sres[(i + 1) & 1]);
-            } else if constexpr (RES != 0) {
-                fetch_res(i, rres[0], sres[0]);
+            if constexpr (RES != 0) {
+                // residual rows of the 4 passes: same row, or row modulo res_rows (one division per block, then steps of 8);
+                // 16 bytes per lane when the residual is the bf16 stream itself, two float4 when it is fp32
+                int mr = mw + i * 32 + r8;
+                if (res_mod) mr %= ep.res_rows;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (ep.res_out) {
+                        const TOUT* rp = reinterpret_cast<const TOUT*>(ep.residual) + (long)mr * ep.ldr + n8;
+                        ra[p] = load4_out<TOUT>(rp);
+                        rb[p] = load4_out<TOUT>(rp + 4);
+                    } else {
+                        const float* rp = ep.residual + (long)mr * ep.ldr + n8;
+                        ra[p] = *reinterpret_cast<const float4*>(rp);
+                        rb[p] = *reinterpret_cast<const float4*>(rp + 4);
+                    }
+                    mr += 8;
+                    if (res_mod) { while (mr >= ep.res_rows) mr -= ep.res_rows; }
+                }
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
