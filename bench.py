@@ -357,7 +357,6 @@ def decoder_block_replay(model, sample, steps: int, q_mode: str = "pair"):
         pf = model._point_features(P, sample["ref_pcd"][0].float().contiguous(), sample["ref_normal"][0].float().contiguous(),
                                    sample["ref_rgb"][0].float().contiguous())
 
-        pf16 = model._pf16(P, pf)                             # the block's `query` as the reference's block receives it under autocast (bf16)
         branch = torch.cuda.Stream()
 
         def block():
@@ -369,17 +368,17 @@ def decoder_block_replay(model, sample, steps: int, q_mode: str = "pair"):
             main = torch.cuda.current_stream()
             if q_mode == "pair":
                 Q, Kd, Vd = dec.project_q_kv(P, pf, N, tok, B * T, K, row_map=(K, Lt, 4))
-                return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q, pf16)
+                return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q)
             if q_mode == "serial":
                 Q = dec.project_q(P, pf, 1, N)
                 Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))
-                return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q, pf16)
+                return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q)
             branch.wait_stream(main)
             with torch.cuda.stream(branch):
                 Q = dec.project_q(P, pf, 1, N)
             Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))
             main.wait_stream(branch)
-            return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q, pf16)
+            return model.decoder_block(P, Kd[:T], Vd[:T], pf, Q)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -112,11 +112,6 @@ typedef struct {
      *     [ln_ncb][M] (sum, M2) with ln_ncb = K / 64 even and <= 16, and the consumer merges the blocks of its tiles' rows (the arithmetic
      *     of m324_rowstats_finish, eps = ln_eps) while its first operand tiles are in flight -- no launch between the two GEMMs. */
     int ln_ncb; float ln_eps;
-    /* ABI 21: dtype of `residual`.  M324_F32 (0, the default of a zeroed struct): fp32 -- or, when `residual` IS `C` and out_dtype is
-     * bf16, the bf16 stream being updated in place.  M324_BF16: a bf16 operand other than C (out_dtype bf16 only) -- the decoder's
-     * out-projection adds the point features, which ARE bf16 in the reference under autocast (`query` is the output of an nn.Linear,
-     * Pcd_motion.py:550-553, transformer.py:365-369): half the residual bytes through the L2s (profiles/r06_misc_ab.md section 6). */
-    int res_dtype;
 } m324_gemm_args;
 int m324_gemm(const m324_gemm_args* a, void* stream);
 /* Two independent GEMMs in ONE launch (horizontal fusion of small latency-bound problems).  Built for the pair the hot path has:

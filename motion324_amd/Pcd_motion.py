@@ -38,7 +38,6 @@ FUSE_HEAD_N3 = switches.flag("M324_FUSE_HEAD")              # head fc1 + GELU + 
 KV_REHEARSE = int(switches.get("M324_KV_REHEARSE") or 0)       # one-rank rehearsal of the overlapped exchange as rank 0 of W
 KV_OVERLAP = switches.flag("M324_KV_OVERLAP")              # frame-parallel: own keys attended while the K|V all-gather is in flight
 BF16_DECODER_STREAM = switches.flag("M324_BF16_DECODER")    # the decoder's residual stream in bf16 (bf16 inference only)
-BF16_RESIDUAL = switches.flag("M324_BF16_QUERY_RES")       # ... and the point features it starts from as a bf16 residual operand
 HOIST_DECODER_Q = switches.flag("M324_HOIST_Q")             # hoisted decoder q projection (graph capture)
 DECODE_ROWS = int(switches.get("M324_DECODE_ROWS"))         # max (frames x points) rows per decoder pass: bounds the [rows, 4C] MLP buffer
 
@@ -344,28 +343,16 @@ class Motion_Latent_Model(nn.Module):
         ops.gemm(feat, P.mat(self.point_normal_rgb_proj.weight), out, bias=P.vec(self.point_normal_rgb_proj.bias))
         return out
 
-    def decoder_block(self, P: Prepared, Kd, Vd, pf: torch.Tensor, Q=None, pf16: Optional[torch.Tensor] = None):
+    def decoder_block(self, P: Prepared, Kd, Vd, pf: torch.Tensor, Q=None):
         """The decoder cross-attention block on one sample's mesh points (reference transformer.py:365-377 through
         Pcd_motion.py:556-561): pf fp32 [n, C] point features = the queries, Kd / Vd the T frames' latent keys / values
         (project_kv).  Returns (x [T * n, C] stream after attention + MLP, its LNFold or None).  Q: an already projected
-        query set (the graph hoists it onto the shape-encoder branch).  pf16: the point features as the reference's block
-        receives them under autocast -- bf16, the output of an nn.Linear (Pcd_motion.py:550-553) -- used as the residual of
-        the bf16 stream (`query + attn_out`, transformer.py:369; ABI 21 res_dtype: half the residual bytes of the
-        out-projection); None: made here."""
+        query set (the graph hoists it onto the shape-encoder branch)."""
         dec = self.decoder_cross_attn
         n = pf.shape[0]
         if Q is None:
             Q = dec.project_q(P, pf, 1, n)
-        res = pf
-        if BF16_DECODER_STREAM and BF16_RESIDUAL and P.dtype == torch.bfloat16 and not torch.is_grad_enabled():
-            res = pf16 if pf16 is not None else ops.cast(pf, torch.bfloat16)
-        return dec.attend(P, Q, Kd, Vd, res, n, shared_q=True, bf16_stream=BF16_DECODER_STREAM, want_fold=True)
-
-    def _pf16(self, P: Prepared, pf: torch.Tensor) -> Optional[torch.Tensor]:
-        """the bf16 form of the point features (the block's `query` under autocast) when the bf16 stream uses it as its residual"""
-        if BF16_DECODER_STREAM and BF16_RESIDUAL and P.dtype == torch.bfloat16 and not torch.is_grad_enabled():
-            return ops.cast(pf, torch.bfloat16)
-        return None
+        return dec.attend(P, Q, Kd, Vd, pf, n, shared_q=True, bf16_stream=BF16_DECODER_STREAM, want_fold=True)
 
     def decoder_block_flops(self, B: int, T: int, N: int) -> float:
         """Reference FLOPs of the block (to_q counted once per frame, as the reference computes it)."""
@@ -558,7 +545,7 @@ class Motion_Latent_Model(nn.Module):
                 hoisted = []
                 for b in range(B):
                     pf_b = self._point_features(P, pcd_h[b], nrm_h[b].contiguous(), rgb_h[b].contiguous())
-                    hoisted.append((pf_b, self.decoder_cross_attn.project_q(P, pf_b, 1, N), self._pf16(P, pf_b)))
+                    hoisted.append((pf_b, self.decoder_cross_attn.project_q(P, pf_b, 1, N)))
 
         # B. image encoder (reference :466-475): resize + normalise + patchify + ViT, frozen
         video = sample["rgb_video"]
@@ -648,23 +635,22 @@ class Motion_Latent_Model(nn.Module):
             pf0 = self._point_features(P, pcd[0], nrm[0].contiguous(), rgb[0].contiguous())
             with span("stage:decoder_cross_attn_block", self.decoder_block_flops(B, T, N)):
                 Q0, Kd, Vd = dec.project_q_kv(P, pf0, N, tok, B * T, K, row_map=(K, Lt, 4))
-            paired = (pf0, Q0, self._pf16(P, pf0))
+            paired = (pf0, Q0)
         else:
             with span("stage:decoder_cross_attn_block", self.decoder_block_flops(B, T, N)):
                 Kd, Vd = dec.project_kv(P, tok, B * T, K, row_map=(K, Lt, 4))       # latent tokens 4..4+K of every frame
         for b in range(B):
             for n0 in range(0, N, nchunk):
                 n1 = min(N, n0 + nchunk)
-                pf16 = None
                 if hoisted is not None:
-                    pf, Q, pf16 = hoisted[b]
+                    pf, Q = hoisted[b]
                 elif paired is not None:
-                    pf, Q, pf16 = paired
+                    pf, Q = paired
                 else:
                     pf = self._point_features(P, pcd[b, n0:n1], nrm[b, n0:n1].contiguous(), rgb[b, n0:n1].contiguous())
                 with span("stage:decoder_cross_attn_block", 0.0):
                     x, fold_d = self.decoder_block(P, Kd[b * T:(b + 1) * T], Vd[b * T:(b + 1) * T], pf,
-                                                   None if (hoisted is None and paired is None) else Q, pf16)
+                                                   None if (hoisted is None and paired is None) else Q)
                 if cap is not None and n0 == 0 and n1 == N:
                     cap.setdefault("decoder_out_t0", []).append(x[:N].clone())
                 if fold_d is not None:

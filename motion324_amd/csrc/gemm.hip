@@ -1143,7 +1143,7 @@ static Epilogue make_epilogue(const m324_gemm_args* a) {
                     {(bf16_t*)a->qkv_q, (bf16_t*)a->qkv_k, (bf16_t*)a->qkv_v}, {a->qkv_qw, a->qkv_kw}, a->qkv_eps, a->qkv_qscale,
                     a->qkv_L, a->qkv_H, a->aux_mode == M324_AUX_QKV_HEADS_VT ? 1 : 0,
                     (a->out_dtype == M324_BF16 && (long)a->M * a->N * 2 > ((long)m324::tunable(m324::TUN_NT_MB) << 20)) ? 1 : 0,
-                    (a->residual && a->out_dtype == M324_BF16 && ((const void*)a->residual == (const void*)a->C || a->res_dtype == M324_BF16)) ? 1 : 0,
+                    (a->residual && (const void*)a->residual == (const void*)a->C && a->out_dtype == M324_BF16) ? 1 : 0,
                     reinterpret_cast<const float2*>(a->ln_rowstat), a->ln_colsum, reinterpret_cast<float2*>(a->ln_stats_out),
                     static_cast<bf16_t*>(a->ln_copy_out), a->ln_ldcopy, a->ln_rowstat ? a->ln_ncb : 0, a->ln_eps};
 }
@@ -1354,8 +1354,6 @@ static int gemm_validate(const m324_gemm_args* a) {
     M324_REQUIRE(257l * (a->lda > a->ldw ? a->lda : a->ldw) * esz + (long)a->K * esz < 0x7FFFFFFFl,
                  "m324_gemm: leading dimension %ld too large for the 256-row staging window", a->lda > a->ldw ? a->lda : a->ldw);
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
-    M324_REQUIRE(a->res_dtype == M324_F32 || (a->res_dtype == M324_BF16 && a->residual && a->out_dtype == M324_BF16),
-                 "m324_gemm: res_dtype %d (a bf16 residual needs a bf16 output)", a->res_dtype);
     M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
                  "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
     M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 5, "m324_gemm: aux_mode %d", a->aux_mode);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 21
+ABI_VERSION = 20
 ERR_UNSUPPORTED = -3          # m324_status M324_ERR_UNSUPPORTED
 
 
@@ -43,7 +43,6 @@ class GemmArgs(C.Structure):
         ("ln_rowstat", C.c_void_p), ("ln_colsum", C.c_void_p),
         ("ln_stats_out", C.c_void_p),
         ("ln_copy_out", C.c_void_p), ("ln_ldcopy", C.c_long), ("ln_ncb", C.c_int), ("ln_eps", C.c_float),
-        ("res_dtype", C.c_int),
     ]
 
 

@@ -264,13 +264,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     args.act = act
     args.gamma = _vec(gamma, N, "gamma")
     if residual is not None:
-        bf16_res = residual.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
-        if residual.dtype != torch.float32 and not bf16_res:
-            raise L.M324Error("gemm: residual must be fp32 (or bf16 beside a bf16 output: the stream itself, or another operand)")
+        in_place_bf16 = residual.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and residual.data_ptr() == out.data_ptr()
+        if residual.dtype != torch.float32 and not in_place_bf16:
+            raise L.M324Error("gemm: residual must be fp32 (or the bf16 output itself, updated in place)")
         args.residual, args.ldr = _rows(residual, "residual")
         args.res_rows = res_rows
-        if bf16_res and residual.data_ptr() != out.data_ptr():
-            args.res_dtype = BF16                      # ABI 21: a bf16 residual operand that is not the output
     gin, gout, off = row_map
     need = ((M - 1) // gin * gout + (M - 1) % gin + off + 1) if gin > 0 else M
     if out.shape[0] < need or out.shape[1] < N:

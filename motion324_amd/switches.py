@@ -16,7 +16,6 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_AUTO_GRAPH": ("1", "Pcd_motion.AUTO_GRAPH", "inference forward(): hipGraph replay from the third call with the same shapes on"),
     "M324_FUSE_HEAD": ("1", "Pcd_motion.FUSE_HEAD_N3", "bf16 inference: head Linear + GELU + Linear(C -> 3) in one GEMM epilogue (M324_AUX_N3)"),
     "M324_BF16_DECODER": ("1", "Pcd_motion.BF16_DECODER_STREAM", "bf16 inference: the decoder's two-addition residual stream in bf16 (0: fp32 like the trunk)"),
-    "M324_BF16_QUERY_RES": ("1", "Pcd_motion.BF16_RESIDUAL", "bf16 inference with the bf16 decoder stream: the point features enter the stream (`query + attn_out`) as a bf16 residual operand, as in the reference under autocast (0: fp32 point features)"),
     "M324_HOIST_Q": ("1", "Pcd_motion.HOIST_DECODER_Q", "graph capture: decoder point features + q projection on the shape-encoder branch"),
     "M324_DECODE_ROWS": (str(1 << 17), "Pcd_motion.DECODE_ROWS", "max (frames x points) rows per decoder pass"),
     "M324_OVERLAP": ("1", "Pcd_motion.OVERLAP_SHAPE_ENCODER", "inference: shape encoder on a second HIP stream under the image encoder"),

@@ -45,12 +45,12 @@ def test_gemm_args_struct_layout_matches_header():
     assert names == ["A", "lda", "W", "ldw", "C", "ldc", "M", "N", "K", "in_dtype", "out_dtype", "bias", "act", "gamma",
                      "residual", "ldr", "res_rows", "row_gin", "row_gout", "row_off", "batch", "strideA", "strideW", "strideC", "aux", "ldaux",
                      "aux_mode", "qkv_q", "qkv_k", "qkv_v", "qkv_qw", "qkv_kw", "qkv_eps", "qkv_qscale", "qkv_L", "qkv_H",
-                     "ln_rowstat", "ln_colsum", "ln_stats_out", "ln_copy_out", "ln_ldcopy", "ln_ncb", "ln_eps", "res_dtype"]
+                     "ln_rowstat", "ln_colsum", "ln_stats_out", "ln_copy_out", "ln_ldcopy", "ln_ncb", "ln_eps"]
     assert GemmArgs.A.offset == 0 and GemmArgs.M.offset == 48 and GemmArgs.bias.offset == 72
     assert GemmArgs.residual.offset == 96 and GemmArgs.row_gin.offset == 116 and GemmArgs.batch.offset == 128 and GemmArgs.aux.offset == 160 \
         and GemmArgs.aux_mode.offset == 176 and GemmArgs.qkv_q.offset == 184 and GemmArgs.qkv_eps.offset == 224 \
         and GemmArgs.ln_rowstat.offset == 240 and GemmArgs.ln_ldcopy.offset == 272 and GemmArgs.ln_ncb.offset == 280 and GemmArgs.ln_eps.offset == 284 \
-        and GemmArgs.res_dtype.offset == 288 and ctypes.sizeof(GemmArgs) == 296
+        and ctypes.sizeof(GemmArgs) == 288
 
 
 def test_errors_are_reported_not_thrown_across_the_abi():

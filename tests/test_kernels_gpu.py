@@ -1399,27 +1399,3 @@ def test_gemm_cross_attention_projection_heads(B, L):
     ops.gemm(x, wkv, None, bias=bkv, qkv_heads=(None, Kf, Vtf, None, kw, 1e-5, 1.0, L, H, True))
     assert torch.isfinite(Kf.float()).all() and rel_err(Kf.float(), Ks.float().double()) < 6e-3
     assert torch.equal(Vtf, Vts)
-
-
-@pytest.mark.parametrize("variant", ["v0", "v2", "v10", "v13"])
-@pytest.mark.parametrize("res_rows", [0, 96])
-def test_gemm_bf16_residual_operand(variant, res_rows, tune):
-    """ABI 21 res_dtype: a bf16 residual that is NOT the output (the decoder's out-projection adds the bf16 point features, broadcast over
-    the frames) -- against fp64 math, and equal to the fp32-residual path on the same (bf16-representable) values bit for bit."""
-    from motion324_amd import ops
-    if variant != "v0":
-        tune("M324_GEMM", variant)
-    g = torch.Generator().manual_seed(3)
-    M, N, K = 960, 768, 256
-    a = (torch.randn((M, K), generator=g)).to(torch.bfloat16)
-    w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16)
-    bias = torch.randn((N,), generator=g)
-    R = res_rows or M
-    res16 = torch.randn((R, N), generator=g).to(torch.bfloat16)
-    out16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-    out32 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-    ops.gemm(a.cuda(), w.cuda(), out16, bias=bias.cuda(), residual=res16.cuda(), res_rows=res_rows)
-    ops.gemm(a.cuda(), w.cuda(), out32, bias=bias.cuda(), residual=res16.float().cuda(), res_rows=res_rows)
-    ref = a.double() @ w.double().T + bias.double() + res16.double().repeat(M // R, 1)
-    assert rel_err(out16.float(), ref) < 4e-3
-    assert torch.equal(out16, out32)
