@@ -210,7 +210,7 @@ def _fp_worker(rank, world, port, case, precision, ret):
 
 @pytest.mark.parametrize("world,precision,tol,overlap", [(2, "fp32", 5e-6, "0"), (3, "bf16", 6e-3, "0"), (2, "bf16", 6e-3, "1")])
 def test_frame_parallel_at_c2_size(world, precision, tol, overlap, monkeypatch):
-    """Frame-parallel forward at the real trunk sizes: 32 frames over 2 ranks (16 + 16: the all_gather_into_tensor fast
+    """Frame-parallel forward at the real trunk sizes (two global + two local blocks of the c2 clip's 10368 tokens): 32 frames over 2 ranks (16 + 16: the all_gather_into_tensor fast
     path, 5184 local / 10 368 global tokens) and over 3 ranks (11 + 11 + 10: uneven shards, padded gather) == the
     single-process forward (fp32: summation order only; bf16: the single-process run takes the fused transposed-V
     projection epilogue, the sharded one m324_qkv_split -- bf16 rounding apart).  overlap "1" (M324_KV_OVERLAP=1, opt-in): every
@@ -218,15 +218,16 @@ def test_frame_parallel_at_c2_size(world, precision, tol, overlap, monkeypatch):
     and merges by log-sum-exp -- eagerly and as the chain of hipGraphs with TWO cuts per global block; "0": one attention."""
     import torch.multiprocessing as mp
     monkeypatch.setenv("M324_KV_OVERLAP", overlap)            # read at import by the spawned ranks
-    model, dm = build("c2")
-    ref, _ = run(model, inputs("c2", with_target=False), precision)
+    # the trunk at its real length, everything else shallow (conftest CASES["c2_shallow"]): every rank builds its own model
+    model, dm = build("c2_shallow")
+    ref, _ = run(model, inputs("c2_shallow", with_target=False), precision)
     ref = ref.pcd_moved.cpu()
     del model
     torch.cuda.empty_cache()
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 21000 + (os.getpid() * 11 + world + 5 * int(overlap)) % 4000
-    mp.spawn(_fp_worker, args=(world, port, "c2", precision, ret), nprocs=world, join=True)
+    mp.spawn(_fp_worker, args=(world, port, "c2_shallow", precision, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret[r].shape == ref.shape
         assert rel_err(ret[r], ref) < tol, (r, rel_err(ret[r], ref))
