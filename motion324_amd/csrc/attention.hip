@@ -696,6 +696,116 @@ __global__ __launch_bounds__(NWV * 64) void attn_bwd_dq_mfma_kernel(const bf16_t
     }
 }
 
+// Round 6 (A/B, M324_ATTN_BWD_NW=2): the dQ kernel with 64 queries per wave -- four waves, one per SIMD, 256 queries per workgroup like the
+// eight-wave form.  The eight-wave kernel reads one 16-byte fragment per lane and MFMA (24 KiB of K / V / Kt per wave and tile for 24 MFMAs):
+// 128 B per clock and CU, the LDS's whole bandwidth, against MFMAs that would take half that time.  Here every K / V / Kt fragment feeds
+// the MFMAs of TWO query blocks, so the reads per MFMA halve; ~330 registers (one wave per SIMD).  Compiler-scheduled.
+__global__ __launch_bounds__(256) void attn_bwd_dq2_mfma_kernel(const bf16_t* __restrict__ Qs, long q_bstride, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V, const bf16_t* __restrict__ Kt,
+                                                                const bf16_t* __restrict__ dO, const float* __restrict__ lse,
+                                                                const float* __restrict__ D, bf16_t* __restrict__ dQ, int H, int Lq, int Lk,
+                                                                int Lkp, float scale) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 3 * 8192];   // [stage][K | V | Kt]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const long bh = (long)b * H + h;
+    const bf16_t* Qh = Qs + (long)b * q_bstride + (long)h * Lq * 64;
+    const bf16_t* dOh = dO + bh * (long)Lq * 64;
+    const bf16_t* Kh = K + bh * (long)Lk * 64;
+    const bf16_t* Vh = V + bh * (long)Lk * 64;
+    const bf16_t* Kth = Kt + bh * 64 * (long)Lkp;
+    int q[2];
+    bool qok[2];
+    bf16x8 qf[2][4], dof[2][4];
+    float l2[2], dl[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        q[n] = (blockIdx.x * 4 + wave) * 64 + n * 32 + l31;
+        qok[n] = q[n] < Lq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 a = qok[n] ? *reinterpret_cast<const uint4*>(Qh + (long)q[n] * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+            uint4 c = qok[n] ? *reinterpret_cast<const uint4*>(dOh + (long)q[n] * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+            qf[n][ks] = *reinterpret_cast<bf16x8*>(&a);
+            dof[n][ks] = *reinterpret_cast<bf16x8*>(&c);
+        }
+        l2[n] = qok[n] ? lse[bh * Lq + q[n]] : 0.f;
+        dl[n] = qok[n] ? D[bh * Lq + q[n]] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rK = dma_rsrc(Kh, (long)Lk * 128), rV = dma_rsrc(Vh, (long)Lk * 128), rKt = dma_rsrc(Kth, 64l * Lkp * 2);
+    auto issue = [&](int t) {                                   // rows past Lk read as zeros (masked below)
+        unsigned char* st = smem + (t & 1) * 24576;
+        dma_rows<4>(st, rK, 64, t * KV, 0, wave, lane);
+        dma_rows<4>(st + 8192, rV, 64, t * KV, 0, wave, lane);
+        dma_rows<4>(st + 16384, rKt, Lkp, 0, (long)t * KV, wave, lane);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][i][r] = 0.f;
+    const int nt = (Lk + KV - 1) / KV;
+    issue(0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile t landed (see the eight-wave kernel)
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1);
+        const unsigned char* sk = smem + (t & 1) * 24576;
+        const unsigned char* sv = sk + 8192;
+        const unsigned char* skt = sk + 16384;
+        f32x16 s[2][2], dp[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[n][kb][r] = -l2[n], dp[n][kb][r] = -dl[n];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + k_off(kb * 32 + l31, ks * 2 + hi));
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + k_off(kb * 32 + l31, ks * 2 + hi));
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    s[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[n][ks], s[n][kb], 0, 0, 0);
+                    dp[n][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[n][ks], dp[n][kb], 0, 0, 0);
+                }
+            }
+        }
+        const int kv0 = t * KV;
+        const bool ragged = kv0 + KV > Lk;
+        bf16x8 dsf[2][4];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = __builtin_amdgcn_exp2f(s[n][kb][r]);
+                    if (ragged && kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) p = 0.f;
+                    s[n][kb][r] = p * dp[n][kb][r];                                   // dS^T
+                }
+            pack_frags(s[n], dsf[n]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(skt + k_off(db * 32 + l31, 2 * j + hi));
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[n][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[n][j], acc[n][db], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        bf16_t* orow = dQ + (bh * Lq + (qok[n] ? q[n] : 0)) * 64;
+        store_row_chunks(acc[n], scale, hi, qok[n], [&](int chunk, uint4 v) { *reinterpret_cast<uint4*>(orow + chunk * 8) = v; });
+    }
+}
+
 template <int NWV>
 __global__ __launch_bounds__(NWV * 64, 2) void attn_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ Qst,
                                                                 long q_bstride, long qt_bstride, const bf16_t* __restrict__ K,
@@ -1121,8 +1231,12 @@ extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_b
     // keeps all 16 fragments of a phase in flight.  Round 2 measured the 8-wave form 0.7 % slower; that was while every tile
     // waited ~6600 cycles for its lse / D loads.  Now: dQ + dK/dV at B = 8, L = 3888: 1552 us against 1724 (round 2: 2270).
     const int fbw = m324::tunable(m324::TUN_ATTN_BWD_NW);
-    const bool w8 = fbw ? fbw == 8 : Lk >= 1024;
+    const bool w8 = fbw == 8 || ((fbw == 0 || fbw == 2) && Lk >= 1024);      // 2: A/B, the dQ kernel's 64-queries-per-wave form
     if (w8) {
+        if (fbw == 2)                                          // A/B: 64 queries per wave, four waves (round 6)
+            hipLaunchKernelGGL(attn_bwd_dq2_mfma_kernel, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs, q_bstride,
+                               (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D, (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
+        else
         hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<8>, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
                            q_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D,
                            (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
