@@ -1224,33 +1224,35 @@ extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_b
     M324_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && H <= 65535 && B <= 65535, "m324_attention_bwd_mfma: bad sizes");
     const int Lkp = (Lk + 63) / 64 * 64, Lqp = (Lq + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
-    // Eight waves per workgroup for key sets of 1024 and more (the per-frame blocks' 324 keys would leave most of a second
-    // 256-key workgroup idle: the whole step measured 1 % slower with it) (M324_ATTN_BWD_NW=4|8 forces one form: A/B runs, tests): every
-    // staged tile then feeds 256 instead of 128 rows -- half the LDS-DMA pieces per wave and tile, which cost ~70 cycles of issue
-    // each (stamps: 660 cycles for a wave's nine pieces) -- and the dK / dV kernel, alone on its CU with 256 registers per wave,
-    // keeps all 16 fragments of a phase in flight.  Round 2 measured the 8-wave form 0.7 % slower; that was while every tile
-    // waited ~6600 cycles for its lse / D loads.  Now: dQ + dK/dV at B = 8, L = 3888: 1552 us against 1724 (round 2: 2270).
+    // Rounds 3-5 ran eight waves per workgroup for key sets of 1024 and more (every staged tile feeds 256 instead of 128 rows: half the LDS-DMA
+    // pieces per wave and tile; measured 1552 us against 1724 at B = 8, L = 3888 at the time -- before lse / D rode with the tiles).
     const int fbw = m324::tunable(m324::TUN_ATTN_BWD_NW);
-    const bool w8 = fbw == 8 || ((fbw == 0 || fbw == 2) && Lk >= 1024);      // 2: A/B, the dQ kernel's 64-queries-per-wave form
-    if (w8) {
-        if (fbw == 2)                                          // A/B: 64 queries per wave, four waves (round 6)
-            hipLaunchKernelGGL(attn_bwd_dq2_mfma_kernel, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs, q_bstride,
-                               (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D, (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
-        else
+    // M324_ATTN_BWD_NW: 0 = by key count; 4 | 8 = both kernels with that many waves; 84 = dQ with eight waves, dK / dV with four; 48 = the
+    // other way round; 2 = the dQ kernel's 64-queries-per-wave form (four waves) beside the eight-wave dK / dV kernel (A/B runs, tests)
+    // Round 6: FOUR waves per workgroup are the default at every size again (three co-resident workgroups hide more of a tile's waits than
+    // one eight-wave workgroup's shared tiles save: dQ + dK/dV at B = 8, L = 3888 1476-1485 us against 1491-1508, B = 32 5757 against 5970;
+    // the c3 training step 89.8-90.0 ms against 91.1-91.2, alternated processes on one box; profiles/r06_misc_ab.md section 8).
+    const bool big = Lk >= 1024;
+    const bool dq8 = fbw == 8 || fbw == 84, dkv8 = fbw == 8 || fbw == 48 || fbw == 2;
+    if (fbw == 2 && big)
+        hipLaunchKernelGGL(attn_bwd_dq2_mfma_kernel, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs, q_bstride,
+                           (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D, (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
+    else if (dq8)
         hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<8>, dim3(ceil_div(Lq, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
                            q_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D,
                            (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<8>, dim3(ceil_div(Lk, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
-                           (const bf16_t*)Qst, q_bstride, qt_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO,
-                           (const bf16_t*)dOt, lse, D, (bf16_t*)dK, (bf16_t*)dV, H, Lq, Lk, Lqp);
-    } else {
+    else
         hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<4>, dim3(ceil_div(Lq, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs,
                            q_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Kt, (const bf16_t*)dO, lse, D,
                            (bf16_t*)dQ, H, Lq, Lk, Lkp, scale);
+    if (dkv8)
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<8>, dim3(ceil_div(Lk, 2 * QB), H, B), dim3(512), 0, s, (const bf16_t*)Qs,
+                           (const bf16_t*)Qst, q_bstride, qt_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO,
+                           (const bf16_t*)dOt, lse, D, (bf16_t*)dK, (bf16_t*)dV, H, Lq, Lk, Lqp);
+    else
         hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<4>, dim3(ceil_div(Lk, QB), H, B), dim3(256), 0, s, (const bf16_t*)Qs,
                            (const bf16_t*)Qst, q_bstride, qt_bstride, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO,
                            (const bf16_t*)dOt, lse, D, (bf16_t*)dK, (bf16_t*)dV, H, Lq, Lk, Lqp);
-    }
     M324_CHECK_LAUNCH("m324_attention_bwd_mfma");
     return M324_OK;
 }

@@ -45,7 +45,7 @@ LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_ATTN_FLAT": ("1", "XCD-aware flat grid: 1 = global and per-frame attention, 2 = the 8-wave global attention only, 0 = 3-D grid"),
     "M324_ATTN_OCC": ("0", "attention A/B: 1 = no one-tile form, 2 = two workgroups per CU (padded LDS), 3 = the per-frame attentions (row-major V, short sequences) keep the three-stage ring, three workgroups per CU (default since round 6: two stages, four per CU)"),
     "M324_ATTN_NQ2": ("0", "attention: 64 queries per wave"),
-    "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup (4 | 8); 0 = 8 from 256 keys on"),
+    "M324_ATTN_BWD_NW": ("0", "attention backward: waves per workgroup -- 0 = four (the default since round 6), 8 = eight for both kernels, 84 = dQ eight + dK/dV four, 48 = the reverse, 2 = dQ with 64 queries per wave (A/B)"),
     "M324_ATTN_EXP": ("0", "attention A/B bits: 1 static priority for the younger half of an 8-wave workgroup, 2 direct stores in the one-tile form, 4 no idle-wave skip in partly filled query tiles, 8 one workgroup per frame in the shared-query one-tile form, 16 its frame-pair form with plain (not nontemporal) stores"),
     "M324_ATTN_PWG": ("1", "attention forward, long sequences: 1 = one wave per SIMD with the hand-placed stream (attention_pwg.hip), 0 = the eight-wave kernel"),
     "M324_QKV_RING": ("1", "128 x 128 chunk ring (v13) instead of the two-stage v2: bit 0 for the fused q|k|v projection (head-major epilogue), bit 1 for plain bf16 outputs (A/B)"),

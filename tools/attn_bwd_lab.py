@@ -50,12 +50,12 @@ def timeit():
 
 
 flops = 7 * 2.0 * B * H * L * L * 64        # dQ kernel 3 GEMMs, dK/dV kernel 4
-res = {4: [], 8: [], 2: []}
+res = {4: [], 8: [], 2: [], 84: [], 48: []}
 for rnd in range(5):                         # interleaved: the clock drifts by several percent within a process
-    for nw in (4, 8, 2):                     # 2 (round 6): the dQ kernel with 64 queries per wave, four waves; dK/dV as with 8
+    for nw in (4, 8, 2, 84, 48):             # 84: dQ eight waves + dK/dV four; 48: the reverse; 2 (round 6): the dQ kernel with 64 queries per wave, four waves; dK/dV as with 8
         lib.set_tunable("M324_ATTN_BWD_NW", nw)
         res[nw].append(timeit())
-for nw in (4, 8, 2):
+for nw in (4, 8, 2, 84, 48):
     ms = sorted(res[nw])[len(res[nw]) // 2]
     print(f"B={B} H={H} L={L} M324_ATTN_BWD_NW={nw}: dQ + dK/dV {ms * 1e3:.1f} us per call = {flops / ms / 1e9:.0f} TF/s (median of 5 interleaved rounds)", flush=True)
 lib.set_tunable("M324_ATTN_BWD_NW", 0)
