@@ -398,6 +398,20 @@ int m324_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
  * dim() > 1, training_utils.py:39-47), elements [n_decay, n) take none.  n, n_decay multiples of 4; 16-byte aligned. */
 int m324_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, const float* grad_scale, void* stream);
+/* bf16 copies of the optimizer's flat fp32 parameter buffer in ONE launch (ABI 21): for every item (a Linear weight [rows, cols],
+ * src_off elements into `src`) the row-major copy at dst + dst_off (the forward GEMM's operand) and, when dstT_off >= 0, the
+ * transposed copy [cols, ldT] at dstT + dstT_off (the dgrad GEMM's operand; columns [rows, ldT) are never written: the caller
+ * zeroes the buffer once).  Round to nearest even, as torch's .to(bfloat16).  items_dev: DEVICE memory (the table is constant
+ * between optimizer steps), ordered by first_tile = the number of 64 x 64 tiles in front of the item; n_tiles = their total.
+ *   replaces: the per-step torch casts + m324_transpose launches of every weight after optimizer.step()
+ *             (train.py:203-213: the reference's autocast re-casts each weight inside every Linear call instead). */
+typedef struct m324_mirror_item {
+    long src_off, dst_off, dstT_off;
+    long first_tile;
+    int rows, cols, ldT, pad_;
+} m324_mirror_item;
+int m324_weight_mirror(const float* src, void* dst, void* dstT, const m324_mirror_item* items_dev, int n_items, long n_tiles,
+                       void* stream);
 /* *out (+)= sum g^2 (gradient-norm pieces); sanitize != 0 first applies nan_to_num(0, 1e-6, -1e-6) in place
  * (train.py:181-183).  partial: >= 1024 floats of scratch. */
 int m324_grad_sumsq(float* g, long n, int sanitize, float* partial, float* out, int accumulate, void* stream);

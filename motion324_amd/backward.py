@@ -163,7 +163,7 @@ def weight_grad(dy: torch.Tensor, a: torch.Tensor, out: Optional[torch.Tensor] =
 
 def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
     """[K', N_pad] transposed GEMM operand of a weight (for dgrad), cached like P.mat."""
-    return P.derived("matT", (weight,), lambda: ops.transpose(P.mat(weight)))
+    return P.mat_t(weight, ops.transpose)
 
 
 def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: torch.Tensor, need_da: bool = True,

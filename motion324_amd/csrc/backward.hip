@@ -271,6 +271,41 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float4* __restrict__ p,
     }
 }
 
+// bf16 copies of the optimizer's flat fp32 parameters, row-major AND transposed, in ONE launch (m324_weight_mirror): the forward /
+// dgrad GEMM operands of every Linear weight after an update.  One workgroup per 64 x 64 tile; the item of a tile by binary search
+// over the items' first-tile numbers (the table lives in device memory: it never changes between steps).
+__global__ __launch_bounds__(256) void weight_mirror_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, bf16_t* __restrict__ dstT,
+                                                            const m324_mirror_item* __restrict__ items, int n_items) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n_items - 1;
+    const long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_tile <= b) lo = mid; else hi = mid - 1;
+    }
+    const m324_mirror_item it = items[lo];
+    const int tc = (it.cols + 63) / 64, tl = (int)(b - it.first_tile);
+    const int r0 = (tl / tc) * 64, c0 = (tl % tc) * 64, t = threadIdx.x;
+    const float* s = src + it.src_off;
+    bf16_t* d = dst + it.dst_off;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int id = t + 256 * i, r = id >> 6, c = id & 63;
+        const bool in = r0 + r < it.rows && c0 + c < it.cols;
+        const float x = in ? s[(long)(r0 + r) * it.cols + c0 + c] : 0.f;
+        tile[r][c] = x;
+        if (in) d[(long)(r0 + r) * it.cols + c0 + c] = f32_to_bf16(x);
+    }
+    if (it.dstT_off < 0) return;
+    __syncthreads();
+    bf16_t* dT = dstT + it.dstT_off;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int id = t + 256 * i, c = id >> 6, r = id & 63;
+        if (c0 + c < it.cols && r0 + r < it.rows) dT[(long)(c0 + c) * it.ldT + r0 + r] = f32_to_bf16(tile[r][c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void grad_sanitize_sumsq_kernel(float* __restrict__ g, long n, int sanitize,
                                                                   float* __restrict__ partial) {
     __shared__ float red[4];
@@ -414,6 +449,15 @@ extern "C" int m324_adamw_flat(float* p, const float* g, float* m, float* v, lon
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (float4*)p, (const float4*)g,
                        (float4*)m, (float4*)v, n / 4, n_decay / 4, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
     M324_CHECK_LAUNCH("m324_adamw_flat");
+    return M324_OK;
+}
+
+extern "C" int m324_weight_mirror(const float* src, void* dst, void* dstT, const m324_mirror_item* items_dev, int n_items, long n_tiles,
+                                  void* stream) {
+    M324_REQUIRE(src && dst && items_dev && n_items > 0 && n_tiles > 0 && n_tiles <= 0x7FFFFFFFL, "m324_weight_mirror: bad arguments");
+    hipLaunchKernelGGL(weight_mirror_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (bf16_t*)dstT,
+                       items_dev, n_items);
+    M324_CHECK_LAUNCH("m324_weight_mirror");
     return M324_OK;
 }
 

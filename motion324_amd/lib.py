@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 20
+ABI_VERSION = 21
 ERR_UNSUPPORTED = -3          # m324_status M324_ERR_UNSUPPORTED
 
 
@@ -49,6 +49,11 @@ class GemmArgs(C.Structure):
 class ColsumItem(C.Structure):
     _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("ld", C.c_long), ("rows", C.c_int), ("cols", C.c_int),
                 ("accumulate", C.c_int), ("chain", C.c_int)]
+
+
+class MirrorItem(C.Structure):
+    _fields_ = [("src_off", C.c_long), ("dst_off", C.c_long), ("dstT_off", C.c_long), ("first_tile", C.c_long), ("rows", C.c_int),
+                ("cols", C.c_int), ("ldT", C.c_int), ("pad_", C.c_int)]
 
 
 _P, _L, _I, _F = C.c_void_p, C.c_long, C.c_int, C.c_float
@@ -99,6 +104,7 @@ SIGNATURES = {
     "m324_mse_bwd": [_P, _P, _P, _F, _P, _L, _P],
     "m324_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "m324_adamw_flat": [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _I, _P, _P],
+    "m324_weight_mirror": [_P, _P, _P, _P, _I, _L, _P],
     "m324_grad_sumsq": [_P, _L, _I, _P, _P, _I, _P],
     "m324_comm_unique_id": [C.c_char_p, _I],
     "m324_comm_init": [C.POINTER(C.c_void_p), C.c_char_p, _I, _I],

@@ -896,6 +896,15 @@ def adamw_flat(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
                                      step, _p(grad_scale), _stream()), "m324_adamw_flat")
 
 
+def weight_mirror(src: torch.Tensor, dst: torch.Tensor, dstT: Optional[torch.Tensor], table: torch.Tensor, n_items: int, n_tiles: int) -> None:
+    """bf16 row-major and transposed copies of the Linear weights inside a flat fp32 parameter buffer, one launch
+    (m324_weight_mirror; table: the items as a device byte tensor, see lib.MirrorItem)."""
+    if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or (dstT is not None and dstT.dtype != torch.bfloat16) or table.dtype != torch.uint8 \
+            or table.numel() != n_items * C.sizeof(L.MirrorItem) or not table.is_cuda:
+        raise L.M324Error("weight_mirror: fp32 source, bf16 copies and a device table of lib.MirrorItem records")
+    L.check(L.load().m324_weight_mirror(_p(src), _p(dst), _p(dstT), _p(table), n_items, n_tiles, _stream()), "m324_weight_mirror")
+
+
 def grad_sumsq(g: torch.Tensor, out: torch.Tensor, partial: torch.Tensor, sanitize: bool, accumulate: bool) -> None:
     L.check(L.load().m324_grad_sumsq(_p(g), g.numel(), int(sanitize), _p(partial), _p(out), int(accumulate), _stream()),
             "m324_grad_sumsq")

@@ -30,7 +30,11 @@ import torch.distributed as dist
 
 from . import lib as L
 from . import ops, parallel
+from . import prepared, switches
 from .prepared import bump_generation
+
+
+WEIGHT_MIRROR = switches.flag("M324_WEIGHT_MIRROR")
 
 
 def cosine_with_warmup(step: int, warmup: int, total: int, base_lr: float) -> float:
@@ -126,6 +130,9 @@ class FusedAdamW:
                     p.data = view              # the parameter now lives in the flat buffer
         if flatten:
             bump_generation()                  # parameter storage moved: drop cached kernel-ready copies
+        self._mirror_params: List[torch.nn.Parameter] = []
+        if flatten and WEIGHT_MIRROR:
+            self._build_mirror(dev)
         self.step_count = 0
         self._partial = torch.empty(1024, dtype=torch.float32, device=dev)
         self._sumsq = torch.zeros((), dtype=torch.float32, device=dev)
@@ -143,6 +150,48 @@ class FusedAdamW:
         self._bucket_of = {i: b for b, (_, _, mem) in enumerate(self.buckets) for i in mem}
         self._comm_stream: Optional[torch.cuda.Stream] = None
         self._reset_reduce_state()
+
+    # ------------------------------------------------------------------ bf16 weight mirror
+    def _build_mirror(self, dev: torch.device) -> None:
+        """bf16 copies of every Linear weight of the flat parameter buffer -- [N, K] for the forward GEMMs, [K, round_up(N, 64)] for
+        the dgrad GEMMs -- in two flat buffers that ONE m324_weight_mirror launch rewrites after each update (instead of ~115 torch
+        casts and ~90 m324_transpose launches per step: Prepared hands the views out while they are current, prepared.register_mirror).
+        Weights whose K is not a multiple of the GEMM's K-tile (the 51- and 774-wide point embeddings) stay on Prepared's padding path."""
+        import ctypes as C
+        items, o, ot, tiles = [], 0, 0, 0
+        for i, p in enumerate(self.params):
+            if p.dim() != 2:              # Linear weights only (the token tables are not GEMM operands)
+                continue
+            n, k = p.shape
+            if k % prepared.K_ALIGN != 0:
+                continue
+            ldt = (n + 63) // 64 * 64
+            items.append((i, self.offsets[i], o, ot, tiles, n, k, ldt))
+            o += (n * k + 63) // 64 * 64
+            ot += k * ldt
+            tiles += ((n + 63) // 64) * ((k + 63) // 64)
+        if not items:
+            return
+        self._mirror = torch.empty(o, dtype=torch.bfloat16, device=dev)
+        self._mirror_t = torch.zeros(ot, dtype=torch.bfloat16, device=dev)          # the pad columns of the transposed copies stay zero
+        arr = (L.MirrorItem * len(items))()
+        for j, (i, so, do, dto, ft, n, k, ldt) in enumerate(items):
+            arr[j].src_off, arr[j].dst_off, arr[j].dstT_off, arr[j].first_tile = so, do, dto, ft
+            arr[j].rows, arr[j].cols, arr[j].ldT = n, k, ldt
+            p = self.params[i]
+            prepared.register_mirror(p, self._mirror[do:do + n * k].view(n, k), self._mirror_t[dto:dto + k * ldt].view(k, ldt), self._mirror, do)
+            self._mirror_params.append(p)
+        self._mirror_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self._mirror_n, self._mirror_tiles = len(items), tiles
+        self.sync_mirror()
+
+    def sync_mirror(self) -> None:
+        """Rewrites the bf16 weight copies from the flat parameters as they are now (after an update, or after anything else wrote
+        the parameters: load_state_dict, a manual edit) and vouches for them."""
+        if not self._mirror_params:
+            return
+        ops.weight_mirror(self.flat_param, self._mirror, self._mirror_t, self._mirror_table, self._mirror_n, self._mirror_tiles)
+        prepared.validate_mirrors(self._mirror_params)
 
     # ------------------------------------------------------------------ gradient buffer
     def owns(self, p) -> bool:
@@ -261,6 +310,8 @@ class FusedAdamW:
                     ops.adamw_step(p.data.view(-1), self.flat_grad[o:o + n], self.m[o:o + n], self.v[o:o + n], lr, self.betas[0],
                                    self.betas[1], self.eps, self.wd if self.decay[i] else 0.0, self.step_count, self._gscale)
             bump_generation()           # the kernel wrote parameter memory behind torch's back: drop cached bf16 copies
+            if self.flatten:
+                self.sync_mirror()      # ... and rewrite the ones this optimizer keeps itself
         return {"grad_norm": norm, "skipped": skipped}
 
     def zero_grad(self, set_to_none: bool = True) -> None:

@@ -63,6 +63,48 @@ def weight_stamp(module: torch.nn.Module) -> int:
     return h
 
 
+class _Mirror:
+    __slots__ = ("ref", "mat", "mat_t", "gen", "ptr", "version", "base", "off")
+
+
+_MIRRORS: Dict[int, _Mirror] = {}
+
+
+def register_mirror(p: torch.Tensor, mat: torch.Tensor, mat_t: Optional[torch.Tensor], base: Optional[torch.Tensor] = None, off: int = 0) -> None:
+    """An optimizer that keeps bf16 copies of its parameters current itself (optim.FusedAdamW: one m324_weight_mirror launch per step
+    over its flat parameter buffer) registers them here: mat [N, K] row-major and mat_t [K, round_up(N, 64)] for parameter p.  A copy
+    is handed out by Prepared.mat / mat_t while validate_mirrors() has vouched for it SINCE the last change Prepared would notice
+    (generation counter, the tensor's in-place version, its storage address); otherwise Prepared converts as for any parameter.
+    base / off: the flat bf16 buffer mat is a view of and mat's first element in it (Prepared.cat_rows hands out ONE view over
+    neighbouring weights -- the k and v projections of a cross-attention -- instead of concatenating copies)."""
+    e = _Mirror()
+    e.base, e.off = base, off
+    e.ref, e.mat, e.mat_t, e.gen, e.ptr, e.version = weakref.ref(p, lambda _r, k=id(p): _MIRRORS.pop(k, None)), mat, mat_t, -1, 0, -1
+    _MIRRORS[id(p)] = e
+
+
+def validate_mirrors(ps: Sequence[torch.Tensor]) -> None:
+    """The registered copies of these parameters were (re)written from their current values just now."""
+    for p in ps:
+        e = _MIRRORS.get(id(p))
+        if e is not None and e.ref() is p:
+            e.gen, e.ptr, e.version = _GENERATION, p.data_ptr(), p._version
+
+
+def drop_mirrors(ps: Sequence[torch.Tensor]) -> None:
+    for p in ps:
+        _MIRRORS.pop(id(p), None)
+
+
+def _mirror(p: torch.Tensor, dtype: torch.dtype, device: torch.device) -> Optional[_Mirror]:
+    e = _MIRRORS.get(id(p))
+    device = torch.device(device)
+    if e is None or dtype != torch.bfloat16 or e.gen != _GENERATION or e.ref() is not p or e.ptr != p.data_ptr() or e.version != p._version \
+            or e.mat.device.type != device.type or (device.index is not None and e.mat.device.index != device.index):
+        return None
+    return e
+
+
 def pad_k(k: int) -> int:
     return (k + K_ALIGN - 1) // K_ALIGN * K_ALIGN
 
@@ -114,10 +156,26 @@ class Prepared:
 
     def mat(self, p: torch.Tensor) -> torch.Tensor:
         """[N, K'] compute-dtype GEMM operand of a Linear/Conv weight (flattened, K zero-padded to 64)."""
+        e = _mirror(p, self.dtype, self.device) if _MIRRORS else None
+        if e is not None:
+            return e.mat
         return self._get("mat", (p,), lambda: self._mat_of(p))
+
+    def mat_t(self, p: torch.Tensor, transpose) -> torch.Tensor:
+        """[K', round_up(N, 64)] transposed operand (the dgrad GEMMs'): the optimizer's mirror when it is current, else
+        transpose(self.mat(p)), cached like mat."""
+        e = _mirror(p, self.dtype, self.device) if _MIRRORS else None
+        if e is not None and e.mat_t is not None:
+            return e.mat_t
+        return self.derived("matT", (p,), lambda: transpose(self.mat(p)))
 
     def cat_rows(self, ps: Sequence[torch.Tensor]) -> torch.Tensor:
         """Several [N_i, K] weights stacked along N (one GEMM for k and v projections)."""
+        es = [_mirror(p, self.dtype, self.device) for p in ps] if _MIRRORS else [None]
+        if all(e is not None and e.base is not None for e in es) and all(e.base is es[0].base and e.mat.shape[1] == es[0].mat.shape[1] for e in es) \
+                and all(es[i].off + es[i].mat.numel() == es[i + 1].off for i in range(len(es) - 1)):
+            k = es[0].mat.shape[1]
+            return es[0].base[es[0].off:es[-1].off + es[-1].mat.numel()].view(-1, k)
         return self._get("cat", tuple(ps), lambda: torch.cat([self._mat_of(p) for p in ps], dim=0).contiguous())
 
     def vec(self, p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:

@@ -53,6 +53,16 @@ def test_gemm_args_struct_layout_matches_header():
         and ctypes.sizeof(GemmArgs) == 288
 
 
+def test_mirror_item_struct_layout_matches_header():
+    """m324_mirror_item (include/m324.h, ABI 21): four longs, four ints."""
+    from motion324_amd.lib import MirrorItem
+    assert [f[0] for f in MirrorItem._fields_] == ["src_off", "dst_off", "dstT_off", "first_tile", "rows", "cols", "ldT", "pad_"]
+    assert MirrorItem.first_tile.offset == 24 and MirrorItem.rows.offset == 32 and MirrorItem.ldT.offset == 40 and ctypes.sizeof(MirrorItem) == 48
+    text = open(os.path.join(REPO, "include", "m324.h")).read()
+    body = re.search(r"typedef struct m324_mirror_item \{(.*?)\} m324_mirror_item;", text, flags=re.S).group(1)
+    assert re.sub(r"\s+", " ", body).strip() == "long src_off, dst_off, dstT_off; long first_tile; int rows, cols, ldT, pad_;"
+
+
 def test_errors_are_reported_not_thrown_across_the_abi():
     """Argument validation happens before any HIP call, so it is observable without a GPU."""
     from motion324_amd import lib

@@ -122,6 +122,62 @@ def test_queued_column_sums_give_the_same_training_step(monkeypatch):
         assert worst < 1e-5 and exact >= len(g0) // 2
 
 
+def test_weight_mirror_gives_the_same_training_steps(monkeypatch):
+    """optim.FusedAdamW's bf16 weight mirror (one m324_weight_mirror launch per update instead of a cast per weight and a
+    m324_transpose per dgrad operand): every copy equals torch's cast / its transpose bit for bit, Prepared hands the mirror's
+    views out exactly while they are current, and three steps give the same losses and parameters with and without it."""
+    import motion324_amd as m
+    from motion324_amd import optim, prepared, synth, training
+    from motion324_amd.optim import FusedAdamW, backward_completion_order
+    from conftest import CASES, synth_sd
+    dims, (B, T, N, S, HW) = CASES["tiny"]["dims"], CASES["tiny"]["shape"]
+    dm = synth.Dims(**dims)
+    cfg = synth.make_config(frames=dm.frames, d=dm.d, d_head=dm.d_head, tokens=dm.tokens, pcd_layers=dm.pcd_layers, n_layer=dm.n_layer)
+    cfg["model"]["dino"] = {"depth": dm.dino_depth}
+    sample = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_inputs(B, T, N, S, HW, seed=1, with_target=True).items()}
+    res = {}
+    m.set_precision("bf16")
+    try:
+        for mirror in (False, True):
+            monkeypatch.setattr(optim, "WEIGHT_MIRROR", mirror)
+            model = m.Motion_Latent_Model(cfg)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_sd(dims).items()}, strict=False)
+            model = model.train().to(DEV)
+            model.drop_rate = 0.0
+            opt = FusedAdamW(model.named_parameters(), lr=1e-3, allowed_gradnorm_factor=1e9, order=backward_completion_order(model))
+            P = prepared.Prepared.for_module(model, DEV, torch.bfloat16)
+            losses = []
+            for _ in range(3):
+                loss, _, _ = training.forward_backward(model, sample, sink=opt)
+                opt.finish_reduce()
+                assert not opt.step()["skipped"]
+                losses.append(float(loss))
+            if mirror:
+                w = model.global_transformer_blocks[0].attn.to_qkv.weight
+                assert len(opt._mirror_params) > 10 and any(p is w for p in opt._mirror_params)
+                for p in opt._mirror_params:
+                    got, got_t = P.mat(p), P.mat_t(p, None)                     # (None: a call of the fallback would raise)
+                    assert got.data_ptr() >= opt._mirror.data_ptr() and torch.equal(got, p.detach().to(torch.bfloat16))
+                    n = p.shape[0]
+                    assert got_t.shape == (p.shape[1], (n + 63) // 64 * 64) and torch.equal(got_t[:, :n], got.t()) and not got_t[:, n:].any()
+                ca = model.decoder_cross_attn.attn
+                kv = P.cat_rows((ca.to_k.weight, ca.to_v.weight))
+                assert kv.data_ptr() == P.mat(ca.to_k.weight).data_ptr()      # neighbours in the flat buffer: one view, no copy
+                assert torch.equal(kv, torch.cat([ca.to_k.weight, ca.to_v.weight]).to(torch.bfloat16))
+                with torch.no_grad():
+                    w.mul_(1.0)                                                 # a tracked in-place edit: the mirror is stale ...
+                assert P.mat(w).data_ptr() != got.data_ptr() or w is not p
+                assert not (opt._mirror.data_ptr() <= P.mat(w).data_ptr() < opt._mirror.data_ptr() + opt._mirror.numel() * 2)
+                opt.sync_mirror()                                               # ... until the optimizer rewrites it
+                assert opt._mirror.data_ptr() <= P.mat(w).data_ptr() < opt._mirror.data_ptr() + opt._mirror.numel() * 2
+            res[mirror] = (losses, {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad})
+    finally:
+        m.set_precision(None)
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for n, p in res[False][1].items():
+        assert torch.equal(p, res[True][1][n]), n
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gelu_forward_backward(dtype):
     from motion324_amd import ops
@@ -387,7 +443,7 @@ def test_cross_attn_block_backward_vs_oracle_autograd(dtype, shared):
                                                (1, 12, 324, 324, False), (1, 2, 700, 129, False)])
 def test_attention_backward_mfma_against_autograd(tune, nw, B, H, Lq, Lk, shared):
     """bf16 MFMA backward kernels (through qkv_split's train outputs) vs fp64 autograd and vs the reference kernels;
-    both workgroup sizes (M324_ATTN_BWD_NW; default: 8 waves from 256 keys on)."""
+    both workgroup sizes (M324_ATTN_BWD_NW; default: four waves)."""
     from motion324_amd import ops
     tune("M324_ATTN_BWD_NW", nw)
     dtype = torch.bfloat16

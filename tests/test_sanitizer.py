@@ -73,6 +73,7 @@ items = (L.ColsumItem * 3)()
 assert h.m324_colsum_multi(None, 0, None) < 0 and h.m324_colsum_multi(items, 3, None) < 0          # null pointers in the items
 items[0].dst, items[0].src, items[0].ld, items[0].rows, items[0].cols, items[0].chain = 4096, 4096, 8, 2, 8, 1
 assert h.m324_colsum_multi(items, 1, None) < 0                                                       # a chain without a head
+assert h.m324_weight_mirror(None, None, None, None, 0, 0, None) < 0 and h.m324_weight_mirror(16, 16, None, 16, 1, 0, None) < 0
 hexbuf = C.create_string_buffer(16)
 assert h.m324_comm_unique_id(hexbuf, 16) < 0          # n < 257: refused before RCCL is looked up
 print("SAN_OK", n_plans, n_attn)
