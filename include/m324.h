@@ -398,9 +398,9 @@ int m324_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
  * dim() > 1, training_utils.py:39-47), elements [n_decay, n) take none.  n, n_decay multiples of 4; 16-byte aligned. */
 int m324_adamw_flat(float* p, const float* g, float* m, float* v, long n, long n_decay, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, const float* grad_scale, void* stream);
-/* bf16 copies of the optimizer's flat fp32 parameter buffer in ONE launch (ABI 21): for every item (a Linear weight [rows, cols],
- * src_off elements into `src`) the row-major copy at dst + dst_off (the forward GEMM's operand) and, when dstT_off >= 0, the
- * transposed copy [cols, ldT] at dstT + dstT_off (the dgrad GEMM's operand; columns [rows, ldT) are never written: the caller
+/* bf16 copies of the optimizer's flat fp32 parameter buffer in ONE launch (ABI 21): for every item (a Linear weight [rows, cols], cols a
+ * multiple of 64, src_off -- a multiple of 4 -- elements into `src`) the row-major copy at dst + dst_off (the forward GEMM's operand) and, when dstT_off >= 0, the
+ * transposed copy [cols, ldT] at dstT + dstT_off (the dgrad GEMM's operand; columns [rows, ldT) receive nothing but zeros: the caller
  * zeroes the buffer once).  Round to nearest even, as torch's .to(bfloat16).  items_dev: DEVICE memory (the table is constant
  * between optimizer steps), ordered by first_tile = the number of 64 x 64 tiles in front of the item; n_tiles = their total.
  *   replaces: the per-step torch casts + m324_transpose launches of every weight after optimizer.step()

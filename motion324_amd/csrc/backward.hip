@@ -284,41 +284,78 @@ __global__ __launch_bounds__(256) void weight_mirror_kernel(const float* __restr
         if (items[mid].first_tile <= b) lo = mid; else hi = mid - 1;
     }
     const m324_mirror_item it = items[lo];
-    const int tc = (it.cols + 63) / 64, tl = (int)(b - it.first_tile);
+    const int tc = it.cols >> 6, tl = (int)(b - it.first_tile);          // cols is a multiple of 64: every column tile is whole
     const int r0 = (tl / tc) * 64, c0 = (tl % tc) * 64, t = threadIdx.x;
     const float* s = src + it.src_off;
     bf16_t* d = dst + it.dst_off;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int id = t + 256 * i, r = id >> 6, c = id & 63;
-        const bool in = r0 + r < it.rows && c0 + c < it.cols;
-        const float x = in ? s[(long)(r0 + r) * it.cols + c0 + c] : 0.f;
-        tile[r][c] = x;
-        if (in) d[(long)(r0 + r) * it.cols + c0 + c] = f32_to_bf16(x);
+    for (int i = 0; i < 4; ++i) {               // 16 rows per pass: a lane takes four consecutive values (16 bytes in, 8 out)
+        const int r = 16 * i + (t >> 4), c = (t & 15) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < it.rows) {
+            x = *reinterpret_cast<const float4*>(s + (long)(r0 + r) * it.cols + c0 + c);
+            *reinterpret_cast<uint2*>(d + (long)(r0 + r) * it.cols + c0 + c) = make_uint2(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w));
+        }
+        tile[r][c] = x.x; tile[r][c + 1] = x.y; tile[r][c + 2] = x.z; tile[r][c + 3] = x.w;
     }
     if (it.dstT_off < 0) return;
     __syncthreads();
     bf16_t* dT = dstT + it.dstT_off;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int id = t + 256 * i, c = id >> 6, r = id & 63;
-        if (c0 + c < it.cols && r0 + r < it.rows) dT[(long)(c0 + c) * it.ldT + r0 + r] = f32_to_bf16(tile[r][c]);
+    for (int i = 0; i < 8; ++i) {               // 8 transposed rows per pass: a lane packs two neighbouring source rows (4 bytes out)
+        const int c = 8 * i + (t >> 5), r = (t & 31) * 2;
+        if (r0 + r < it.rows)                   // (a row count is never odd inside a tile that has its second row: rows past the end are zeros
+            *reinterpret_cast<uint32_t*>(dT + (long)(c0 + c) * it.ldT + r0 + r) = pack_bf16x2(tile[r][c], tile[r + 1][c]);      //  and land in the pad)
     }
 }
 
+__device__ __forceinline__ float sanitized(float x, bool& changed) {      // nan_to_num(0, 1e-6, -1e-6), train.py:181-183
+    if (x != x) { changed = true; return 0.f; }
+    if (x == INFINITY) { changed = true; return 1e-6f; }
+    if (x == -INFINITY) { changed = true; return -1e-6f; }
+    return x;
+}
+
+// VEC: 16-byte accesses, four of them in flight per lane and pass (the 628 MB flat gradient buffer in one launch of at most 1024
+// workgroups: with one 4-byte load per lane and pass the kernel ran at 1 TB/s), and a value is written back only when the
+// sanitizer changed it (never, in a healthy step).  Fixed summation order per lane, wave, workgroup: deterministic.
+template <bool VEC>
 __global__ __launch_bounds__(256) void grad_sanitize_sumsq_kernel(float* __restrict__ g, long n, int sanitize,
                                                                   float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float x = g[i];
-        if (sanitize) {
-            if (x != x) x = 0.f;
-            else if (x == INFINITY) x = 1e-6f;
-            else if (x == -INFINITY) x = -1e-6f;
-            g[i] = x;
+    const long stride = (long)gridDim.x * 256;
+    if (VEC) {
+        float4* g4 = reinterpret_cast<float4*>(g);
+        const long n4 = n >> 2;
+        auto one = [&](long i, float4 x) {
+            if (sanitize) {
+                bool ch = false;
+                x.x = sanitized(x.x, ch); x.y = sanitized(x.y, ch); x.z = sanitized(x.z, ch); x.w = sanitized(x.w, ch);
+                if (ch) g4[i] = x;
+            }
+            s += x.x * x.x; s += x.y * x.y; s += x.z * x.z; s += x.w * x.w;
+        };
+        long i = (long)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+            one(i, a); one(i + stride, b); one(i + 2 * stride, c); one(i + 3 * stride, d);
         }
-        s += x * x;
+        for (; i < n4; i += stride) one(i, g4[i]);
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {       // the last n % 4 values
+            const long k = (n4 << 2) + threadIdx.x;
+            bool ch = false;
+            const float x = sanitize ? sanitized(g[k], ch) : g[k];
+            if (ch) g[k] = x;
+            s += x * x;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            bool ch = false;
+            const float x = sanitize ? sanitized(g[i], ch) : g[i];
+            if (ch) g[i] = x;
+            s += x * x;
+        }
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -455,6 +492,7 @@ extern "C" int m324_adamw_flat(float* p, const float* g, float* m, float* v, lon
 extern "C" int m324_weight_mirror(const float* src, void* dst, void* dstT, const m324_mirror_item* items_dev, int n_items, long n_tiles,
                                   void* stream) {
     M324_REQUIRE(src && dst && items_dev && n_items > 0 && n_tiles > 0 && n_tiles <= 0x7FFFFFFFL, "m324_weight_mirror: bad arguments");
+    M324_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0 && ((uintptr_t)dstT % 4) == 0, "m324_weight_mirror: unaligned buffers");
     hipLaunchKernelGGL(weight_mirror_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (bf16_t*)dstT,
                        items_dev, n_items);
     M324_CHECK_LAUNCH("m324_weight_mirror");
@@ -463,9 +501,11 @@ extern "C" int m324_weight_mirror(const float* src, void* dst, void* dstT, const
 
 extern "C" int m324_grad_sumsq(float* g, long n, int sanitize, float* partial, float* out, int accumulate, void* stream) {
     M324_REQUIRE(g && partial && out && n > 0, "m324_grad_sumsq: bad arguments");
-    const int nb = grid_for(n) < 1024 ? grid_for(n) : 1024;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(grad_sanitize_sumsq_kernel, dim3(nb), dim3(256), 0, s, g, n, sanitize, partial);
+    const bool vec = ((uintptr_t)g % 16) == 0 && n >= 4096;
+    const int nb = vec ? (grid_for(n / 16) < 1024 ? grid_for(n / 16) : 1024) : (grid_for(n) < 1024 ? grid_for(n) : 1024);
+    if (vec) hipLaunchKernelGGL(grad_sanitize_sumsq_kernel<true>, dim3(nb), dim3(256), 0, s, g, n, sanitize, partial);
+    else hipLaunchKernelGGL(grad_sanitize_sumsq_kernel<false>, dim3(nb), dim3(256), 0, s, g, n, sanitize, partial);
     hipLaunchKernelGGL(sum_partial_kernel, dim3(1), dim3(64), 0, s, partial, nb, out, accumulate);
     M324_CHECK_LAUNCH("m324_grad_sumsq");
     return M324_OK;

@@ -361,6 +361,21 @@ def test_adamw_matches_torch_and_grad_norm():
     clean = torch.nan_to_num(gg, nan=0.0, posinf=1e-6, neginf=-1e-6)
     assert torch.equal(gd.cpu(), clean)
     assert abs(float(out) - float((clean.double() ** 2).sum())) < 1e-3
+    # the 16-byte form (aligned buffers of 4096 values and more; tail of n % 4 values) and the scalar form on an unaligned view
+    big = _rand((1_000_003 + 1,), 29)
+    for off in (0, 1):
+        gg = big[off:off + 1_000_003 - off].clone()
+        gg[3], gg[500_001], gg[-1], gg[-2] = float("nan"), float("inf"), float("-inf"), float("nan")
+        gd = big.to(DEV)[off:off + gg.numel()]
+        gd.copy_(gg)
+        assert (gd.data_ptr() % 16 == 0) == (off == 0)
+        ops.grad_sumsq(gd, out, partial, sanitize=True, accumulate=False)
+        clean = torch.nan_to_num(gg, nan=0.0, posinf=1e-6, neginf=-1e-6)
+        assert torch.equal(gd.cpu(), clean)
+        want = float((clean.double() ** 2).sum())
+        assert abs(float(out) - want) < 1e-5 * want
+        ops.grad_sumsq(gd, out, partial, sanitize=False, accumulate=True)
+        assert abs(float(out) - 2 * want) < 1e-5 * want
 
 
 def _autograd_block(kind, sd, x, *args):
