@@ -217,6 +217,68 @@ __global__ __launch_bounds__(256) void linear_n3_bwd_kernel(const T* __restrict_
     }
 }
 
+// The same with 16-byte accesses (K % 8 == 0, K <= 2048, aligned rows): thread t owns the 8-column chunk t % (K / 8) of the rows
+// rs, rs + nrs, ... of its workgroup's share (nrs = 256 / (K / 8) rows side by side; K = 768: 96 chunks x 2 rows, 192 busy
+// threads), four rows in flight per thread; the row slots' sums meet in LDS in a fixed order.  The scalar kernel above moved two
+// bytes per lane and access: 134 us for the 49152 x 768 head of one training sample (150 MB), this one ~35.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_n3_bwd_vec_kernel(const T* __restrict__ A, long lda, const float* __restrict__ W,
+                                                                const float* __restrict__ dout, T* __restrict__ dA, long ldda,
+                                                                float* __restrict__ partial, int M, int K) {
+    extern __shared__ float red[];              // [nrs - 1][3][K]
+    const int nch = K >> 3, nrs = 256 / nch, t = threadIdx.x;
+    const int ch = t % nch, rs = t / nch;
+    float w[3][8], sum[3][8];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        load8(W + (long)j * K + ch * 8, w[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[j][e] = 0.f;
+    }
+    if (rs < nrs) {
+        const long step = (long)gridDim.x * nrs;
+        auto row = [&](long m, const float (&a)[8]) {
+            const float d0 = dout[m * 3], d1 = dout[m * 3 + 1], d2 = dout[m * 3 + 2];
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sum[0][e] += d0 * a[e]; sum[1][e] += d1 * a[e]; sum[2][e] += d2 * a[e];
+                o[e] = d0 * w[0][e] + d1 * w[1][e] + d2 * w[2][e];
+            }
+            store8(dA + m * ldda + ch * 8, o);
+        };
+        long m = (long)blockIdx.x * nrs + rs;
+        for (; m + 3 * step < M; m += 4 * step) {
+            float a0[8], a1[8], a2[8], a3[8];
+            load8(A + m * lda + ch * 8, a0); load8(A + (m + step) * lda + ch * 8, a1);
+            load8(A + (m + 2 * step) * lda + ch * 8, a2); load8(A + (m + 3 * step) * lda + ch * 8, a3);
+            row(m, a0); row(m + step, a1); row(m + 2 * step, a2); row(m + 3 * step, a3);
+        }
+        for (; m < M; m += step) {
+            float a0[8];
+            load8(A + m * lda + ch * 8, a0);
+            row(m, a0);
+        }
+        if (rs > 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[((long)(rs - 1) * 3 + j) * K + ch * 8 + e] = sum[j][e];
+        }
+    }
+    __syncthreads();
+    if (rs == 0) {
+        float* pr = partial + (long)blockIdx.x * 3 * K;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            for (int r = 1; r < nrs; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum[j][e] += red[((long)(r - 1) * 3 + j) * K + ch * 8 + e];
+            store8(pr + (long)j * K + ch * 8, sum[j]);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------- loss backward
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                       const float* __restrict__ gscale, float coef, float* __restrict__ d, long n) {
@@ -451,6 +513,17 @@ extern "C" int m324_linear_n3_bwd(const void* A, long lda, const float* W, const
                                   int n_partial, int M, int K, int dtype, void* stream) {
     M324_REQUIRE(A && W && dout && dA && partial && n_partial > 0 && M > 0 && K > 0, "m324_linear_n3_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    const int esz = dtype == M324_BF16 ? 2 : 4;
+    if (K % 8 == 0 && K >= 64 && K <= 2048 && (lda * esz) % 16 == 0 && (ldda * esz) % 16 == 0 && ((uintptr_t)A % 16) == 0 &&
+        ((uintptr_t)dA % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)partial % 16) == 0) {
+        const int nrs = 256 / (K / 8);
+        const size_t lds = (size_t)(nrs - 1) * 3 * K * sizeof(float);
+        DISPATCH_DTYPE(dtype, "m324_linear_n3_bwd",
+                       hipLaunchKernelGGL(linear_n3_bwd_vec_kernel<T>, dim3(n_partial), dim3(256), lds, s, (const T*)A, lda, W, dout,
+                                          (T*)dA, ldda, partial, M, K));
+        M324_CHECK_LAUNCH("m324_linear_n3_bwd");
+        return M324_OK;
+    }
     DISPATCH_DTYPE(dtype, "m324_linear_n3_bwd",
                    hipLaunchKernelGGL(linear_n3_bwd_kernel<T>, dim3(n_partial), dim3(256), 0, s, (const T*)A, lda, W, dout, (T*)dA,
                                       ldda, partial, M, K));

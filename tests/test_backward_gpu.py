@@ -312,9 +312,10 @@ def test_qkv_split_train_outputs_and_backward(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_linear_n3_backward(dtype):
+@pytest.mark.parametrize("M,K", [(999, 192), (5000, 768), (3, 64), (700, 2048), (130, 52)])
+def test_linear_n3_backward(dtype, M, K):
+    """(K = 52: the scalar kernel; the others the 16-byte one: 24 / 96 / 8 / 256 chunks per row, 10 / 2 / 32 / 1 rows side by side)"""
     from motion324_amd import ops
-    M, K = 999, 192
     a, w = _q(_rand((M, K), 21), dtype), _rand((3, K), 22, 0.1)
     dout = _rand((M, 3), 23)
     at, wt = a.double().requires_grad_(True), w.double().requires_grad_(True)
