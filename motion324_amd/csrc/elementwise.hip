@@ -655,6 +655,56 @@ __global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ 
     }
 }
 
+// The two kernels above with four neighbouring columns per lane (8 / 16 bytes per access instead of 2 / 4; cols % 4 == 0, aligned rows):
+// the bias-gradient sums of the training step's tall bf16 gradients (49152 x 768: 66 -> ~20 us) and the sums over the batch of a shared
+// query's gradient (8 x 3.1 M: 41 -> ~12 us).  Same summation order per column as the scalar forms.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void acc4(float4& s, const float4 v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_chunk4_kernel(const T* __restrict__ x, long ld, float* __restrict__ scratch, int rows,
+                                                            int cols) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, c = (blockIdx.x * 64 + lane) * 4, w = threadIdx.x >> 6;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+        const int step = gridDim.y * 4;
+        int r = blockIdx.y * 4 + w;
+        for (; r + 3 * step < rows; r += 4 * step) {       // four rows in flight
+            const float4 a = ld4(x + (long)r * ld + c), b = ld4(x + (long)(r + step) * ld + c), d = ld4(x + (long)(r + 2 * step) * ld + c),
+                         e = ld4(x + (long)(r + 3 * step) * ld + c);
+            acc4(s, a); acc4(s, b); acc4(s, d); acc4(s, e);
+        }
+        for (; r < rows; r += step) acc4(s, ld4(x + (long)r * ld + c));
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < cols) {
+        float4 v = red[0][lane];
+        acc4(v, red[1][lane]); acc4(v, red[2][lane]); acc4(v, red[3][lane]);
+        *reinterpret_cast<float4*>(scratch + (long)blockIdx.y * cols + c) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide4_kernel(const T* __restrict__ x, long ld, float* __restrict__ out, int rows,
+                                                           long cols, int accumulate) {
+    for (long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4; c < cols; c += (long)gridDim.x * 1024) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int r = 0; r < rows; ++r) acc4(s, ld4(x + (long)r * ld + c));
+        if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(out + c);
+            s = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
+        }
+        *reinterpret_cast<float4*>(out + c) = s;
+    }
+}
+
 // m324_colsum_multi: one launch for many (destination, chain of fp32 row blocks) pairs.  The table travels in the kernel arguments.
 // A destination's workgroups: "wide" (every source of its chain has <= 64 rows: the split-K partials of a weight gradient) -- a thread
 // owns four neighbouring columns and walks the rows, then the chain, in order (colsum_wide_kernel's arithmetic); "tall" (the
@@ -1208,8 +1258,21 @@ extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int col
                            int scratch_rows, void* stream) {
     M324_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "m324_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    const int esz = dtype == M324_BF16 ? 2 : 4;
+    const bool v4 = cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && (dtype == M324_BF16 || dtype == M324_F32);
+    (void)esz;
     if (scratch && scratch_rows > 1 && rows >= 256) {    // two-stage: row chunks in parallel, then a short deterministic sum
-        const int R = scratch_rows < 64 ? scratch_rows : 64;
+        const int R = scratch_rows < 256 ? scratch_rows : 256;
+        if (v4 && ((uintptr_t)scratch % 16) == 0) {
+            DISPATCH_DTYPE(dtype, "m324_colsum",
+                           hipLaunchKernelGGL(colsum_chunk4_kernel<T>, dim3(ceil_div(cols, 256), R), dim3(256), 0, s, (const T*)x, ld,
+                                              scratch, rows, cols));
+            const int nb = ceil_div(cols, 1024) < 8192 ? ceil_div(cols, 1024) : 8192;
+            hipLaunchKernelGGL(colsum_wide4_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)scratch, (long)cols, out, R, (long)cols,
+                               accumulate);
+            M324_CHECK_LAUNCH("m324_colsum");
+            return M324_OK;
+        }
         DISPATCH_DTYPE(dtype, "m324_colsum",
                        hipLaunchKernelGGL(colsum_chunk_kernel<T>, dim3(ceil_div(cols, 64), R), dim3(256), 0, s, (const T*)x, ld,
                                           scratch, rows, cols));
@@ -1219,7 +1282,12 @@ extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int col
         M324_CHECK_LAUNCH("m324_colsum");
         return M324_OK;
     }
-    if (rows <= 64) {
+    if (rows <= 64 && v4) {
+        const long q = ((long)cols + 1023) / 1024;
+        DISPATCH_DTYPE(dtype, "m324_colsum",
+                       hipLaunchKernelGGL(colsum_wide4_kernel<T>, dim3((int)(q < 8192 ? q : 8192)), dim3(256), 0, s, (const T*)x, ld, out, rows,
+                                          (long)cols, accumulate));
+    } else if (rows <= 64) {
         const int nb = (int)(((long)cols + 255) / 256 < 8192 ? ((long)cols + 255) / 256 : 8192);
         DISPATCH_DTYPE(dtype, "m324_colsum",
                        hipLaunchKernelGGL(colsum_wide_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)x, ld, out, rows, (long)cols,

@@ -646,7 +646,7 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool
         COLSUMS.flush()
     scratch, srows = None, 0
     if R >= 256:                                   # two-stage: row chunks in parallel, then a short fixed-order sum
-        srows = 64 if R >= 2048 else 16
+        srows = 256 if R >= 16384 else (64 if R >= 2048 else 16)
         scratch = torch.empty((srows, Cc), dtype=torch.float32, device=x.device)
     L.check(L.load().m324_colsum(px, ld, _vec(out, Cc, "out"), R, Cc, code_of(x.dtype), int(accumulate), _p(scratch), srows,
                                  _stream()), "m324_colsum")

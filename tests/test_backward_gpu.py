@@ -560,6 +560,26 @@ def test_colsum_wide_few_rows():
     assert rel_err(ops.colsum(xb.to(DEV)), xb.double().sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("R,Cc,ld", [(12, 100004, 100004), (8, 4096, 4100), (20000, 768, 768), (3000, 260, 264), (300, 64, 64), (2, 8, 8)])
+def test_colsum_four_columns_per_lane(dtype, R, Cc, ld):
+    """cols % 4 == 0 with aligned rows: 8- / 16-byte accesses (m324_colsum's wide and two-stage forms), strided sources, accumulation;
+    the wide form sums a column's rows in order, exactly like the scalar kernel (bit-identical to it on an unaligned view)."""
+    from motion324_amd import ops
+    full = _q(_rand((R, ld), 61), dtype).to(dtype)
+    x = full[:, :Cc]
+    d = full.to(DEV)[:, :Cc]
+    want = x.double().sum(0)
+    s = ops.colsum(d)
+    assert rel_err(s, want) < 1e-5
+    ops.colsum(d, out=s, accumulate=True)
+    assert rel_err(s, 2 * want) < 1e-5
+    if R <= 64:
+        pad = torch.zeros((R, ld + 1), dtype=dtype, device=DEV)          # every row starts at an odd element: the scalar kernel
+        pad[:, 1:] = full.to(DEV)
+        assert torch.equal(ops.colsum(pad[:, 1:1 + Cc]), ops.colsum(d))
+
+
 @pytest.mark.parametrize("nw", ["4", "8"])
 def test_attention_backward_mfma_many_workgroups_is_race_free(tune, nw):
     """Regression: the dQ kernel once relied on __syncthreads() to wait for its LDS-DMA tiles; the compiler emitted no
