@@ -1,4 +1,8 @@
-out=gpurun_out/r6final; mkdir -p $out
+#!/bin/bash
+# One call on the GPU box at the end of a round: the whole GPU suite, the smoke entry, the default bench line, a rocprofv3 kernel
+# table of the training step and its un-profiled time (c3 and c4).
+# usage (inside gpurun): bash tools/round_check.sh [tag]     -> gpurun_out/<tag>/{pytest_gpu.txt,smoke.txt,bench.json,train_kernel_stats.md,train_c3.json,train_c4.json}
+out=gpurun_out/${1:-round_check}; mkdir -p $out
 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.txt 2>&1; tail -3 $out/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; tail -2 $out/smoke.txt
 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json
