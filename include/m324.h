@@ -31,9 +31,12 @@ typedef enum { M324_ACT_NONE = 0, M324_ACT_GELU = 1 } m324_act;
  *   M324_AUX_STORE_PREACT  : aux[m,n] = acc + bias, the value the activation is applied to -- one launch gives the
  *                            MLP both gelu(z) (C) and z (aux), which the backward needs (autograd of transformer.py:73-78);
  *   M324_AUX_MUL_GELU_GRAD : the result is multiplied by gelu'(aux[m,n]) = Phi(z) + z phi(z) before it is stored -- the
- *                            dgrad GEMM of the MLP's second Linear then delivers d(pre-activation) directly.           */
+ *                            dgrad GEMM of the MLP's second Linear then delivers d(pre-activation) directly.
+ *   M324_AUX_STORE_GELU_GRAD / M324_AUX_MUL (ABI 22): the same pair with the work moved to where erf is evaluated anyway --
+ *                            aux[m,n] = gelu'(acc + bias) next to C = gelu(acc + bias), and "the result is multiplied by aux[m,n]":
+ *                            the dgrad epilogue multiplies instead of evaluating erf and exp a second time.                    */
 typedef enum { M324_AUX_NONE = 0, M324_AUX_STORE_PREACT = 1, M324_AUX_MUL_GELU_GRAD = 2, M324_AUX_QKV_HEADS = 3,
-               M324_AUX_QKV_HEADS_VT = 4, M324_AUX_N3 = 5 } m324_aux_mode;
+               M324_AUX_QKV_HEADS_VT = 4, M324_AUX_N3 = 5, M324_AUX_STORE_GELU_GRAD = 6, M324_AUX_MUL = 7 } m324_aux_mode;
 /*   M324_AUX_N3 (inference, bf16): the regression head Linear -> GELU -> Linear(N -> 3) (Pcd_motion.py:336-341) without its
  *   [M, N] intermediate: h = gelu(A W^T + bias) is contracted with the [3, N] fp32 weight passed in qkv_qw inside the
  *   epilogue and only partial sums leave, aux = float part[N / 64][M][3] (C may be NULL); m324_n3_finish adds the N / 64

@@ -23,6 +23,7 @@ from .prepared import Prepared
 RMS_EPS = 1e-5
 DIRECT_GRADS = switches.get("M324_DIRECT_GRADS") != "0"
 ACC_GRADS = switches.flag("M324_ACC_GRADS")
+GELU_GRAD_FWD = switches.flag("M324_GELU_GRAD_FWD")
 
 
 class GradStore:
@@ -167,9 +168,10 @@ def _wt(P: Prepared, weight: torch.Tensor) -> torch.Tensor:
 
 
 def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: torch.Tensor, need_da: bool = True,
-               gelu_grad_of: Optional[torch.Tensor] = None, dy_colsum: Optional[torch.Tensor] = None):
+               gelu_grad_of: Optional[torch.Tensor] = None, dy_colsum: Optional[torch.Tensor] = None, mul_by: Optional[torch.Tensor] = None):
     """y = a W^T + b.  a [M, Ka] and dy [M, N] in the compute dtype.  Returns da [M, Ka] (compute dtype) or None.
-    gelu_grad_of = z with a = gelu(z): the returned tensor is dz = da * gelu'(z) (fused into the dgrad GEMM's epilogue).
+    gelu_grad_of = z with a = gelu(z): the returned tensor is dz = da * gelu'(z) (fused into the dgrad GEMM's epilogue); mul_by = gelu'(z)
+    itself, left by the forward (M324_GELU_GRAD_FWD): the epilogue multiplies.
     dy_colsum: the column sums of dy when the kernel that produced dy delivered them (Carry), else computed here."""
     M, N = dy.shape
     if bias is not None:
@@ -199,7 +201,7 @@ def linear_bwd(P: Prepared, G: GradStore, weight, bias, a: torch.Tensor, dy: tor
     if Wt.shape[1] != N:
         raise RuntimeError("linear_bwd: output width must be a multiple of 64")
     da = torch.empty((M, Wt.shape[0]), dtype=dy.dtype, device=dy.device)
-    ops.gemm(dy, Wt, da, gelu_grad_of=gelu_grad_of)
+    ops.gemm(dy, Wt, da, gelu_grad_of=gelu_grad_of, mul_by=mul_by)
     return da
 
 
@@ -240,6 +242,9 @@ def mlp_internals(P: Prepared, norm2, mlp, x_mid: torch.Tensor) -> dict:
     ops.layernorm(x_mid, P.vec(norm2.weight), P.vec(norm2.bias), norm2.eps, h2)
     z = torch.empty((rows, fc1.out_features), dtype=P.dtype, device=x_mid.device)
     g = torch.empty_like(z)
+    if GELU_GRAD_FWD:                          # g = gelu(z) and gelu'(z) in one launch: erf is evaluated once, where it is needed anyway
+        ops.gemm(h2, P.mat(fc1.weight), g, bias=P.vec(fc1.bias), act=ACT_GELU, gelu_grad_out=z)
+        return dict(h2=h2, dg=z, g=g)
     ops.gemm(h2, P.mat(fc1.weight), g, bias=P.vec(fc1.bias), act=ACT_GELU, preact_out=z)     # g = gelu(z) and z in one launch
     return dict(h2=h2, z=z, g=g)
 
@@ -251,9 +256,9 @@ def mlp_residual_bwd(P: Prepared, G: GradStore, norm2, mlp, x_mid: torch.Tensor,
     fc1, fc2 = mlp.mlp[0], mlp.mlp[2]
     carry = carry if carry is not None else Carry()
     m = saved if saved is not None else mlp_internals(P, norm2, mlp, x_mid)
-    h2, z, g = m["h2"], m["z"], m["g"]
+    h2, g = m["h2"], m["g"]
     dxT, dsum = carry.take(P, dx)
-    dz = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT, gelu_grad_of=z, dy_colsum=dsum)      # (dxT W2) * gelu'(z)
+    dz = linear_bwd(P, G, fc2.weight, fc2.bias, g, dxT, gelu_grad_of=m.get("z"), mul_by=m.get("dg"), dy_colsum=dsum)      # (dxT W2) * gelu'(z)
     dh2 = linear_bwd(P, G, fc1.weight, fc1.bias, h2, dz)
     dw, db = carry.ln_bwd(P, x_mid, P.vec(norm2.weight), norm2.eps, dh2, dx, accumulate=True)
     G.add(norm2.weight, dw)

@@ -1240,9 +1240,9 @@ int launch(const m324_gemm_args* a, hipStream_t s) {
             }
         } else if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) {
             if constexpr (sizeof(TOUT) == 2) M324_GLDS(4, 0);
-        } else if (a->aux_mode == M324_AUX_STORE_PREACT) {
+        } else if (a->aux_mode == M324_AUX_STORE_PREACT || a->aux_mode == M324_AUX_STORE_GELU_GRAD) {
             M324_GLDS(2, 0);
-        } else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD) {
+        } else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD || a->aux_mode == M324_AUX_MUL) {
             M324_GLDS(3, 0);
         } else if (a->act == M324_ACT_GELU) {
             if (res == 0) M324_GLDS(1, 0); else M324_GLDS(1, 2);
@@ -1278,8 +1278,8 @@ extern "C" int m324_gemm_plan(const m324_gemm_args* a, char* buf, int n) {
                     : (a->residual && a->row_gin <= 0 && (a->res_rows <= 0 || a->res_rows >= a->M)) ? 1 : 2;
     int act = a->act == M324_ACT_GELU ? 1 : 0, rs = act ? (res ? 2 : 0) : res;
     if (a->aux_mode == M324_AUX_QKV_HEADS || a->aux_mode == M324_AUX_QKV_HEADS_VT) act = 4, rs = 0;
-    else if (a->aux_mode == M324_AUX_STORE_PREACT) act = 2, rs = 0;
-    else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD) act = 3, rs = 0;
+    else if (a->aux_mode == M324_AUX_STORE_PREACT || a->aux_mode == M324_AUX_STORE_GELU_GRAD) act = 2, rs = 0;
+    else if (a->aux_mode == M324_AUX_MUL_GELU_GRAD || a->aux_mode == M324_AUX_MUL) act = 3, rs = 0;
     if (lnf) {
         if (a->ln_rowstat) act |= 8, rs = 0;
         else act = a->out_dtype == M324_F32 ? 48 : 16, rs = res;
@@ -1356,7 +1356,7 @@ static int gemm_validate(const m324_gemm_args* a) {
     M324_REQUIRE(!a->residual || a->ldr >= a->N, "m324_gemm: ldr too small");
     M324_REQUIRE(a->batch <= 1 || (vec_ok(a) && !a->residual && a->batch <= 65535),
                  "m324_gemm: a batched launch needs a vectorisable, residual-free problem");
-    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= 5, "m324_gemm: aux_mode %d", a->aux_mode);
+    M324_REQUIRE(a->aux_mode >= 0 && a->aux_mode <= M324_AUX_MUL, "m324_gemm: aux_mode %d", a->aux_mode);
     if (n3_mode) {
         M324_REQUIRE(a->aux && a->qkv_qw && a->act == M324_ACT_GELU && !a->residual && !a->gamma && a->row_gin <= 0 && a->batch <= 1,
                      "m324_gemm: M324_AUX_N3 = Linear + GELU + [3, N] contraction: aux (partial sums) and qkv_qw (the [3, N] weight) "
@@ -1388,10 +1388,10 @@ static int gemm_validate(const m324_gemm_args* a) {
         M324_REQUIRE(a->aux && a->ldaux >= a->N && a->ldaux % 4 == 0 && ((uintptr_t)a->aux % (4 * osz)) == 0 && vec_ok(a) &&
                          a->row_gin <= 0 && a->batch <= 1,
                      "m324_gemm: aux operand needs a vectorisable, un-remapped, un-batched problem with ldaux >= N");
-        M324_REQUIRE(a->aux_mode != M324_AUX_STORE_PREACT || a->act == M324_ACT_GELU,
-                     "m324_gemm: M324_AUX_STORE_PREACT only makes sense with an activation");
-        M324_REQUIRE(a->aux_mode != M324_AUX_MUL_GELU_GRAD || a->act == M324_ACT_NONE,
-                     "m324_gemm: M324_AUX_MUL_GELU_GRAD excludes an activation");
+        M324_REQUIRE((a->aux_mode != M324_AUX_STORE_PREACT && a->aux_mode != M324_AUX_STORE_GELU_GRAD) || a->act == M324_ACT_GELU,
+                     "m324_gemm: M324_AUX_STORE_PREACT / M324_AUX_STORE_GELU_GRAD only make sense with an activation");
+        M324_REQUIRE((a->aux_mode != M324_AUX_MUL_GELU_GRAD && a->aux_mode != M324_AUX_MUL) || a->act == M324_ACT_NONE,
+                     "m324_gemm: M324_AUX_MUL_GELU_GRAD / M324_AUX_MUL exclude an activation");
         M324_REQUIRE(!a->residual, "m324_gemm: the aux operand excludes a residual");
     }
     if (a->ln_rowstat || a->ln_stats_out || a->ln_copy_out) {
@@ -1399,7 +1399,8 @@ static int gemm_validate(const m324_gemm_args* a) {
         M324_REQUIRE(a->in_dtype == M324_BF16 && a->N % 64 == 0 && a->M > 64 && vec_ok(a) && a->batch <= 1 && a->K >= 128,
                      "m324_gemm: the LayerNorm fold needs a bf16, vectorisable, un-batched problem with M > 64, N %% 64 == 0 and "
                      "K >= 128 (M=%d N=%d K=%d)", a->M, a->N, a->K);
-        M324_REQUIRE(a->aux_mode != M324_AUX_STORE_PREACT && a->aux_mode != M324_AUX_MUL_GELU_GRAD,
+        M324_REQUIRE(a->aux_mode != M324_AUX_STORE_PREACT && a->aux_mode != M324_AUX_MUL_GELU_GRAD && a->aux_mode != M324_AUX_STORE_GELU_GRAD &&
+                         a->aux_mode != M324_AUX_MUL,
                      "m324_gemm: the LayerNorm fold is an inference feature (no training aux modes)");
         // the combinations that are built (gemm_tile.h store_tile_lds, ACTX bits): a consumer has no residual / gamma / row
         // map (and a bf16 output behind GELU); a producer is x = residual + A W^T (+ bias, gamma) with its statistics, plus

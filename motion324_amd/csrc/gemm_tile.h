@@ -89,8 +89,11 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 #define M324_GELU_CLAMP 4.2426405f
 // N independent pairs, one Horner step of every pair before the next step of any: a dependent v_pk_fma_f32 needs a wait
 // state, and the compiler otherwise emits the pairs one after another with an s_nop between all 11 dependent steps.
-template <int N>
-__device__ __forceinline__ void gelu_poly2n(f32x2v (&x)[N]) {
+// GRAD: d receives gelu'(x) = Phi(x) + x phi(x) as well -- Phi is the polynomial's own 1/2 + u Q(u^2), phi(x) = exp2(-x^2 log2(e) / 2) /
+// sqrt(2 pi): four more instructions per value, one of them transcendental (M324_AUX_STORE_GELU_GRAD: the training forward leaves the
+// derivative instead of the pre-activation, so that the dgrad epilogue of the Linear behind the GELU multiplies instead of evaluating erf + exp).
+template <int N, bool GRAD = false>
+__device__ __forceinline__ void gelu_poly2n(f32x2v (&x)[N], f32x2v* d = nullptr) {
     f32x2v u[N], t[N], p[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -113,6 +116,16 @@ __device__ __forceinline__ void gelu_poly2n(f32x2v (&x)[N]) {
 #undef M324_GELU_STEP
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = __builtin_elementwise_fma(u[i], p[i], (f32x2v)(0.5f));
+    if constexpr (GRAD) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const f32x2v xx = x[i] * x[i], xs = x[i] * (f32x2v)(0.39894228040143267794f);
+            f32x2v e;
+            e.x = __builtin_amdgcn_exp2f(-0.72134752044448170368f * xx.x);
+            e.y = __builtin_amdgcn_exp2f(-0.72134752044448170368f * xx.y);
+            d[i] = __builtin_elementwise_fma(xs, e, p[i]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = x[i] * p[i];
 }
@@ -142,6 +155,38 @@ __device__ __forceinline__ void apply_gelu8(float4& v, float4& w) {
     } else {
         apply_gelu4<TOUT>(v);
         apply_gelu4<TOUT>(w);
+    }
+}
+
+// v <- gelu(v), d <- gelu'(v) (both from the fp32 value in front of the activation)
+template <typename TOUT>
+__device__ __forceinline__ void apply_gelu4_grad(float4& v, float4& d) {
+    if constexpr (sizeof(TOUT) == 2) {
+        f32x2v a[2] = {{v.x, v.y}, {v.z, v.w}}, g[2];
+        gelu_poly2n<2, true>(a, g);
+        v = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+        d = make_float4(g[0].x, g[0].y, g[1].x, g[1].y);
+    } else {
+        auto one = [](float z, float& dz) {
+            const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+            dz = cdf + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+            return z * cdf;
+        };
+        v = make_float4(one(v.x, d.x), one(v.y, d.y), one(v.z, d.z), one(v.w, d.w));
+    }
+}
+template <typename TOUT>
+__device__ __forceinline__ void apply_gelu8_grad(float4& v, float4& w, float4& dv, float4& dw) {
+    if constexpr (sizeof(TOUT) == 2) {
+        f32x2v a[4] = {{v.x, v.y}, {v.z, v.w}, {w.x, w.y}, {w.z, w.w}}, g[4];
+        gelu_poly2n<4, true>(a, g);
+        v = make_float4(a[0].x, a[0].y, a[1].x, a[1].y);
+        w = make_float4(a[2].x, a[2].y, a[3].x, a[3].y);
+        dv = make_float4(g[0].x, g[0].y, g[1].x, g[1].y);
+        dw = make_float4(g[2].x, g[2].y, g[3].x, g[3].y);
+    } else {
+        apply_gelu4_grad<TOUT>(v, dv);
+        apply_gelu4_grad<TOUT>(w, dw);
     }
 }
 
@@ -753,14 +798,23 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                 if (fold) ln_fold4(x, rs[p], cs, bi);
                 else { x.x += bi.x; x.y += bi.y; x.z += bi.z; x.w += bi.w; }
                 const int m = mb + 4 * p;
-                if (ACT == 2 && (!CHECK || (m < M && nok)))
-                    store4_out<TOUT>(static_cast<TOUT*>(ep.aux) + (long)m * ep.ldaux + n, x.x, x.y, x.z, x.w);
-                if (ACT == 1 || ACT == 2) apply_gelu4<TOUT>(x);
+                if constexpr (ACT == 2) {
+                    float4 keep = x;                        // the pre-activation, or (M324_AUX_STORE_GELU_GRAD) the activation's derivative there
+                    if (ep.aux_mode == M324_AUX_STORE_GELU_GRAD) apply_gelu4_grad<TOUT>(x, keep);
+                    else apply_gelu4<TOUT>(x);
+                    if (!CHECK || (m < M && nok))
+                        store4_out<TOUT>(static_cast<TOUT*>(ep.aux) + (long)m * ep.ldaux + n, keep.x, keep.y, keep.z, keep.w);
+                }
+                if (ACT == 1) apply_gelu4<TOUT>(x);
                 if (ep.gamma) { x.x *= ga.x; x.y *= ga.y; x.z *= ga.z; x.w *= ga.w; }
                 if (has_res) { x.x += res[p].x; x.y += res[p].y; x.z += res[p].z; x.w += res[p].w; }
                 if constexpr (ACT == 3) {
-                    x.x *= gelu_grad<TOUT>(az[p].x); x.y *= gelu_grad<TOUT>(az[p].y);
-                    x.z *= gelu_grad<TOUT>(az[p].z); x.w *= gelu_grad<TOUT>(az[p].w);
+                    if (ep.aux_mode == M324_AUX_MUL) {       // aux already holds the factor (the forward's M324_AUX_STORE_GELU_GRAD)
+                        x.x *= az[p].x; x.y *= az[p].y; x.z *= az[p].z; x.w *= az[p].w;
+                    } else {
+                        x.x *= gelu_grad<TOUT>(az[p].x); x.y *= gelu_grad<TOUT>(az[p].y);
+                        x.z *= gelu_grad<TOUT>(az[p].z); x.w *= gelu_grad<TOUT>(az[p].w);
+                    }
                 }
                 if constexpr (STATS) xs[p] = x;
                 if (!CHECK || (m < M && nok)) {
@@ -854,10 +908,14 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     y.x += b1.x; y.y += b1.y; y.z += b1.z; y.w += b1.w;
                 }
                 const long m = mw + i * 32 + p * 8 + r8;
-                if constexpr (ACT == 2)
+                if constexpr (ACT == 2) {
+                    float4 kx = x, ky = y;                  // the pre-activation, or (M324_AUX_STORE_GELU_GRAD) the activation's derivative there
+                    if (ep.aux_mode == M324_AUX_STORE_GELU_GRAD) apply_gelu8_grad<TOUT>(x, y, kx, ky);
+                    else apply_gelu8<TOUT>(x, y);
                     *reinterpret_cast<uint4*>(static_cast<TOUT*>(ep.aux) + m * ep.ldaux + n8) =
-                        make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-                if (ACT == 1 || ACT == 2) apply_gelu8<TOUT>(x, y);
+                        make_uint4(pack_bf16x2(kx.x, kx.y), pack_bf16x2(kx.z, kx.w), pack_bf16x2(ky.x, ky.y), pack_bf16x2(ky.z, ky.w));
+                }
+                if (ACT == 1) apply_gelu8<TOUT>(x, y);
                 if (ep.gamma) {
                     x.x *= g0.x; x.y *= g0.y; x.z *= g0.z; x.w *= g0.w;
                     y.x *= g1.x; y.y *= g1.y; y.z *= g1.z; y.w *= g1.w;
@@ -867,10 +925,15 @@ __device__ __forceinline__ void store_tile_lds(const f32x16 (&acc)[MI][2], float
                     y.x += rb[p].x; y.y += rb[p].y; y.z += rb[p].z; y.w += rb[p].w;
                 }
                 if constexpr (ACT == 3) {
-                    x.x *= gelu_grad<TOUT>(z0[p].x); x.y *= gelu_grad<TOUT>(z0[p].y);
-                    x.z *= gelu_grad<TOUT>(z0[p].z); x.w *= gelu_grad<TOUT>(z0[p].w);
-                    y.x *= gelu_grad<TOUT>(z1[p].x); y.y *= gelu_grad<TOUT>(z1[p].y);
-                    y.z *= gelu_grad<TOUT>(z1[p].z); y.w *= gelu_grad<TOUT>(z1[p].w);
+                    if (ep.aux_mode == M324_AUX_MUL) {       // aux already holds the factor (the forward's M324_AUX_STORE_GELU_GRAD)
+                        x.x *= z0[p].x; x.y *= z0[p].y; x.z *= z0[p].z; x.w *= z0[p].w;
+                        y.x *= z1[p].x; y.y *= z1[p].y; y.z *= z1[p].z; y.w *= z1[p].w;
+                    } else {
+                        x.x *= gelu_grad<TOUT>(z0[p].x); x.y *= gelu_grad<TOUT>(z0[p].y);
+                        x.z *= gelu_grad<TOUT>(z0[p].z); x.w *= gelu_grad<TOUT>(z0[p].w);
+                        y.x *= gelu_grad<TOUT>(z1[p].x); y.y *= gelu_grad<TOUT>(z1[p].y);
+                        y.z *= gelu_grad<TOUT>(z1[p].z); y.w *= gelu_grad<TOUT>(z1[p].w);
+                    }
                 }
                 if constexpr (STATS) { xa[p] = x; ya[p] = y; }
                 store16(C + m * ldc + n8, ep.stream != 0, pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));

@@ -16,7 +16,7 @@ void m324_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int m324_abi_version(void) { return 21; }
+extern "C" int m324_abi_version(void) { return 22; }
 
 // ---- tunables (see common.h): environment read once at load, then m324_set_tunable only
 namespace {

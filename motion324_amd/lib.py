@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("M324_LIB") or os.path.join(HERE, "libm324.so")      #
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
-ABI_VERSION = 21
+ABI_VERSION = 22
 ERR_UNSUPPORTED = -3          # m324_status M324_ERR_UNSUPPORTED
 
 

@@ -169,11 +169,14 @@ def gemm_tn(x: torch.Tensor, y: torch.Tensor, slices: int = 1, out: Optional[tor
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act: int = L.ACT_NONE, gamma=None,
          residual: Optional[torch.Tensor] = None, res_rows: int = 0, row_map=(0, 0, 0),
          preact_out: Optional[torch.Tensor] = None, gelu_grad_of: Optional[torch.Tensor] = None,
+         gelu_grad_out: Optional[torch.Tensor] = None, mul_by: Optional[torch.Tensor] = None,
          qkv_heads: Optional[tuple] = None, n3: Optional[tuple] = None, ln: Optional[tuple] = None,
          stats_out: Optional[torch.Tensor] = None, copy_out: Optional[torch.Tensor] = None, defer: Optional[list] = None) -> torch.Tensor:
     """out[row_map(m), :N] = epilogue(a[M,K] @ w[N,K]^T); see include/m324.h m324_gemm.
     preact_out [M, N] (out's dtype) also receives the value the activation is applied to (M324_AUX_STORE_PREACT);
     gelu_grad_of [M, N] = z: the result is multiplied by gelu'(z) (M324_AUX_MUL_GELU_GRAD).  Training only.
+    gelu_grad_out [M, N] receives gelu'(pre-activation) (M324_AUX_STORE_GELU_GRAD) and mul_by [M, N] multiplies the result
+    (M324_AUX_MUL): the same pair with erf evaluated once, in the forward.
     qkv_heads = (Q, K, V, q_w, k_w, eps, q_scale, L, H): the fused q|k|v projection is written head-major into Q / K / V
     [B, H, L, 64] with per-head RMSNorm and the q pre-scale (M324_AUX_QKV_HEADS); `out` is ignored (may be None).
     A V of shape [B, H, 64, L] selects M324_AUX_QKV_HEADS_VT: V leaves transposed and key-permuted, the operand
@@ -274,14 +277,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias=None, act:
     if out.shape[0] < need or out.shape[1] < N:
         raise L.M324Error(f"gemm: out{tuple(out.shape)} too small for {need} x {N}")
     args.row_gin, args.row_gout, args.row_off = gin, gout, off
-    aux = preact_out if preact_out is not None else gelu_grad_of
-    if aux is not None:
-        if preact_out is not None and gelu_grad_of is not None:
-            raise L.M324Error("gemm: preact_out and gelu_grad_of are mutually exclusive")
+    auxes = [(t, mode) for t, mode in ((preact_out, 1), (gelu_grad_of, 2), (gelu_grad_out, 6), (mul_by, 7)) if t is not None]
+    if auxes:
+        if len(auxes) > 1:
+            raise L.M324Error("gemm: preact_out, gelu_grad_of, gelu_grad_out and mul_by are mutually exclusive")
+        aux, mode = auxes[0]
         if aux.dtype != out.dtype or aux.shape[0] < M or aux.shape[1] < N:
             raise L.M324Error(f"gemm: aux operand {aux.dtype}{tuple(aux.shape)} does not match out {out.dtype} [{M}, {N}]")
         args.aux, args.ldaux = _rows(aux, "aux")
-        args.aux_mode = 1 if preact_out is not None else 2
+        args.aux_mode = mode
     esz = a.element_size()
     tag = "" if not _timing() else (
         f"{_gemm_plan(args)} | M={M} N={N} K={K}{' bias' if bias is not None else ''}{' gelu' if act else ''}"

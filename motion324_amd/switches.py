@@ -31,6 +31,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
     "M324_TRAIN_DINO_FUSED": ("1", "training.DINO_FUSED", "training: the frozen DINOv2 encoder (no gradient flows through it) runs its inference form -- LayerNorm fold, fused q|k|v epilogue -- and is enqueued first in the step (0: the unfused form the trainable blocks use)"),
     "M324_DIRECT_GRADS": ("1", "backward.DIRECT_GRADS", "training: weight / bias gradients are written straight into the optimizer's flat gradient buffer (0: temporary + copy)"),
     "M324_ACC_GRADS": ("1", "backward.ACC_GRADS", "training: later gradients of a shared weight (the decoder's per-sample passes) are summed into the one it holds by the weight-gradient kernel's own reduction (0: temporary + torch add)"),
+    "M324_GELU_GRAD_FWD": ("1", "backward.GELU_GRAD_FWD", "training: the fc1 GEMM of every MLP leaves gelu'(z) next to gelu(z) (M324_AUX_STORE_GELU_GRAD) and the dgrad GEMM behind fc2 multiplies by it (M324_AUX_MUL); 0: it leaves z and the dgrad epilogue evaluates erf and exp again"),
     "M324_WEIGHT_MIRROR": ("1", "optim.WEIGHT_MIRROR", "training: FusedAdamW keeps bf16 row-major and transposed copies of every Linear weight in two flat buffers, rewritten by one m324_weight_mirror launch after each update (0: Prepared casts / m324_transpose per weight and step)"),
     "M324_DEFER_COLSUM": ("1", "ops.DEFER_COLSUM", "training: the sums of the weight gradients' split-K partials and of the norm-weight partials wait in a queue and leave in one m324_colsum_multi launch per block (0: one m324_colsum launch each, at once)"),
     "M324_PRECISION": ("", "prepared.compute_dtype()", "force bf16 / fp32 (default: follow torch.autocast like the reference)"),

@@ -463,6 +463,22 @@ def test_gemm_training_aux_operand(dtype, M, N, K):
     assert rel_err(dz.float(), dref) < TOL[dtype]
     with pytest.raises(M324Error):          # the pre-activation output needs an activation
         ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), g, preact_out=z)
+    # the same pair with erf evaluated once (ABI 22): M324_AUX_STORE_GELU_GRAD leaves gelu'(z) of the fp32 z next to gelu(z), M324_AUX_MUL multiplies
+    g2 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    d = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), g2, bias=bias.to(DEV), act=ACT_GELU, gelu_grad_out=d)
+    assert torch.equal(g2, g)
+    cdf0 = 0.5 * (1 + torch.erf(zref / math.sqrt(2.0)))
+    pdf0 = torch.exp(-0.5 * zref * zref) / math.sqrt(2 * math.pi)
+    assert rel_err(d.float(), cdf0 + zref * pdf0) < TOL[dtype]
+    dz2 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm(dy.to(dtype).to(DEV), w.to(dtype).to(DEV), dz2, mul_by=d)
+    assert rel_err(dz2.float(), (dy.double() @ w.double().T) * d.float().cpu().double()) < TOL[dtype]
+    assert rel_err(dz2.float(), (dy.double() @ w.double().T) * (cdf0 + zref * pdf0)) < 2 * TOL[dtype]
+    with pytest.raises(M324Error):
+        ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), g, gelu_grad_out=d)
+    with pytest.raises(M324Error):
+        ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), g, act=ACT_GELU, mul_by=d)
 
 
 @pytest.mark.parametrize("M,N,Kc,slices", [(64, 128, 128, 1), (150, 192, 328, 1), (1000, 768, 64, 3), (4096, 2304, 768, 4),
