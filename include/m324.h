@@ -386,9 +386,11 @@ int m324_qkv_split_bwd(const void* dQ, const void* dK, const void* dV, const voi
                        long ldok, void* dv_out, long ldov, float* partial, int n_partial, int B, int L, int H, int dtype,
                        void* stream);
 /* Backward of m324_linear_n3: dA[M,K] = dout[M,3] . W[3,K]; partial [n_partial][3*K] = per-block sums of dout^T A
- * (reduce with m324_colsum to get dW). */
+ * (reduce with m324_colsum to get dW).  mul (optional, ABI 22; A's dtype, [M, ldmul]): dA[m,k] is multiplied by mul[m,k] --
+ * with the gelu'(z) the head's first Linear left (M324_AUX_STORE_GELU_GRAD) the kernel delivers d(pre-activation) directly and
+ * the m324_gelu_bwd pass over the tensor is gone. */
 int m324_linear_n3_bwd(const void* A, long lda, const float* W, const float* dout, void* dA, long ldda, float* partial,
-                       int n_partial, int M, int K, int dtype, void* stream);
+                       int n_partial, int M, int K, int dtype, const void* mul, long ldmul, void* stream);
 /* d[i] = coef * (*grad_scale) * (pred[i] - target[i])  -- backward of m324_mse (coef = 2 * weight / n). */
 int m324_mse_bwd(const float* pred, const float* target, const float* grad_scale, float coef, float* d, long n,
                  void* stream);

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void qkv_split_bwd_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void linear_n3_bwd_kernel(const T* __restrict__ A, long lda, const float* __restrict__ W,
                                                             const float* __restrict__ dout, T* __restrict__ dA, long ldda,
-                                                            float* __restrict__ partial, int M, int K) {
+                                                            float* __restrict__ partial, int M, int K, const T* __restrict__ mul, long ldmul) {
     const int t = threadIdx.x;
     // each thread owns columns t, t+256, ... ; rows are strided over blocks
     for (int k = t; k < K; k += 256) {
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void linear_n3_bwd_kernel(const T* __restrict_
             const float d0 = dout[m * 3], d1 = dout[m * 3 + 1], d2 = dout[m * 3 + 2];
             const float a = ld1(A + m * lda + k);
             s0 += d0 * a; s1 += d1 * a; s2 += d2 * a;
-            Elem<T>::store(dA + m * ldda + k, d0 * w0 + d1 * w1 + d2 * w2);
+            const float f = mul ? ld1(mul + m * ldmul + k) : 1.0f;
+            Elem<T>::store(dA + m * ldda + k, (d0 * w0 + d1 * w1 + d2 * w2) * f);
         }
         float* pr = partial + (long)blockIdx.x * 3 * K;
         pr[k] = s0; pr[K + k] = s1; pr[2 * (long)K + k] = s2;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void linear_n3_bwd_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void linear_n3_bwd_vec_kernel(const T* __restrict__ A, long lda, const float* __restrict__ W,
                                                                 const float* __restrict__ dout, T* __restrict__ dA, long ldda,
-                                                                float* __restrict__ partial, int M, int K) {
+                                                                float* __restrict__ partial, int M, int K, const T* __restrict__ mul, long ldmul) {
     extern __shared__ float red[];              // [nrs - 1][3][K]
     const int nch = K >> 3, nrs = 256 / nch, t = threadIdx.x;
     const int ch = t % nch, rs = t / nch;
@@ -239,11 +240,13 @@ __global__ __launch_bounds__(256) void linear_n3_bwd_vec_kernel(const T* __restr
         const long step = (long)gridDim.x * nrs;
         auto row = [&](long m, const float (&a)[8]) {
             const float d0 = dout[m * 3], d1 = dout[m * 3 + 1], d2 = dout[m * 3 + 2];
-            float o[8];
+            float o[8], f[8];
+            if (mul) load8(mul + m * ldmul + ch * 8, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 sum[0][e] += d0 * a[e]; sum[1][e] += d1 * a[e]; sum[2][e] += d2 * a[e];
                 o[e] = d0 * w[0][e] + d1 * w[1][e] + d2 * w[2][e];
+                if (mul) o[e] *= f[e];
             }
             store8(dA + m * ldda + ch * 8, o);
         };
@@ -510,23 +513,24 @@ extern "C" int m324_qkv_split_bwd(const void* dQ, const void* dK, const void* dV
 }
 
 extern "C" int m324_linear_n3_bwd(const void* A, long lda, const float* W, const float* dout, void* dA, long ldda, float* partial,
-                                  int n_partial, int M, int K, int dtype, void* stream) {
-    M324_REQUIRE(A && W && dout && dA && partial && n_partial > 0 && M > 0 && K > 0, "m324_linear_n3_bwd: bad arguments");
+                                  int n_partial, int M, int K, int dtype, const void* mul, long ldmul, void* stream) {
+    M324_REQUIRE(A && W && dout && dA && partial && n_partial > 0 && M > 0 && K > 0 && (!mul || ldmul >= K), "m324_linear_n3_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int esz = dtype == M324_BF16 ? 2 : 4;
     if (K % 8 == 0 && K >= 64 && K <= 2048 && (lda * esz) % 16 == 0 && (ldda * esz) % 16 == 0 && ((uintptr_t)A % 16) == 0 &&
-        ((uintptr_t)dA % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)partial % 16) == 0) {
+        ((uintptr_t)dA % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)partial % 16) == 0 &&
+        (!mul || (((uintptr_t)mul % 16) == 0 && (ldmul * esz) % 16 == 0))) {
         const int nrs = 256 / (K / 8);
         const size_t lds = (size_t)(nrs - 1) * 3 * K * sizeof(float);
         DISPATCH_DTYPE(dtype, "m324_linear_n3_bwd",
                        hipLaunchKernelGGL(linear_n3_bwd_vec_kernel<T>, dim3(n_partial), dim3(256), lds, s, (const T*)A, lda, W, dout,
-                                          (T*)dA, ldda, partial, M, K));
+                                          (T*)dA, ldda, partial, M, K, (const T*)mul, ldmul));
         M324_CHECK_LAUNCH("m324_linear_n3_bwd");
         return M324_OK;
     }
     DISPATCH_DTYPE(dtype, "m324_linear_n3_bwd",
                    hipLaunchKernelGGL(linear_n3_bwd_kernel<T>, dim3(n_partial), dim3(256), 0, s, (const T*)A, lda, W, dout, (T*)dA,
-                                      ldda, partial, M, K));
+                                      ldda, partial, M, K, (const T*)mul, ldmul));
     M324_CHECK_LAUNCH("m324_linear_n3_bwd");
     return M324_OK;
 }

@@ -100,7 +100,7 @@ SIGNATURES = {
     "m324_attention_bwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "m324_attention_bwd_mfma": [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "m324_qkv_split_bwd": [_P, _P, _P, _P, _L, _P, _L, _P, _P, _F, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P],
-    "m324_linear_n3_bwd": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P],
+    "m324_linear_n3_bwd": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P, _L, _P],
     "m324_mse_bwd": [_P, _P, _P, _F, _P, _L, _P],
     "m324_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "m324_adamw_flat": [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _F, _I, _P, _P],

@@ -858,17 +858,23 @@ def qkv_split_bwd(dQ, dK, dV, q_raw, k_raw, q_w, k_w, eps: float, B: int, Lq: in
             both[64:] if (dK is not None and k_w is not None) else None)
 
 
-def linear_n3_bwd(a: torch.Tensor, w: torch.Tensor, dout: torch.Tensor):
-    """Backward of linear_n3: returns (dA [M,K] in a.dtype, dW [3,K] fp32, db [3] fp32)."""
+def linear_n3_bwd(a: torch.Tensor, w: torch.Tensor, dout: torch.Tensor, mul_by: Optional[torch.Tensor] = None):
+    """Backward of linear_n3: returns (dA [M,K] in a.dtype, dW [3,K] fp32, db [3] fp32).  mul_by [M, K] (a's dtype): dA is multiplied by it
+    (the gelu'(z) the Linear in front left with gemm(gelu_grad_out=...): dA is then the gradient of ITS pre-activation)."""
     M, K = a.shape
     pa, lda = _rows(a, "a")
     dout = dout.reshape(M, 3)
     if dout.dtype != torch.float32 or not dout.is_contiguous():
         raise L.M324Error("linear_n3_bwd: dout must be contiguous fp32 [M,3]")
+    pm, ldm = (None, 0)
+    if mul_by is not None:
+        if mul_by.dtype != a.dtype or mul_by.shape[0] < M or mul_by.shape[1] < K:
+            raise L.M324Error(f"linear_n3_bwd: mul_by {mul_by.dtype}{tuple(mul_by.shape)} does not match a {a.dtype}[{M}, {K}]")
+        pm, ldm = _rows(mul_by, "mul_by")
     dA = torch.empty((M, K), dtype=a.dtype, device=a.device)
-    n_partial = min(512, M)
+    n_partial = min(1024, M)
     partial = torch.empty((n_partial, 3 * K), dtype=torch.float32, device=a.device)
-    L.check(L.load().m324_linear_n3_bwd(pa, lda, _p(w), _p(dout), _p(dA), K, _p(partial), n_partial, M, K, code_of(a.dtype),
+    L.check(L.load().m324_linear_n3_bwd(pa, lda, _p(w), _p(dout), _p(dA), K, _p(partial), n_partial, M, K, code_of(a.dtype), pm, ldm,
                                         _stream()), "m324_linear_n3_bwd")
     return dA, colsum(partial).reshape(3, K), colsum(dout)
 

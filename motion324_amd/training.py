@@ -199,8 +199,8 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
         ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
         h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
         if keep:
-            z2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
-            ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU, preact_out=z2)
+            z2 = torch.empty(x.shape, dtype=P.dtype, device=dev)              # the pre-activation, or gelu' of it (M324_GELU_GRAD_FWD)
+            ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU, **{"gelu_grad_out" if bw.GELU_GRAD_FWD else "preact_out": z2})
             head = (h, z2, h2)
         else:
             ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU)
@@ -228,12 +228,19 @@ def _forward_backward(model, sample: Dict[str, torch.Tensor], grad_scale: float 
             h = torch.empty(x.shape, dtype=P.dtype, device=dev)
             ops.layernorm(x, P.vec(head_ln.weight), P.vec(head_ln.bias), head_ln.eps, h)
             z2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
-            ops.gemm(h, P.mat(head_fc1.weight), z2, bias=P.vec(head_fc1.bias))
-            h2 = ops.gelu(z2)
-        dh2, dW3, db3 = ops.linear_n3_bwd(h2, w3, d_out[b])
+            if bw.GELU_GRAD_FWD:
+                h2 = torch.empty(x.shape, dtype=P.dtype, device=dev)
+                ops.gemm(h, P.mat(head_fc1.weight), h2, bias=P.vec(head_fc1.bias), act=ACT_GELU, gelu_grad_out=z2)
+            else:
+                ops.gemm(h, P.mat(head_fc1.weight), z2, bias=P.vec(head_fc1.bias))
+                h2 = ops.gelu(z2)
+        if bw.GELU_GRAD_FWD:                                  # z2 holds gelu'(pre-activation): the 3-wide Linear's backward multiplies by it
+            dz2, dW3, db3 = ops.linear_n3_bwd(h2, w3, d_out[b], mul_by=z2)
+        else:
+            dh2, dW3, db3 = ops.linear_n3_bwd(h2, w3, d_out[b])
+            dz2 = ops.gelu_bwd(z2, dh2)
         G.add(head_fc2.weight, dW3)
         G.add(head_fc2.bias, db3)
-        dz2 = ops.gelu_bwd(z2, dh2)
         dh = bw.linear_bwd(P, G, head_fc1.weight, head_fc1.bias, h, dz2)
         dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
         dw, db = ops.layernorm_bwd(x, P.vec(head_ln.weight), head_ln.eps, dh, dx, accumulate=False, reduce=not ops.DEFER_COLSUM)

@@ -324,6 +324,10 @@ def test_linear_n3_backward(dtype, M, K):
     dA, dW, db = ops.linear_n3_bwd(a.to(dtype).to(DEV), w.to(DEV), dout.to(DEV))
     assert rel_err(dA.float(), at.grad) < (1e-6 if dtype == torch.float32 else 5e-3)
     assert rel_err(dW, wt.grad) < 1e-5 and rel_err(db, bt.grad) < 1e-5
+    f = _q(_rand((M, K), 24), dtype)                         # optional factor on dA (the gelu'(z) of the Linear in front)
+    dA2, dW2, db2 = ops.linear_n3_bwd(a.to(dtype).to(DEV), w.to(DEV), dout.to(DEV), mul_by=f.to(dtype).to(DEV))
+    assert rel_err(dA2.float(), at.grad * f.double()) < (1e-6 if dtype == torch.float32 else 5e-3)
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)
 
 
 def test_mse_backward_and_cast():
