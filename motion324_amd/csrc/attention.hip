@@ -1229,7 +1229,7 @@ extern "C" int m324_attention_bwd_mfma(const void* Qs, const void* Qst, long q_b
     const int fbw = m324::tunable(m324::TUN_ATTN_BWD_NW);
     // M324_ATTN_BWD_NW: 0 = by key count; 4 | 8 = both kernels with that many waves; 84 = dQ with eight waves, dK / dV with four; 48 = the
     // other way round; 2 = the dQ kernel's 64-queries-per-wave form (four waves) beside the eight-wave dK / dV kernel (A/B runs, tests)
-    // Round 6: FOUR waves per workgroup are the default at every size again (three co-resident workgroups hide more of a tile's waits than
+    // Round 6: FOUR waves per workgroup are the default at every size again (two co-resident four-wave workgroups hide more of a tile's waits than
     // one eight-wave workgroup's shared tiles save: dQ + dK/dV at B = 8, L = 3888 1476-1485 us against 1491-1508, B = 32 5757 against 5970;
     // the c3 training step 89.8-90.0 ms against 91.1-91.2, alternated processes on one box; profiles/r06_misc_ab.md section 8).
     const bool big = Lk >= 1024;
