@@ -881,16 +881,26 @@ constexpr int TN_TROW = 512, TN_TOP = 32 * TN_TROW, TN_RING = 4;      // bytes p
 __device__ __forceinline__ void tn_pipe_body(unsigned char* __restrict__ ring_w, const unsigned char* __restrict__ ring_r,
                                              float* __restrict__ scratch, const bf16_t* __restrict__ X, long ldx,
                                              const bf16_t* __restrict__ Y, long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc,
-                                             int ks, long strideC, int ntj) {
+                                             int ks, long strideC, int ntj, int ntiles, int nslices, int xcd) {
     constexpr int TROW = TN_TROW, TOP = TN_TOP;
     constexpr int RING = TN_RING, PPW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int n0 = (blockIdx.x / ntj) * 256, j0 = (blockIdx.x % ntj) * 256;
-    const int mbeg = blockIdx.y * ks;
-    const int mend = blockIdx.y == gridDim.y - 1 ? M : mbeg + ks;      // (mend - mbeg) % 32 == 0 (host-checked)
-    C += (long)blockIdx.y * strideC;
+    // Flat grid of (slice, tile) items.  Workgroup i runs on XCD i % 8: every XCD takes a CONTIGUOUS range of the items (slice-major), so the
+    // workgroups that walk one slice's token rows -- each 256-column panel of a slice is read by N / 256 or Kc / 256 of them -- meet in ONE
+    // L2 instead of eight (round 6: with the (tile, slice) grid in dispatch order a slice's tiles sat on eight XCDs and every workgroup pulled
+    // its panels from HBM / MALL: 290 MB instead of 95 for a 768 x 768 gradient of 31104 tokens; M324_XCD bit 0 = 0: the old order).
+    int item = blockIdx.x;
+    if (xcd) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = item & 7, loc = item >> 3;
+        item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int slice = item / ntiles, tile = item - slice * ntiles;
+    const int n0 = (tile / ntj) * 256, j0 = (tile % ntj) * 256;
+    const int mbeg = slice * ks;
+    const int mend = slice == nslices - 1 ? M : mbeg + ks;      // (mend - mbeg) % 32 == 0 (host-checked)
+    C += (long)slice * strideC;
 
     // staging: piece p = rows 2p, 2p+1 of the half-tile; wave w moves pieces 2w, 2w+1 (rows 4w .. 4w+3) of X and of Y
     const int sr = lane >> 5;                    // row within the piece
@@ -997,9 +1007,9 @@ __device__ __forceinline__ void tn_pipe_body(unsigned char* __restrict__ ring_w,
 
 __global__ __launch_bounds__(512, 2) void gemm_tn_pipe_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ Y,
                                                               long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc,
-                                                              int ks, long strideC, int ntj) {
+                                                              int ks, long strideC, int ntj, int ntiles, int nslices, int xcd) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[TN_RING * 2 * TN_TOP];
-    tn_pipe_body(smem, smem, reinterpret_cast<float*>(smem), X, ldx, Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
+    tn_pipe_body(smem, smem, reinterpret_cast<float*>(smem), X, ldx, Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj, ntiles, nslices, xcd);
 }
 
 // the vectorised epilogue of the LDS-DMA kernel needs 4-column runs to be addressable as float4 / uint2
@@ -1327,8 +1337,9 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
     const bool big = m324::tunable(m324::TUN_GEMM_TN) != 128 && M % 32 == 0 && N % 256 == 0 && Kc % 256 == 0 && M / slices >= 256;
     if (big) {
         const int ntj = Kc / 256;
-        hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3((N / 256) * ntj, slices), dim3(512), 0, (hipStream_t)stream,
-                           (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
+        const int ntiles = (N / 256) * ntj;
+        hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(ntiles * slices), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
+                           (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj, ntiles, slices, m324::tunable(m324::TUN_XCD) & 1);
     } else {
         const int ntj = ceil_div(Kc, 128);
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(N, 128) * ntj, slices), dim3(256), 0, (hipStream_t)stream,
