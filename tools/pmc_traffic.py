@@ -7,6 +7,10 @@ import csv
 import sys
 
 
+BY_GRID = "--by-grid" in sys.argv          # one row per (kernel, grid): the launches of one kernel differ by orders of magnitude in a training step
+TOP = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 14
+
+
 def load(path, name):
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
@@ -14,6 +18,8 @@ def load(path, name):
             continue
         k = r["Kernel_Name"]
         k = k[k.find("::") + 2:][:48] if "anonymous" in k else k[:48]
+        if BY_GRID:
+            k += " grid=" + str(r.get("Grid_Size", r.get("Grid_Size_X", "?")))
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
     return acc
@@ -73,7 +79,7 @@ def main():
         fm = 2.0 * f[k][1] * 1024 / n / 1e6
         wm = w.get(k, [1, 0.0])[1] * 1024 / max(w.get(k, [1, 0.0])[0], 1) / 1e6
         rows.append((n * (fm + wm), k, n, fm, wm))
-    for _, k, n, fm, wm in sorted(rows, reverse=True)[:14]:
+    for _, k, n, fm, wm in sorted(rows, reverse=True)[:TOP]:
         print(f"| {k} | {n} | {fm:.2f} | {wm:.2f} | {fm + wm:.2f} |")
 
 
