@@ -785,17 +785,23 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ Y,
                                                          long ldy, float* __restrict__ C, long ldc, int M, int N, int Kc, int ks,
-                                                         long strideC, int ntj) {
+                                                         long strideC, int ntj, int ntiles, int nslices, int xcd) {
     constexpr int TROW = 256;                    // bytes per LDS row (128 bf16)
     constexpr int TOP = 64 * TROW;               // one operand of a stage: 16 KiB
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 2 * TOP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = (blockIdx.x / ntj) * 128, j0 = (blockIdx.x % ntj) * 128;
-    const int mbeg = blockIdx.y * ks;
-    const int mend = blockIdx.y == gridDim.y - 1 ? M : mbeg + ks;
-    C += (long)blockIdx.y * strideC;
+    int item = blockIdx.x;                       // flat grid of (slice, tile) items, a contiguous slice-major range per XCD: see tn_pipe_body
+    if (xcd) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = item & 7, loc = item >> 3;
+        item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int slice = item / ntiles, tile = item - slice * ntiles;
+    const int n0 = (tile / ntj) * 128, j0 = (tile % ntj) * 128;
+    const int mbeg = slice * ks;
+    const int mend = slice == nslices - 1 ? M : mbeg + ks;
+    C += (long)slice * strideC;
 
     // staging: piece p = rows 4p .. 4p+3; wave w moves pieces 4w .. 4w+3 of X and of Y
     const int sr = lane >> 4, sc = (lane & 15) ^ (4 * sr);       // row within the piece, source chunk of this lane's slot
@@ -1341,9 +1347,9 @@ extern "C" int m324_gemm_tn(const void* X, long ldx, const void* Y, long ldy, fl
         hipLaunchKernelGGL(gemm_tn_pipe_kernel, dim3(ntiles * slices), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
                            (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj, ntiles, slices, m324::tunable(m324::TUN_XCD) & 1);
     } else {
-        const int ntj = ceil_div(Kc, 128);
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(N, 128) * ntj, slices), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj);
+        const int ntj = ceil_div(Kc, 128), ntiles = ceil_div(N, 128) * ntj;
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(ntiles * slices), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,
+                           (const bf16_t*)Y, ldy, C, ldc, M, N, Kc, ks, strideC, ntj, ntiles, slices, m324::tunable(m324::TUN_XCD) & 1);
     }
     M324_CHECK_LAUNCH("m324_gemm_tn");
     return M324_OK;
