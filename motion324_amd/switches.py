@@ -42,7 +42,7 @@ HOST: Dict[str, Tuple[str, str, str]] = {
 LIBRARY: Dict[str, Tuple[str, str]] = {
     "M324_GEMM": ("0", "force a GEMM schedule (v2 | v5 | v9 | v10 | v11 | v12 | v13 | v15); 0 = chooser"),
     "M324_GEMM_TN": ("0", "128: force the 128 x 128 weight-gradient kernel"),
-    "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges, bit 1 4 x 2 group order for wide weights, bit 2 force it; bit 3: the ring GEMMs' look-ahead pieces past the end of K fetch the last stage again (rounds 1-4) instead of nothing (A/B); bit 4: the 256 x 128 kernel (v12) without the residual prefetch (A/B)"),
+    "M324_XCD": ("3", "tile order: bit 0 XCD-contiguous ranges (NN GEMMs; the weight-gradient GEMM's (slice, tile) items since round 6), bit 1 4 x 2 group order for wide weights, bit 2 force it; bit 3: the ring GEMMs' look-ahead pieces past the end of K fetch the last stage again (rounds 1-4) instead of nothing (A/B); bit 4: the 256 x 128 kernel (v12) without the residual prefetch (A/B)"),
     "M324_ATTN_NW": ("0", "attention forward: waves per workgroup (4 | 8); 0 = by sequence length"),
     "M324_ATTN_FLAT": ("1", "XCD-aware flat grid: 1 = global and per-frame attention, 2 = the 8-wave global attention only, 0 = 3-D grid"),
     "M324_ATTN_OCC": ("0", "attention A/B: 1 = no one-tile form, 2 = two workgroups per CU (padded LDS), 3 = the per-frame attentions (row-major V, short sequences) keep the three-stage ring, three workgroups per CU (default since round 6: two stages, four per CU)"),
