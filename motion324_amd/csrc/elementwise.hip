@@ -1258,9 +1258,8 @@ extern "C" int m324_colsum(const void* x, long ld, float* out, int rows, int col
                            int scratch_rows, void* stream) {
     M324_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "m324_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const int esz = dtype == M324_BF16 ? 2 : 4;
+    // four columns per lane: 8-byte (bf16) / 16-byte (fp32) accesses need whole 4-column groups and 16-byte aligned rows
     const bool v4 = cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && (dtype == M324_BF16 || dtype == M324_F32);
-    (void)esz;
     if (scratch && scratch_rows > 1 && rows >= 256) {    // two-stage: row chunks in parallel, then a short deterministic sum
         const int R = scratch_rows < 256 ? scratch_rows : 256;
         if (v4 && ((uintptr_t)scratch % 16) == 0) {

@@ -157,7 +157,6 @@ class FusedAdamW:
         the dgrad GEMMs -- in two flat buffers that ONE m324_weight_mirror launch rewrites after each update (instead of ~115 torch
         casts and ~90 m324_transpose launches per step: Prepared hands the views out while they are current, prepared.register_mirror).
         Weights whose K is not a multiple of the GEMM's K-tile (the 51- and 774-wide point embeddings) stay on Prepared's padding path."""
-        import ctypes as C
         items, o, ot, tiles = [], 0, 0, 0
         for i, p in enumerate(self.params):
             if p.dim() != 2:              # Linear weights only (the token tables are not GEMM operands)
