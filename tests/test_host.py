@@ -114,6 +114,44 @@ def test_prepared_cache_pads_converts_and_invalidates():
     assert cat.shape == (16, 64)
 
 
+def test_prepared_hands_out_an_optimizers_mirror_only_while_it_is_current():
+    """prepared.register_mirror / validate_mirrors (optim.FusedAdamW's bf16 weight copies): Prepared.mat / mat_t / cat_rows return the
+    registered views while the generation counter, the tensor's in-place version and its storage are what they were when the optimizer
+    vouched for them; anything else falls back to the per-weight conversion."""
+    from motion324_amd import prepared
+    from motion324_amd.prepared import Prepared
+    a, b = torch.nn.Parameter(torch.randn(8, 64)), torch.nn.Parameter(torch.randn(8, 64))
+    base = torch.zeros(2 * 8 * 64, dtype=torch.bfloat16)
+    base_t = torch.zeros(2 * 64 * 64, dtype=torch.bfloat16)
+    views = []
+    for i, p in enumerate((a, b)):
+        mat, mat_t = base[i * 512:(i + 1) * 512].view(8, 64), base_t[i * 4096:(i + 1) * 4096].view(64, 64)
+        prepared.register_mirror(p, mat, mat_t, base, i * 512)
+        views.append((mat, mat_t))
+    P = Prepared(torch.device("cpu"), torch.bfloat16)
+    fallback = lambda m: m.t().contiguous()
+    try:
+        assert P.mat(a).data_ptr() != views[0][0].data_ptr()                  # registered, not yet vouched for
+        base.copy_(torch.cat([a.detach().reshape(-1), b.detach().reshape(-1)]).to(torch.bfloat16))
+        prepared.validate_mirrors([a, b])
+        assert P.mat(a).data_ptr() == views[0][0].data_ptr() and P.mat_t(b, fallback).data_ptr() == views[1][1].data_ptr()
+        kv = P.cat_rows((a, b))                                               # neighbours in the flat buffer: one view
+        assert kv.data_ptr() == base.data_ptr() and kv.shape == (16, 64) and torch.equal(kv[8:], b.detach().to(torch.bfloat16))
+        assert P.cat_rows((b, a)).data_ptr() != base.data_ptr()               # not in buffer order: concatenated copies
+        assert Prepared(torch.device("cpu"), torch.float32).mat(a).dtype == torch.float32      # the mirror is bf16 only
+        with torch.no_grad():
+            a.mul_(2.0)                                                       # tracked in-place edit: a's copy is stale, b's is not
+        assert P.mat(a).data_ptr() != views[0][0].data_ptr() and torch.equal(P.mat(a), a.detach().to(torch.bfloat16))
+        assert P.mat(b).data_ptr() == views[1][0].data_ptr()
+        prepared.bump_generation()                                            # raw-pointer update somewhere: nothing is trusted
+        assert P.mat(b).data_ptr() != views[1][0].data_ptr()
+        prepared.validate_mirrors([a, b])
+        assert P.mat(b).data_ptr() == views[1][0].data_ptr()
+    finally:
+        prepared.drop_mirrors([a, b])
+    assert P.mat(b).data_ptr() != views[1][0].data_ptr()
+
+
 def test_precision_follows_override_and_env(monkeypatch):
     import motion324_amd as m
     assert m.compute_dtype() == torch.float32
