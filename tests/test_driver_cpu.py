@@ -43,6 +43,35 @@ def test_known_answers_from_reading_the_reference():
     assert _simulate(8, 12)[0] == list(range(8))          # single forward keeps the predicted frame 0
 
 
+def test_merge_is_one_gather_over_the_plan():
+    """inference.merge_windows (round 6: one index_select over the (window, slot) pairs, index cached per plan) against the plan read
+    slot by slot, for every golden (T, C) pair; the frames the reference overwrites come from ref_pcd."""
+    from motion324_amd.inference import merge_windows, plan_windows
+    ref = torch.arange(5 * 3, dtype=torch.float32).reshape(1, 5, 3) - 100.0
+    for key in _golden():
+        T, C = map(int, key.split(","))
+        windows, out_map = plan_windows(T, C)
+        nW, Cw = len(windows), len(windows[0])
+        outs = (torch.arange(nW * Cw, dtype=torch.float32).reshape(nW, Cw, 1, 1) + torch.zeros((1, 1, 5, 3))).contiguous()
+        for _ in range(2):                                    # second pass: the cached index
+            merged = merge_windows(outs, out_map, ref)
+            assert merged.shape == (1, len(out_map), 5, 3)
+            for t, slot in enumerate(out_map):
+                want = ref[0] if slot is None else outs[slot[0], slot[1]]
+                assert torch.equal(merged[0, t], want), (key, t)
+
+
+def test_graph_shape_key_tells_shapes_byte_frames_and_flags_apart():
+    from motion324_amd.graph import shape_key
+    base = {"rgb_video": torch.zeros((1, 4, 8, 8, 3)), "ref_pcd": torch.zeros((1, 16, 3))}
+    k0 = shape_key(base)
+    assert k0 == shape_key({k: v.clone() for k, v in base.items()})
+    assert shape_key(dict(base, rgb_video=torch.zeros((1, 4, 8, 8, 3), dtype=torch.uint8))) != k0
+    assert shape_key(dict(base, ref_pcd=torch.zeros((1, 17, 3)))) != k0
+    assert shape_key(dict(base, m324_keep_reuse=True)) != k0
+    assert shape_key(dict(base, m324_mesh_tokens=torch.zeros((1, 64, 8)))) != k0
+
+
 def test_partition_is_balanced_and_complete():
     from motion324_amd.parallel import counts, partition
     for n in (0, 1, 7, 8, 9, 23, 256):
