@@ -500,6 +500,20 @@ def test_gemm_tn_weight_gradient(M, N, Kc, slices):
     assert rel_err(out2, wide[:, 64:].float().cpu().double().T @ y.double()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,Kc,slices", [(31104, 768, 768, 28), (8192, 2304, 768, 9), (4096, 768, 3072, 7), (1000, 136, 72, 5)])
+def test_gemm_tn_does_not_depend_on_where_a_tile_runs(tune, M, N, Kc, slices):
+    """Round 6: the weight-gradient kernels take a flat grid of (slice, tile) items, a contiguous slice-major range per XCD (M324_XCD
+    bit 0).  Which XCD computes a tile must not change a single bit of it: same partial sums with the old dispatch order."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    x, y = _q(_rand((M, N), 76), dtype).to(dtype).to(DEV), _q(_rand((M, Kc), 77, 0.3), dtype).to(dtype).to(DEV)
+    flat = ops.gemm_tn(x, y, slices)
+    tune("M324_XCD", "2")
+    plain = ops.gemm_tn(x, y, slices)
+    assert torch.equal(flat, plain)
+    assert rel_err(flat, x.float().cpu().double().T @ y.float().cpu().double()) < 2e-5
+
+
 def test_gemm_tn_tile_kernels_agree(tune):
     """The 256 x 256 pipelined TN kernel (default where it applies) and the 128 x 128 kernel (M324_GEMM_TN=128) compute
     the same sums over the same slices: only the order inside a slice differs."""
